@@ -1,0 +1,110 @@
+"""ctypes binding of libdfd_hip.so (declared in include/dfd_hip.h).
+
+The product path has no CPU or ATen fallback: if the shared object is missing or a
+symbol cannot be resolved, importing/using the kernels raises immediately.
+"""
+
+from __future__ import annotations
+
+import ctypes
+from ctypes import POINTER, Structure, c_double, c_float, c_int, c_int64, c_size_t, c_void_p
+from pathlib import Path
+
+LIB_PATH = Path(__file__).resolve().parent / "libdfd_hip.so"
+
+DFD_OK = 0
+ERRORS = {-1: "DFD_EINVAL", -2: "DFD_EUNSUPPORTED", -3: "DFD_ELAUNCH", -4: "DFD_EWORKSPACE"}
+F32, BF16 = 0, 1
+ACT_NONE, ACT_SILU, ACT_RELU, ACT_GELU = 0, 1, 2, 3
+PRO_NONE, PRO_BN_ACT, PRO_BN_ACT_GATE, PRO_AFFINE2 = 0, 1, 2, 3
+MAX_PARTIALS = 1024
+ADAMW_TABLE_COLS = 5
+ADAMW_HP_LEN = 8
+
+
+class DwShape(Structure):
+    _fields_ = [(n, c_int) for n in ("N", "H", "W", "C", "Ho", "Wo", "k", "stride", "pad_top", "pad_left")]
+
+
+class StemShape(Structure):
+    _fields_ = [(n, c_int) for n in ("N", "H", "W", "Cout", "Ho", "Wo", "k", "stride", "pad_top", "pad_left")]
+
+
+class Prologue(Structure):
+    _fields_ = [
+        ("mode", c_int), ("act", c_int), ("HW", c_int), ("_pad", c_int),
+        ("a2", c_void_p), ("coef", c_void_p), ("gate", c_void_p),
+    ]
+
+
+P = c_void_p
+_PI = POINTER(c_int)
+
+# name -> (restype, argtypes); every symbol include/dfd_hip.h declares
+SIGNATURES: dict[str, tuple] = {
+    "dfd_version": (c_int, []),
+    "dfd_bn_finalize": (c_int, [P, c_int, c_int, c_double, P, P, P, P, c_float, c_float, P, P]),
+    "dfd_bn_eval_coeffs": (c_int, [P, P, P, P, c_float, c_int, P, P]),
+    "dfd_bn_bwd_finalize": (c_int, [P, c_int, c_int, c_double, P, P, c_int, P, P, c_int, P, P]),
+    "dfd_bn_act_apply": (c_int, [c_int, P, P, c_int, P, P, P, c_int, c_int, c_int, P]),
+    "dfd_bn_bwd_reduce": (c_int, [c_int, P, P, P, P, c_int, c_int, c_int, P, c_int, _PI, P]),
+    "dfd_act_bn_bwd": (c_int, [c_int, P, P, P, P, P, c_int, P, c_int, c_int, c_int, P, c_int, _PI, P]),
+    "dfd_pool_act": (c_int, [c_int, P, P, c_int, P, c_int, c_int, c_int, P]),
+    "dfd_pool_bwd_reduce": (c_int, [c_int, P, P, P, c_int, P, c_int, c_int, c_int, P]),
+    "dfd_scale_rows": (c_int, [c_int, P, P, P, c_int, c_int, c_int, P]),
+    "dfd_se_fc_fwd": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, P, P, P]),
+    "dfd_se_fc_bwd": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, P, P, P, P, P, c_int, P, P]),
+    "dfd_dwconv_fwd": (c_int, [c_int, P, P, c_int, P, P, POINTER(DwShape), P, c_int, _PI, P]),
+    "dfd_dwconv_bwd_data": (c_int, [c_int, P, P, P, P, P, P, c_int, P, POINTER(DwShape), P, c_int, _PI, P]),
+    "dfd_dwconv_bwd_weight": (c_int, [c_int, P, P, P, P, P, c_int, P, POINTER(DwShape), c_int, P, c_size_t, P]),
+    "dfd_dwconv_bwd_weight_ws": (c_size_t, [POINTER(DwShape)]),
+    "dfd_pwconv_fwd": (c_int, [c_int, P, POINTER(Prologue), P, P, P, c_int, c_int, c_int, P, c_int, _PI, P]),
+    "dfd_pwconv_wgrad": (c_int, [c_int, P, POINTER(Prologue), c_int, P, POINTER(Prologue), c_int, c_int, P, c_int, P, c_size_t, P]),
+    "dfd_pwconv_wgrad_ws": (c_size_t, [c_int, c_int, c_int]),
+    "dfd_pw_prep_weights": (c_int, [c_int, P, P, P, c_int, c_int, P]),
+    "dfd_stem_conv_fwd": (c_int, [c_int, P, P, P, POINTER(StemShape), P, c_int, _PI, P]),
+    "dfd_stem_conv_wgrad": (c_int, [c_int, P, P, P, P, P, POINTER(StemShape), c_int, P, c_size_t, P]),
+    "dfd_stem_conv_wgrad_ws": (c_size_t, [POINTER(StemShape)]),
+    "dfd_dropout": (c_int, [P, P, c_float, P, c_int, P]),
+    "dfd_linear_fwd": (c_int, [P, P, P, P, c_int, c_int, c_int, P]),
+    "dfd_linear_bwd": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, P]),
+    "dfd_ce_loss": (c_int, [P, P, c_int, c_int, c_float, c_float, P, P, P, P]),
+    "dfd_softmax_argmax": (c_int, [P, c_int, c_int, P, P, P]),
+    "dfd_adamw_step": (c_int, [P, c_int, P, P]),
+}
+
+_lib: ctypes.CDLL | None = None
+
+
+def load() -> ctypes.CDLL:
+    """Load libdfd_hip.so and bind every declared symbol; raises if anything is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build it with `python -m deepfakedetection_amd.build` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback."
+        )
+    lib = ctypes.CDLL(str(LIB_PATH))
+    for name, (restype, argtypes) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as exc:
+            raise RuntimeError(f"libdfd_hip.so does not export {name}") from exc
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib
+
+
+def check(code: int, op: str, detail: str = "") -> None:
+    if code != DFD_OK:
+        raise RuntimeError(f"{op} failed with {ERRORS.get(code, code)} {detail}")
+
+
+__all__ = [
+    "ACT_GELU", "ACT_NONE", "ACT_RELU", "ACT_SILU", "ADAMW_HP_LEN", "ADAMW_TABLE_COLS", "BF16", "F32",
+    "MAX_PARTIALS", "PRO_AFFINE2", "PRO_BN_ACT", "PRO_BN_ACT_GATE", "PRO_NONE", "DwShape", "Prologue",
+    "StemShape", "SIGNATURES", "check", "load", "c_int64",
+]

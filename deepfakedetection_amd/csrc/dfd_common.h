@@ -1,0 +1,173 @@
+// dfd_common.h — shared device helpers for the gfx950 (MI355X / CDNA4) kernels.
+//
+// Conventions used by every kernel in this directory:
+//   * activations are NHWC, i.e. a [rows = N*H*W][C] row-major matrix, element
+//     type T = float or bf16 (storage: unsigned short); C % 8 == 0.
+//   * one lane moves one 16-byte channel vector: 8 bf16 or 4 f32 (VEC).
+//   * statistics, BN coefficients, SE gates, weights' master copies are f32.
+//   * wave = 64 lanes, workgroup = 256 threads (4 waves) unless noted.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/dfd_hip.h"
+
+#define DFD_THREADS 256
+
+struct bf16 { unsigned short x; };  // storage tag; arithmetic is always f32
+
+__device__ __forceinline__ float bf2f(unsigned short h) {
+    return __uint_as_float(((unsigned)h) << 16);
+}
+__device__ __forceinline__ unsigned short f2bf(float f) {
+    __bf16 b = (__bf16)f;  // v_cvt_pk_bf16_f32: RNE, NaN stays NaN
+    return __builtin_bit_cast(unsigned short, b);
+}
+__device__ __forceinline__ unsigned pack_bf2(float lo, float hi) {
+    return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
+}
+// round an f32 to what it would be after a store/load through T
+template <typename T> __device__ __forceinline__ float round_to(float f);
+template <> __device__ __forceinline__ float round_to<float>(float f) { return f; }
+template <> __device__ __forceinline__ float round_to<bf16>(float f) { return bf2f(f2bf(f)); }
+
+// ---------------------------------------------------------------------------
+// 16-byte channel vectors
+// ---------------------------------------------------------------------------
+template <typename T> struct Vec;
+template <> struct Vec<float> {
+    static constexpr int N = 4;
+    __device__ __forceinline__ static void load(const float* p, float (&v)[4]) {
+        float4 q = *reinterpret_cast<const float4*>(p);
+        v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+    }
+    __device__ __forceinline__ static void store(float* p, const float (&v)[4]) {
+        *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+    __device__ __forceinline__ static void zero(float* p) {
+        *reinterpret_cast<float4*>(p) = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+};
+template <> struct Vec<bf16> {
+    static constexpr int N = 8;
+    __device__ __forceinline__ static void unpack(const uint4& q, float (&v)[8]) {
+        v[0] = __uint_as_float(q.x << 16); v[1] = __uint_as_float(q.x & 0xffff0000u);
+        v[2] = __uint_as_float(q.y << 16); v[3] = __uint_as_float(q.y & 0xffff0000u);
+        v[4] = __uint_as_float(q.z << 16); v[5] = __uint_as_float(q.z & 0xffff0000u);
+        v[6] = __uint_as_float(q.w << 16); v[7] = __uint_as_float(q.w & 0xffff0000u);
+    }
+    __device__ __forceinline__ static uint4 pack(const float (&v)[8]) {
+        uint4 q;
+        q.x = pack_bf2(v[0], v[1]); q.y = pack_bf2(v[2], v[3]);
+        q.z = pack_bf2(v[4], v[5]); q.w = pack_bf2(v[6], v[7]);
+        return q;
+    }
+    __device__ __forceinline__ static void load(const bf16* p, float (&v)[8]) {
+        uint4 q = *reinterpret_cast<const uint4*>(p);
+        unpack(q, v);
+    }
+    __device__ __forceinline__ static void store(bf16* p, const float (&v)[8]) {
+        *reinterpret_cast<uint4*>(p) = pack(v);
+    }
+    __device__ __forceinline__ static void zero(bf16* p) {
+        *reinterpret_cast<uint4*>(p) = make_uint4(0, 0, 0, 0);
+    }
+};
+
+// load VEC consecutive f32 parameters (per-channel coefficients)
+template <int N> __device__ __forceinline__ void load_f32(const float* p, float (&v)[N]) {
+#pragma unroll
+    for (int i = 0; i < N; i += 4) {
+        float4 q = *reinterpret_cast<const float4*>(p + i);
+        v[i] = q.x; v[i + 1] = q.y; v[i + 2] = q.z; v[i + 3] = q.w;
+    }
+}
+template <int N> __device__ __forceinline__ void store_f32(float* p, const float (&v)[N]) {
+#pragma unroll
+    for (int i = 0; i < N; i += 4)
+        *reinterpret_cast<float4*>(p + i) = make_float4(v[i], v[i + 1], v[i + 2], v[i + 3]);
+}
+
+// ---------------------------------------------------------------------------
+// activations (DFD_ACT_*)
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float sigmoid_f(float z) {
+    return __builtin_amdgcn_rcpf(1.0f + __expf(-z));
+}
+template <int ACT> __device__ __forceinline__ float act_fwd(float z) {
+    if constexpr (ACT == DFD_ACT_SILU) return z * sigmoid_f(z);
+    else if constexpr (ACT == DFD_ACT_RELU) return z > 0.f ? z : 0.f;
+    else if constexpr (ACT == DFD_ACT_GELU) return 0.5f * z * (1.0f + erff(z * 0.70710678118654752f));
+    else return z;
+}
+// d act(z) / dz
+template <int ACT> __device__ __forceinline__ float act_grad(float z) {
+    if constexpr (ACT == DFD_ACT_SILU) {
+        float s = sigmoid_f(z);
+        return s * (1.0f + z * (1.0f - s));
+    } else if constexpr (ACT == DFD_ACT_RELU) {
+        return z > 0.f ? 1.f : 0.f;
+    } else if constexpr (ACT == DFD_ACT_GELU) {
+        float cdf = 0.5f * (1.0f + erff(z * 0.70710678118654752f));
+        float pdf = 0.39894228040143268f * __expf(-0.5f * z * z);
+        return cdf + z * pdf;
+    } else {
+        return 1.f;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// channel mapping shared by the row-streaming kernels: thread t owns channel
+// vector (vchunk*cvb + t % cvb) and row lane t / cvb; cvb divides C/VEC.
+// ---------------------------------------------------------------------------
+struct ChanMap {
+    int cvb;   // channel vectors per workgroup
+    int rpb;   // row lanes per workgroup = 256 / cvb
+    int nvc;   // number of channel-vector chunks = (C/VEC) / cvb
+};
+static inline ChanMap make_chanmap(int C, int vec) {
+    int cv = C / vec;
+    int cvb = cv;
+    if (cv > 64) {
+        cvb = 1;
+        for (int d = 64; d >= 1; --d) if (cv % d == 0) { cvb = d; break; }
+    }
+    ChanMap m;
+    m.cvb = cvb;
+    m.rpb = DFD_THREADS / cvb;
+    m.nvc = cv / cvb;
+    return m;
+}
+
+// block reduction of NQ*VEC per-thread f32 partial sums over the row lanes that
+// share a channel vector; the result lands in the rl == 0 threads. red must hold
+// DFD_THREADS * NV floats.
+template <int NV>
+__device__ __forceinline__ void reduce_rowlanes(float (&acc)[NV], float* red, int cvb, int rpb, int vl, int rl, bool active) {
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) red[i * DFD_THREADS + t] = active ? acc[i] : 0.f;
+    __syncthreads();
+    if (rl == 0 && active) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            float s = 0.f;
+            for (int r = 0; r < rpb; ++r) s += red[i * DFD_THREADS + r * cvb + vl];
+            acc[i] = s;
+        }
+    }
+    __syncthreads();
+}
+
+#define DFD_CHECK_LAUNCH() (hipGetLastError() == hipSuccess ? DFD_OK : DFD_ELAUNCH)
+
+// dispatch a runtime activation code to a constexpr int ACT inside the body
+#define DISPATCH_ACT(ACTV, ...)                                                      \
+    switch (ACTV) {                                                                  \
+        case DFD_ACT_NONE: { constexpr int ACT = DFD_ACT_NONE; __VA_ARGS__; } break; \
+        case DFD_ACT_SILU: { constexpr int ACT = DFD_ACT_SILU; __VA_ARGS__; } break; \
+        case DFD_ACT_RELU: { constexpr int ACT = DFD_ACT_RELU; __VA_ARGS__; } break; \
+        case DFD_ACT_GELU: { constexpr int ACT = DFD_ACT_GELU; __VA_ARGS__; } break; \
+        default: return DFD_EUNSUPPORTED;                                            \
+    }
+
+int dfd_launch_sum_partials(const float* partials, int P, long L, float* out, int accumulate, hipStream_t st);

@@ -1,0 +1,594 @@
+// dfd_misc.hip — the small kernels around the conv stack: squeeze-excite MLP, stem
+// convolution, classifier head, label-smoothed cross entropy, softmax/argmax and the
+// fused multi-tensor AdamW step.  All f32 except the stem's output / gradient tensors.
+#include "dfd_common.h"
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+template <int ACT> __device__ __forceinline__ float act_rt(float z) { return act_fwd<ACT>(z); }
+
+// ===========================================================================
+// squeeze-excite MLP
+// ===========================================================================
+#define SE_MAX_C 4096
+#define SE_MAX_R 128
+
+template <int ACT>
+__global__ void __launch_bounds__(DFD_THREADS)
+k_se_fc_fwd(const float* __restrict__ pooled, const float* __restrict__ w1, const float* __restrict__ b1,
+            const float* __restrict__ w2, const float* __restrict__ b2, int C, int R, float* __restrict__ hpre,
+            float* __restrict__ gate) {
+    __shared__ float sp[SE_MAX_C];
+    __shared__ float sh[SE_MAX_R];
+    const int n = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    for (int c = t; c < C; c += DFD_THREADS) sp[c] = pooled[(long)n * C + c];
+    __syncthreads();
+    for (int r = wave; r < R; r += 4) {
+        float s = 0.f;
+        for (int c = lane; c < C; c += 64) s = fmaf(w1[(long)r * C + c], sp[c], s);
+        s = wave_sum(s);
+        if (lane == 0) {
+            const float z = s + (b1 ? b1[r] : 0.f);
+            hpre[(long)n * R + r] = z;
+            sh[r] = act_rt<ACT>(z);
+        }
+    }
+    __syncthreads();
+    for (int c = t; c < C; c += DFD_THREADS) {
+        float s = b2 ? b2[c] : 0.f;
+        for (int r = 0; r < R; ++r) s = fmaf(w2[(long)c * R + r], sh[r], s);
+        gate[(long)n * C + c] = sigmoid_f(s);
+    }
+}
+
+// per-image part of the backward: dg_pre, dhpre, hact -> ws ; dpooled
+template <int ACT>
+__global__ void __launch_bounds__(DFD_THREADS)
+k_se_fc_bwd_a(const float* __restrict__ dgate, const float* __restrict__ gate, const float* __restrict__ hpre,
+              const float* __restrict__ w1, const float* __restrict__ w2, int N, int C, int R,
+              float* __restrict__ dpooled, float* __restrict__ ws) {
+    __shared__ float sg[SE_MAX_C];
+    __shared__ float sd[SE_MAX_R];
+    const int n = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    float* ws_g = ws;                         // [N][C]
+    float* ws_dh = ws + (long)N * C;          // [N][R]
+    float* ws_h = ws_dh + (long)N * R;        // [N][R]
+    for (int c = t; c < C; c += DFD_THREADS) {
+        const float g = gate[(long)n * C + c];
+        const float v = dgate[(long)n * C + c] * g * (1.f - g);
+        sg[c] = v;
+        ws_g[(long)n * C + c] = v;
+    }
+    __syncthreads();
+    for (int r = wave; r < R; r += 4) {
+        float s = 0.f;
+        for (int c = lane; c < C; c += 64) s = fmaf(sg[c], w2[(long)c * R + r], s);
+        s = wave_sum(s);
+        if (lane == 0) {
+            const float z = hpre[(long)n * R + r];
+            const float d = s * act_grad<ACT>(z);
+            sd[r] = d;
+            ws_dh[(long)n * R + r] = d;
+            ws_h[(long)n * R + r] = act_rt<ACT>(z);
+        }
+    }
+    __syncthreads();
+    for (int c = t; c < C; c += DFD_THREADS) {
+        float s = 0.f;
+        for (int r = 0; r < R; ++r) s = fmaf(sd[r], w1[(long)r * C + c], s);
+        dpooled[(long)n * C + c] = s;
+    }
+}
+
+// weight gradients: thread (c, rl) owns r = rl, rl+4, ... ; sums over images in order
+#define SE_RPT 32
+__global__ void __launch_bounds__(DFD_THREADS)
+k_se_fc_bwd_w(const float* __restrict__ pooled, const float* __restrict__ ws, int N, int C, int R,
+              float* __restrict__ dw1, float* __restrict__ db1, float* __restrict__ dw2, float* __restrict__ db2,
+              int accumulate) {
+    const float* ws_g = ws;
+    const float* ws_dh = ws + (long)N * C;
+    const float* ws_h = ws_dh + (long)N * R;
+    const int t = threadIdx.x, cl = t & 63, rl = t >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    float a1[SE_RPT], a2[SE_RPT];
+#pragma unroll
+    for (int i = 0; i < SE_RPT; ++i) { a1[i] = 0.f; a2[i] = 0.f; }
+    float sb2 = 0.f;
+    if (c < C) {
+        for (int n = 0; n < N; ++n) {
+            const float g = ws_g[(long)n * C + c], pc = pooled[(long)n * C + c];
+            sb2 += g;
+#pragma unroll
+            for (int i = 0; i < SE_RPT; ++i) {
+                const int r = rl + 4 * i;
+                if (r < R) {
+                    a2[i] = fmaf(g, ws_h[(long)n * R + r], a2[i]);
+                    a1[i] = fmaf(ws_dh[(long)n * R + r], pc, a1[i]);
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < SE_RPT; ++i) {
+            const int r = rl + 4 * i;
+            if (r < R) {
+                float* p2 = dw2 + (long)c * R + r;
+                float* p1 = dw1 + (long)r * C + c;
+                *p2 = (accumulate ? *p2 : 0.f) + a2[i];
+                *p1 = (accumulate ? *p1 : 0.f) + a1[i];
+            }
+        }
+        if (rl == 0 && db2) db2[c] = (accumulate ? db2[c] : 0.f) + sb2;
+    }
+    if (blockIdx.x == 0 && db1) {
+        for (int r = t; r < R; r += DFD_THREADS) {
+            float s = 0.f;
+            for (int n = 0; n < N; ++n) s += ws_dh[(long)n * R + r];
+            db1[r] = (accumulate ? db1[r] : 0.f) + s;
+        }
+    }
+}
+
+extern "C" int dfd_se_fc_fwd(const float* pooled, const float* w1, const float* b1, const float* w2, const float* b2,
+                             int N, int C, int R, int act, float* hpre, float* gate, dfd_stream stream) {
+    if (!pooled || !w1 || !w2 || !hpre || !gate || N < 1 || C < 1 || R < 1) return DFD_EINVAL;
+    if (C > SE_MAX_C || R > SE_MAX_R) return DFD_EUNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    DISPATCH_ACT(act, {
+        hipLaunchKernelGGL((k_se_fc_fwd<ACT>), dim3(N), dim3(DFD_THREADS), 0, st, pooled, w1, b1, w2, b2, C, R, hpre, gate);
+    });
+    return DFD_CHECK_LAUNCH();
+}
+
+extern "C" int dfd_se_fc_bwd(const float* dgate, const float* gate, const float* hpre, const float* pooled,
+                             const float* w1, const float* w2, int N, int C, int R, int act, float* dpooled,
+                             float* dw1, float* db1, float* dw2, float* db2, int accumulate, float* ws,
+                             dfd_stream stream) {
+    if (!dgate || !gate || !hpre || !pooled || !w1 || !w2 || !dpooled || !ws || N < 1 || C < 1 || R < 1) return DFD_EINVAL;
+    if (C > SE_MAX_C || R > SE_MAX_R || R > 4 * SE_RPT) return DFD_EUNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    DISPATCH_ACT(act, {
+        hipLaunchKernelGGL((k_se_fc_bwd_a<ACT>), dim3(N), dim3(DFD_THREADS), 0, st, dgate, gate, hpre, w1, w2, N, C, R, dpooled, ws);
+    });
+    if (hipGetLastError() != hipSuccess) return DFD_ELAUNCH;
+    if (dw1 && dw2) {
+        hipLaunchKernelGGL(k_se_fc_bwd_w, dim3((C + 63) / 64), dim3(DFD_THREADS), 0, st, pooled, ws, N, C, R, dw1, db1, dw2,
+                           db2, accumulate);
+    }
+    return DFD_CHECK_LAUNCH();
+}
+
+// ===========================================================================
+// stem convolution: [N][H][W][3] f32 -> [N][Ho][Wo][Co] T
+// ===========================================================================
+#define STEM_MAX_CO 64
+template <typename T, int K>
+__global__ void __launch_bounds__(DFD_THREADS)
+k_stem_fwd(const float* __restrict__ x, const float* __restrict__ w, T* __restrict__ y, dfd_stem_shape s, ChanMap cm,
+           float* __restrict__ partials, int stats) {
+    constexpr int V = Vec<T>::N;
+    constexpr int TAPS = 3 * K * K;
+    __shared__ __attribute__((aligned(16))) float wl[TAPS * STEM_MAX_CO];   // [ci][kh][kw][Co]
+    __shared__ float red[DFD_THREADS * 2 * V];
+    const int t = threadIdx.x, vl = t % cm.cvb, rl = t / cm.cvb;
+    const bool active = rl < cm.rpb;
+    const int Co = s.Cout, c0 = vl * V;
+    for (int i = t; i < TAPS * Co; i += DFD_THREADS) {
+        const int tap = i / Co, co = i - tap * Co;          // tap = (ci*K + kh)*K + kw
+        wl[tap * Co + co] = round_to<T>(w[(long)co * TAPS + tap]);
+    }
+    __syncthreads();
+    float s1[V], s2[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
+    const long npix = (long)s.N * s.Ho * s.Wo;
+    if (active) {
+        const long step = (long)gridDim.x * cm.rpb;
+        for (long pix = (long)blockIdx.x * cm.rpb + rl; pix < npix; pix += step) {
+            const int ox = (int)(pix % s.Wo);
+            const long tq = pix / s.Wo;
+            const int oy = (int)(tq % s.Ho);
+            const long n = tq / s.Ho;
+            float acc[V];
+#pragma unroll
+            for (int j = 0; j < V; ++j) acc[j] = 0.f;
+#pragma unroll
+            for (int kh = 0; kh < K; ++kh) {
+                const int iy = oy * s.stride - s.pad_top + kh;
+                if (iy < 0 || iy >= s.H) continue;
+#pragma unroll
+                for (int kw = 0; kw < K; ++kw) {
+                    const int ix = ox * s.stride - s.pad_left + kw;
+                    if (ix < 0 || ix >= s.W) continue;
+                    const float* px = x + ((n * s.H + iy) * (long)s.W + ix) * 3;
+#pragma unroll
+                    for (int ci = 0; ci < 3; ++ci) {
+                        const float xv = round_to<T>(px[ci]);
+                        float wv[V];
+                        load_f32<V>(wl + ((ci * K + kh) * K + kw) * Co + c0, wv);
+#pragma unroll
+                        for (int j = 0; j < V; ++j) acc[j] = fmaf(xv, wv[j], acc[j]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < V; ++j) {
+                const float r = round_to<T>(acc[j]);
+                acc[j] = r;
+                s1[j] += r;
+                s2[j] = fmaf(r, r, s2[j]);
+            }
+            Vec<T>::store(y + pix * Co + c0, acc);
+        }
+    }
+    if (stats) {
+        float acc2[2 * V];
+#pragma unroll
+        for (int j = 0; j < V; ++j) { acc2[j] = s1[j]; acc2[V + j] = s2[j]; }
+        reduce_rowlanes<2 * V>(acc2, red, cm.cvb, cm.rpb, vl, rl, active);
+        if (rl == 0) {
+            float* p = partials + (long)blockIdx.x * 2 * Co;
+            float a0[V], a1[V];
+#pragma unroll
+            for (int j = 0; j < V; ++j) { a0[j] = acc2[j]; a1[j] = acc2[V + j]; }
+            store_f32<V>(p + c0, a0);
+            store_f32<V>(p + Co + c0, a1);
+        }
+    }
+}
+
+// weight gradient.  A workgroup stages chunks of 64 output pixels: dy [64][Co] (after
+// the affine map) and the 3*K*K input patch values [64][TAPS]; thread (co, g) owns
+// taps g, g+G, ... ; partial layout [workgroup][Co][TAPS].
+#define STEM_CHUNK 64
+#define STEM_TPT 8
+template <typename T, int K>
+__global__ void __launch_bounds__(DFD_THREADS)
+k_stem_wgrad(const float* __restrict__ x, const T* __restrict__ dz, const T* __restrict__ yraw,
+             const float* __restrict__ coef, dfd_stem_shape s, float* __restrict__ ws) {
+    constexpr int V = Vec<T>::N;
+    constexpr int TAPS = 3 * K * K;
+    __shared__ float sdy[STEM_CHUNK * STEM_MAX_CO];
+    __shared__ float sx[STEM_CHUNK * TAPS];
+    const int t = threadIdx.x, Co = s.Cout;
+    const int G = DFD_THREADS / Co;
+    const int co = t % Co, g = t / Co;
+    const bool on = g < G;
+    float acc[STEM_TPT];
+#pragma unroll
+    for (int i = 0; i < STEM_TPT; ++i) acc[i] = 0.f;
+    const long npix = (long)s.N * s.Ho * s.Wo;
+    const int CV = Co / V;
+    for (long base = (long)blockIdx.x * STEM_CHUNK; base < npix; base += (long)gridDim.x * STEM_CHUNK) {
+        __syncthreads();
+        for (int i = t; i < STEM_CHUNK * CV; i += DFD_THREADS) {
+            const int p = i / CV, v = i - p * CV;
+            const long pix = base + p;
+            float d[V];
+#pragma unroll
+            for (int j = 0; j < V; ++j) d[j] = 0.f;
+            if (pix < npix) {
+                Vec<T>::load(dz + pix * Co + v * V, d);
+                if (coef) {
+                    float yv[V], ka[V], kb[V], kc[V];
+                    Vec<T>::load(yraw + pix * Co + v * V, yv);
+                    load_f32<V>(coef + v * V, ka);
+                    load_f32<V>(coef + Co + v * V, kb);
+                    load_f32<V>(coef + 2 * Co + v * V, kc);
+#pragma unroll
+                    for (int j = 0; j < V; ++j) d[j] = round_to<T>(fmaf(ka[j], d[j], fmaf(kb[j], yv[j], kc[j])));
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < V; ++j) sdy[p * Co + v * V + j] = d[j];
+        }
+        for (int i = t; i < STEM_CHUNK * TAPS; i += DFD_THREADS) {
+            const int p = i / TAPS, tap = i - p * TAPS;
+            const long pix = base + p;
+            float v = 0.f;
+            if (pix < npix) {
+                const int ci = tap / (K * K), kk = tap - ci * K * K, kh = kk / K, kw = kk - kh * K;
+                const int ox = (int)(pix % s.Wo);
+                const long tq = pix / s.Wo;
+                const int oy = (int)(tq % s.Ho);
+                const long n = tq / s.Ho;
+                const int iy = oy * s.stride - s.pad_top + kh, ix = ox * s.stride - s.pad_left + kw;
+                if (iy >= 0 && iy < s.H && ix >= 0 && ix < s.W) v = round_to<T>(x[((n * s.H + iy) * (long)s.W + ix) * 3 + ci]);
+            }
+            sx[p * TAPS + tap] = v;
+        }
+        __syncthreads();
+        if (on) {
+            for (int p = 0; p < STEM_CHUNK; ++p) {
+                const float d = sdy[p * Co + co];
+#pragma unroll
+                for (int i = 0; i < STEM_TPT; ++i) {
+                    const int tap = g + i * G;
+                    if (tap < TAPS) acc[i] = fmaf(d, sx[p * TAPS + tap], acc[i]);
+                }
+            }
+        }
+    }
+    if (on) {
+        float* o = ws + (long)blockIdx.x * Co * TAPS;
+#pragma unroll
+        for (int i = 0; i < STEM_TPT; ++i) {
+            const int tap = g + i * G;
+            if (tap < TAPS) o[co * TAPS + tap] = acc[i];
+        }
+    }
+}
+
+static bool stem_ok(const dfd_stem_shape* s) {
+    if (!s || s->N < 1 || s->H < 1 || s->W < 1 || s->Ho < 1 || s->Wo < 1) return false;
+    if (s->Cout < 8 || s->Cout % 8 || s->Cout > STEM_MAX_CO) return false;
+    if (s->k != 3 || s->stride < 1 || s->stride > 2) return false;
+    if (s->pad_top < 0 || s->pad_left < 0 || s->pad_top >= s->k || s->pad_left >= s->k) return false;
+    return true;
+}
+
+template <typename T>
+static int stem_fwd_t(const float* x, const float* w, void* y, const dfd_stem_shape* s, float* partials, int pcap,
+                      int* nparts, hipStream_t st) {
+    const ChanMap cm = make_chanmap(s->Cout, Vec<T>::N);
+    const long npix = (long)s->N * s->Ho * s->Wo;
+    int cap = partials ? (pcap < DFD_MAX_PARTIALS ? pcap : DFD_MAX_PARTIALS) : DFD_MAX_PARTIALS;
+    long want = (npix + (long)cm.rpb * 4 - 1) / ((long)cm.rpb * 4);
+    if (want > cap) want = cap;
+    if (want < 1) want = 1;
+    if (partials) *nparts = (int)want;
+    hipLaunchKernelGGL((k_stem_fwd<T, 3>), dim3((unsigned)want), dim3(DFD_THREADS), 0, st, x, w, (T*)y, *s, cm, partials,
+                       partials ? 1 : 0);
+    return DFD_CHECK_LAUNCH();
+}
+extern "C" int dfd_stem_conv_fwd(int dtype, const float* x, const float* w, void* y, const dfd_stem_shape* s,
+                                 float* partials, int pcap, int* nparts, dfd_stream stream) {
+    if (!x || !w || !y) return DFD_EINVAL;
+    if (!stem_ok(s)) return s && s->k != 3 ? DFD_EUNSUPPORTED : DFD_EINVAL;
+    if (partials && (!nparts || pcap < 1)) return DFD_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == DFD_BF16) return stem_fwd_t<bf16>(x, w, y, s, partials, pcap, nparts, st);
+    if (dtype == DFD_F32) return stem_fwd_t<float>(x, w, y, s, partials, pcap, nparts, st);
+    return DFD_EINVAL;
+}
+
+static int stem_wgrad_blocks(const dfd_stem_shape* s) {
+    const long npix = (long)s->N * s->Ho * s->Wo;
+    long b = (npix + STEM_CHUNK * 8 - 1) / (STEM_CHUNK * 8);
+    if (b > 1024) b = 1024;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+extern "C" size_t dfd_stem_conv_wgrad_ws(const dfd_stem_shape* s) {
+    if (!stem_ok(s)) return 0;
+    return (size_t)1024 * s->Cout * 27 * 4;
+}
+extern "C" int dfd_stem_conv_wgrad(int dtype, const float* x, const void* dz, const void* y, const float* coef,
+                                   float* dw, const dfd_stem_shape* s, int accumulate, float* ws, size_t ws_bytes,
+                                   dfd_stream stream) {
+    if (!x || !dz || !dw || !ws || (coef && !y)) return DFD_EINVAL;
+    if (!stem_ok(s)) return DFD_EINVAL;
+    if (DFD_THREADS / s->Cout < 1 || (27 + DFD_THREADS / s->Cout - 1) / (DFD_THREADS / s->Cout) > STEM_TPT) return DFD_EUNSUPPORTED;
+    const int P = stem_wgrad_blocks(s);
+    if ((size_t)P * s->Cout * 27 * 4 > ws_bytes) return DFD_EWORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == DFD_BF16)
+        hipLaunchKernelGGL((k_stem_wgrad<bf16, 3>), dim3(P), dim3(DFD_THREADS), 0, st, x, (const bf16*)dz, (const bf16*)y, coef, *s, ws);
+    else if (dtype == DFD_F32)
+        hipLaunchKernelGGL((k_stem_wgrad<float, 3>), dim3(P), dim3(DFD_THREADS), 0, st, x, (const float*)dz, (const float*)y, coef, *s, ws);
+    else
+        return DFD_EINVAL;
+    if (hipGetLastError() != hipSuccess) return DFD_ELAUNCH;
+    // ws is [P][Co][27] and torch's weight is [Co][3][3][3] = [Co][27]
+    return dfd_launch_sum_partials(ws, P, (long)s->Cout * 27, dw, accumulate, st);
+}
+
+// ===========================================================================
+// classifier head
+// ===========================================================================
+__global__ void k_dropout(const float* __restrict__ x, const float* __restrict__ u, float p, float inv_keep,
+                          float* __restrict__ out, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = u[i] >= p ? x[i] * inv_keep : 0.f;
+}
+extern "C" int dfd_dropout(const float* x, const float* u, float p, float* out, int n, dfd_stream stream) {
+    if (!x || !u || !out || n < 1 || p < 0.f || p >= 1.f) return DFD_EINVAL;
+    hipLaunchKernelGGL(k_dropout, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, u, p, 1.0f / (1.0f - p), out, n);
+    return DFD_CHECK_LAUNCH();
+}
+
+__global__ void __launch_bounds__(DFD_THREADS)
+k_linear_fwd(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b, float* __restrict__ out,
+             int K, int J) {
+    const int n = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float* xr = x + (long)n * K;
+    for (int j = wave; j < J; j += 4) {
+        const float* wr = w + (long)j * K;
+        float s = 0.f;
+        for (int k = lane; k < K; k += 64) s = fmaf(xr[k], wr[k], s);
+        s = wave_sum(s);
+        if (lane == 0) out[(long)n * J + j] = s + (b ? b[j] : 0.f);
+    }
+}
+extern "C" int dfd_linear_fwd(const float* x, const float* w, const float* b, float* out, int N, int K, int J,
+                              dfd_stream stream) {
+    if (!x || !w || !out || N < 1 || K < 1 || J < 1) return DFD_EINVAL;
+    hipLaunchKernelGGL(k_linear_fwd, dim3(N), dim3(DFD_THREADS), 0, (hipStream_t)stream, x, w, b, out, K, J);
+    return DFD_CHECK_LAUNCH();
+}
+
+__global__ void k_linear_bwd_x(const float* __restrict__ dout, const float* __restrict__ w, float* __restrict__ dx, int K, int J) {
+    const int n = blockIdx.y, k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= K) return;
+    float s = 0.f;
+    for (int j = 0; j < J; ++j) s = fmaf(dout[(long)n * J + j], w[(long)j * K + k], s);
+    dx[(long)n * K + k] = s;
+}
+__global__ void k_linear_bwd_w(const float* __restrict__ dout, const float* __restrict__ x, float* __restrict__ dw,
+                               float* __restrict__ db, int N, int K, int J, int accumulate) {
+    const int j = blockIdx.y, k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < K) {
+        float s = 0.f;
+        for (int n = 0; n < N; ++n) s = fmaf(dout[(long)n * J + j], x[(long)n * K + k], s);
+        float* p = dw + (long)j * K + k;
+        *p = (accumulate ? *p : 0.f) + s;
+    }
+    if (db && blockIdx.x == 0 && threadIdx.x == 0) {
+        float s = 0.f;
+        for (int n = 0; n < N; ++n) s += dout[(long)n * J + j];
+        db[j] = (accumulate ? db[j] : 0.f) + s;
+    }
+}
+extern "C" int dfd_linear_bwd(const float* dout, const float* x, const float* w, float* dx, float* dw, float* db,
+                              int N, int K, int J, int accumulate, dfd_stream stream) {
+    if (!dout || N < 1 || K < 1 || J < 1) return DFD_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    if (dx) {
+        if (!w) return DFD_EINVAL;
+        hipLaunchKernelGGL(k_linear_bwd_x, dim3((K + 255) / 256, N), dim3(256), 0, st, dout, w, dx, K, J);
+    }
+    if (dw) {
+        if (!x) return DFD_EINVAL;
+        hipLaunchKernelGGL(k_linear_bwd_w, dim3((K + 255) / 256, J), dim3(256), 0, st, dout, x, dw, db, N, K, J, accumulate);
+    }
+    return DFD_CHECK_LAUNCH();
+}
+
+// ===========================================================================
+// label-smoothed cross entropy (mean reduction), softmax / argmax
+// ===========================================================================
+__device__ __forceinline__ float block_reduce(float v, float* sm, bool is_max) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    v = is_max ? wave_max(v) : wave_sum(v);
+    __syncthreads();
+    if (lane == 0) sm[wave] = v;
+    __syncthreads();
+    float r = sm[0];
+    for (int i = 1; i < DFD_THREADS / 64; ++i) r = is_max ? fmaxf(r, sm[i]) : r + sm[i];
+    return r;
+}
+
+__global__ void __launch_bounds__(DFD_THREADS)
+k_ce_rows(const float* __restrict__ logits, const int64_t* __restrict__ targets, int N, int J, float eps, float gscale,
+          float* __restrict__ row_loss, float* __restrict__ dlogits) {
+    __shared__ float sm[4];
+    const int n = blockIdx.x, t = threadIdx.x;
+    const float* lr = logits + (long)n * J;
+    float mx = -INFINITY;
+    for (int j = t; j < J; j += DFD_THREADS) mx = fmaxf(mx, lr[j]);
+    mx = block_reduce(mx, sm, true);
+    float se = 0.f, sl = 0.f;
+    for (int j = t; j < J; j += DFD_THREADS) { const float d = lr[j] - mx; se += __expf(d); sl += d; }
+    se = block_reduce(se, sm, false);
+    sl = block_reduce(sl, sm, false);
+    const float lse = __logf(se);
+    const int tgt = (int)targets[n];
+    // sum_j logp_j = sl - J*lse ; logp_t = lr[t] - mx - lse
+    if (t == 0) {
+        const float logp_t = lr[tgt] - mx - lse;
+        const float smooth = -(sl - (float)J * lse) / (float)J;
+        row_loss[n] = (1.f - eps) * (-logp_t) + eps * smooth;
+    }
+    if (dlogits) {
+        const float inv = 1.f / se, sc = gscale / (float)N;
+        for (int j = t; j < J; j += DFD_THREADS) {
+            const float p = __expf(lr[j] - mx) * inv;
+            const float q = eps / (float)J + (j == tgt ? 1.f - eps : 0.f);
+            dlogits[(long)n * J + j] = (p - q) * sc;
+        }
+    }
+}
+__global__ void k_mean_rows(const float* __restrict__ row_loss, int N, float* __restrict__ loss) {
+    __shared__ float sm[4];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < N; i += DFD_THREADS) s += row_loss[i];
+    s = block_reduce(s, sm, false);
+    if (threadIdx.x == 0) *loss = s / (float)N;
+}
+extern "C" int dfd_ce_loss(const float* logits, const int64_t* targets, int N, int J, float label_smoothing,
+                           float grad_scale, float* row_loss, float* loss, float* dlogits, dfd_stream stream) {
+    if (!logits || !targets || !row_loss || !loss || N < 1 || J < 1) return DFD_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_ce_rows, dim3(N), dim3(DFD_THREADS), 0, st, logits, targets, N, J, label_smoothing, grad_scale,
+                       row_loss, dlogits);
+    hipLaunchKernelGGL(k_mean_rows, dim3(1), dim3(DFD_THREADS), 0, st, row_loss, N, loss);
+    return DFD_CHECK_LAUNCH();
+}
+
+__global__ void __launch_bounds__(DFD_THREADS)
+k_softmax_argmax(const float* __restrict__ logits, int J, float* __restrict__ probs, int64_t* __restrict__ preds) {
+    __shared__ float sm[4];
+    __shared__ int si[4];
+    const int n = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const float* lr = logits + (long)n * J;
+    float mx = -INFINITY;
+    for (int j = t; j < J; j += DFD_THREADS) mx = fmaxf(mx, lr[j]);
+    mx = block_reduce(mx, sm, true);
+    float se = 0.f;
+    for (int j = t; j < J; j += DFD_THREADS) se += __expf(lr[j] - mx);
+    se = block_reduce(se, sm, false);
+    const float inv = 1.f / se;
+    float bp = -1.f; int bi = 0x7fffffff;
+    for (int j = t; j < J; j += DFD_THREADS) {
+        const float p = __expf(lr[j] - mx) * inv;
+        if (probs) probs[(long)n * J + j] = p;
+        if (p > bp) { bp = p; bi = j; }
+    }
+    // arg max of the probabilities, lowest index on ties
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        const float op = __shfl_xor(bp, o);
+        const int oi = __shfl_xor(bi, o);
+        if (op > bp || (op == bp && oi < bi)) { bp = op; bi = oi; }
+    }
+    __syncthreads();
+    if (lane == 0) { sm[wave] = bp; si[wave] = bi; }
+    __syncthreads();
+    if (t == 0) {
+        for (int i = 1; i < 4; ++i)
+            if (sm[i] > bp || (sm[i] == bp && si[i] < bi)) { bp = sm[i]; bi = si[i]; }
+        preds[n] = bi;
+    }
+}
+extern "C" int dfd_softmax_argmax(const float* logits, int N, int J, float* probs, int64_t* preds, dfd_stream stream) {
+    if (!logits || !preds || N < 1 || J < 1) return DFD_EINVAL;
+    hipLaunchKernelGGL(k_softmax_argmax, dim3(N), dim3(DFD_THREADS), 0, (hipStream_t)stream, logits, J, probs, preds);
+    return DFD_CHECK_LAUNCH();
+}
+
+// ===========================================================================
+// fused multi-tensor AdamW (torch.optim.AdamW semantics, decoupled weight decay)
+// ===========================================================================
+__global__ void __launch_bounds__(DFD_THREADS)
+k_adamw(const int64_t* __restrict__ table, const float* __restrict__ hp) {
+    const int64_t* row = table + (long)blockIdx.x * DFD_ADAMW_TABLE_COLS;
+    float* p = reinterpret_cast<float*>(row[0]);
+    const float* g = reinterpret_cast<const float*>(row[1]);
+    float* m = reinterpret_cast<float*>(row[2]);
+    float* v = reinterpret_cast<float*>(row[3]);
+    const int cnt = (int)row[4];
+    const float lr = hp[0], b1 = hp[1], b2 = hp[2], eps = hp[3], wd = hp[4], bc1 = hp[5], bc2 = hp[6], gs = hp[7];
+    const float step = lr / bc1, rs2 = 1.0f / sqrtf(bc2), decay = 1.f - lr * wd;
+    for (int i = threadIdx.x; i < cnt; i += DFD_THREADS) {
+        const float gg = g[i] * gs;
+        const float mm = b1 * m[i] + (1.f - b1) * gg;
+        const float vv = b2 * v[i] + (1.f - b2) * gg * gg;
+        m[i] = mm;
+        v[i] = vv;
+        const float denom = sqrtf(vv) * rs2 + eps;
+        p[i] = p[i] * decay - step * (mm / denom);
+    }
+}
+extern "C" int dfd_adamw_step(const int64_t* table, int nchunks, const float* hp, dfd_stream stream) {
+    if (!table || !hp || nchunks < 1) return DFD_EINVAL;
+    hipLaunchKernelGGL(k_adamw, dim3(nchunks), dim3(DFD_THREADS), 0, (hipStream_t)stream, table, hp);
+    return DFD_CHECK_LAUNCH();
+}

@@ -1,0 +1,649 @@
+// dfd_pwconv.hip — 1x1 convolutions as MFMA GEMMs over the NHWC row matrix.
+//
+//   forward / data-gradient ("NT"):  out[M][Nout] = P(a)[M][K] * w[Nout][K]^T
+//   weight gradient        ("TN"):  dw[Ni][Nj]   = sum_m P(p)[m][i] * Q(q)[m][j]
+//
+// gfx950 specifics:
+//   * bf16: v_mfma_f32_16x16x32_bf16, f32: v_mfma_f32_16x16x4_f32 (exact f32).
+//   * LDS tiles have 128-byte rows of eight 16-byte chunks, XOR-swizzled
+//     (chunk ^= row & 7) so the ds_read_b128 fragment reads are conflict-free.
+//   * the weights are the MFMA "A" operand and the activations the "B" operand, so a
+//     lane's four accumulator registers are four CONSECUTIVE output channels of one
+//     row; the tile goes back through LDS and is written with 16-byte row-major stores.
+//   * the producer's BN + activation (+ SE gate), or the BN-backward affine map of two
+//     tensors, is applied in registers between the global load and the LDS write:
+//     the normalised/activated tensor never exists in HBM.
+//   * the TN kernel reads both operands with ds_read_b64_tr_b16 (hardware transpose)
+//     from tiles stored exactly as they sit in memory ([m][channel]).
+//   * workgroups are persistent over M tiles: per-channel (sum, sumsq) stay in
+//     registers and leave as ONE partial row per workgroup (reproducible reductions).
+#include "dfd_common.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) short short4_t;
+typedef __attribute__((ext_vector_type(8))) short short8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
+#define PW_BM 128
+
+struct ProArgs {
+    const void* a2;
+    const float* coef;
+    const float* gate;
+    int HW;
+};
+
+template <typename T> struct El;
+template <> struct El<bf16> { static constexpr int EPC = 8; static constexpr int BK = 64; };   // elements per 16-B chunk, K tile
+template <> struct El<float> { static constexpr int EPC = 4; static constexpr int BK = 32; };
+
+__device__ __forceinline__ void q_to_f(const uint4& q, float (&v)[8]) { Vec<bf16>::unpack(q, v); }
+__device__ __forceinline__ void q_to_f(const uint4& q, float (&v)[4]) {
+    v[0] = __uint_as_float(q.x); v[1] = __uint_as_float(q.y); v[2] = __uint_as_float(q.z); v[3] = __uint_as_float(q.w);
+}
+__device__ __forceinline__ uint4 f_to_q(const float (&v)[8]) { return Vec<bf16>::pack(v); }
+__device__ __forceinline__ uint4 f_to_q(const float (&v)[4]) {
+    return make_uint4(__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3]));
+}
+
+// apply the prologue to one 16-byte chunk (EPC consecutive k of one row)
+template <typename T, int PRO, int ACT>
+__device__ __forceinline__ uint4 apply_pro(uint4 q, uint4 q2, const float* __restrict__ coef, const float* __restrict__ gate_row,
+                                           int k, int K) {
+    constexpr int E = El<T>::EPC;
+    if constexpr (PRO == DFD_PRO_NONE) {
+        return q;
+    } else {
+        float v[E], c0[E], c1[E];
+        q_to_f(q, v);
+        load_f32<E>(coef + k, c0);
+        load_f32<E>(coef + K + k, c1);
+        if constexpr (PRO == DFD_PRO_AFFINE2) {
+            float v2[E], c2[E];
+            q_to_f(q2, v2);
+            load_f32<E>(coef + 2 * K + k, c2);
+#pragma unroll
+            for (int j = 0; j < E; ++j) v[j] = fmaf(c0[j], v[j], fmaf(c1[j], v2[j], c2[j]));
+        } else {
+#pragma unroll
+            for (int j = 0; j < E; ++j) v[j] = act_fwd<ACT>(fmaf(c0[j], v[j], c1[j]));
+            if constexpr (PRO == DFD_PRO_BN_ACT_GATE) {
+                float gt[E];
+                load_f32<E>(gate_row + k, gt);
+                // the activated tensor is rounded to T before the gate multiply, as an
+                // unfused pipeline would store it
+#pragma unroll
+                for (int j = 0; j < E; ++j) v[j] = round_to<T>(v[j]) * gt[j];
+            }
+        }
+        return f_to_q(v);
+    }
+}
+
+// ===========================================================================
+// NT kernel
+// ===========================================================================
+template <typename T, int BN, int PRO, int ACT, bool RES, bool STATS>
+__global__ void __launch_bounds__(DFD_THREADS)
+k_pw_nt(const T* __restrict__ a, ProArgs pa, const T* __restrict__ w, T* __restrict__ out, const T* __restrict__ res,
+        int M, int K, int Nout, int m_tiles, int n_tiles, int gx, float* __restrict__ partials) {
+    constexpr int E = El<T>::EPC;
+    constexpr int BK = El<T>::BK;
+    constexpr int NTW = BN / 32;            // 16-wide n tiles per wave
+    constexpr int A_BYTES = PW_BM * 128;
+    constexpr int B_BYTES = BN * 128;
+    constexpr int STAGE = A_BYTES + B_BYTES;
+    constexpr int OROW = BN * (int)sizeof(T) + 16;   // epilogue row stride in bytes
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    // XCD-aware remap: workgroups that share an M tile (different n tiles) sit on one XCD
+    const int total = gx * n_tiles;
+    int lin = blockIdx.x;
+    {
+        const int q = total >> 3, r = total & 7, xcd = lin & 7, slot = lin >> 3;
+        lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+    }
+    const int pb = lin / n_tiles, nt = lin - pb * n_tiles;
+    const int n0 = nt * BN;
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int sc = t & 7, sr = t >> 3;      // staging: chunk column, first row
+    const int frow = lane & 15, fk = lane >> 4;
+
+    // epilogue mapping
+    constexpr int CPR = BN / E;             // 16-B chunks per output row
+    constexpr int RL = DFD_THREADS / CPR;
+    const int ec = t % CPR, er = t / CPR;
+    float s1[E], s2[E];
+#pragma unroll
+    for (int j = 0; j < E; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
+
+    const int nk = (K + BK - 1) / BK;
+    const T* a2 = reinterpret_cast<const T*>(pa.a2);
+
+    for (int mt = pb; mt < m_tiles; mt += gx) {
+        const int m0 = mt * PW_BM;
+        f32x4_t acc[NTW][4];
+#pragma unroll
+        for (int i = 0; i < NTW; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+        uint4 ra[4], ra2[4], rb[BN / 32];
+        auto g_load = [&](int kt) {
+            const int k = kt * BK + sc * E;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int m = m0 + sr + 32 * i;
+                ra[i] = make_uint4(0, 0, 0, 0);
+                if (PRO == DFD_PRO_AFFINE2) ra2[i] = make_uint4(0, 0, 0, 0);
+                if (m < M && k < K) {
+                    ra[i] = *reinterpret_cast<const uint4*>(a + (long)m * K + k);
+                    if constexpr (PRO == DFD_PRO_AFFINE2) ra2[i] = *reinterpret_cast<const uint4*>(a2 + (long)m * K + k);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < BN / 32; ++i) {
+                const int n = n0 + sr + 32 * i;
+                rb[i] = (n < Nout && k < K) ? *reinterpret_cast<const uint4*>(w + (long)n * K + k) : make_uint4(0, 0, 0, 0);
+            }
+        };
+        auto s_store = [&](int kt, int buf) {
+            unsigned char* ab = smem + buf * STAGE;
+            unsigned char* bb = ab + A_BYTES;
+            const int k = kt * BK + sc * E;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = sr + 32 * i, m = m0 + r;
+                uint4 q = ra[i];
+                if (PRO != DFD_PRO_NONE && m < M && k < K) {
+                    const float* grow = nullptr;
+                    if constexpr (PRO == DFD_PRO_BN_ACT_GATE) grow = pa.gate + (long)(m / pa.HW) * K;
+                    q = apply_pro<T, PRO, ACT>(ra[i], ra2[i], pa.coef, grow, k, K);
+                }
+                *reinterpret_cast<uint4*>(ab + r * 128 + ((sc ^ (r & 7)) << 4)) = q;
+            }
+#pragma unroll
+            for (int i = 0; i < BN / 32; ++i) {
+                const int r = sr + 32 * i;
+                *reinterpret_cast<uint4*>(bb + r * 128 + ((sc ^ (r & 7)) << 4)) = rb[i];
+            }
+        };
+
+        __syncthreads();   // previous tile's epilogue reads are done
+        g_load(0);
+        s_store(0, 0);
+        __syncthreads();
+        for (int kt = 0; kt < nk; ++kt) {
+            const int buf = kt & 1;
+            if (kt + 1 < nk) g_load(kt + 1);
+            const unsigned char* ab = smem + buf * STAGE;
+            const unsigned char* bb = ab + A_BYTES;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const int klim = kt * BK + ks * (BK / 2);
+                if (klim < K) {
+                    const int c = ks * 4 + fk;
+                    uint4 fa[4], fw[NTW];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int r = wm * 64 + i * 16 + frow;
+                        fa[i] = *reinterpret_cast<const uint4*>(ab + r * 128 + ((c ^ (r & 7)) << 4));
+                    }
+#pragma unroll
+                    for (int i = 0; i < NTW; ++i) {
+                        const int r = wn * (BN / 2) + i * 16 + frow;
+                        fw[i] = *reinterpret_cast<const uint4*>(bb + r * 128 + ((c ^ (r & 7)) << 4));
+                    }
+#pragma unroll
+                    for (int i = 0; i < NTW; ++i)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            if constexpr (sizeof(T) == 2) {
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                                    __builtin_bit_cast(bf16x8_t, fw[i]), __builtin_bit_cast(bf16x8_t, fa[j]), acc[i][j], 0, 0, 0);
+                            } else {
+                                const f32x4_t wv = __builtin_bit_cast(f32x4_t, fw[i]);
+                                const f32x4_t av = __builtin_bit_cast(f32x4_t, fa[j]);
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[0], av[0], acc[i][j], 0, 0, 0);
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[1], av[1], acc[i][j], 0, 0, 0);
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[2], av[2], acc[i][j], 0, 0, 0);
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[3], av[3], acc[i][j], 0, 0, 0);
+                            }
+                        }
+                }
+            }
+            if (kt + 1 < nk) s_store(kt + 1, buf ^ 1);
+            __syncthreads();
+        }
+        // ---- epilogue: accumulators -> LDS [m][n] -> 16-byte row-major stores
+        // acc[i][j][r]: n = wn*BN/2 + i*16 + fk*4 + r ; m = wm*64 + j*16 + frow
+#pragma unroll
+        for (int i = 0; i < NTW; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int m = wm * 64 + j * 16 + frow;
+                const int n = wn * (BN / 2) + i * 16 + fk * 4;
+                unsigned char* p = smem + m * OROW + n * (int)sizeof(T);
+                if constexpr (sizeof(T) == 2) {
+                    uint2 q;
+                    q.x = pack_bf2(acc[i][j][0], acc[i][j][1]);
+                    q.y = pack_bf2(acc[i][j][2], acc[i][j][3]);
+                    *reinterpret_cast<uint2*>(p) = q;
+                } else {
+                    *reinterpret_cast<float4*>(p) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+                }
+            }
+        __syncthreads();
+        const int n = n0 + ec * E;
+        if (n < Nout) {
+#pragma unroll 4
+            for (int r = er; r < PW_BM; r += RL) {
+                const int m = m0 + r;
+                if (m >= M) break;
+                float v[E];
+                q_to_f(*reinterpret_cast<const uint4*>(smem + r * OROW + ec * 16), v);
+                if constexpr (RES) {
+                    float q[E];
+                    Vec<T>::load(res + (long)m * Nout + n, q);
+#pragma unroll
+                    for (int j = 0; j < E; ++j) v[j] = round_to<T>(v[j] + q[j]);
+                }
+                if constexpr (STATS) {
+#pragma unroll
+                    for (int j = 0; j < E; ++j) { s1[j] += v[j]; s2[j] = fmaf(v[j], v[j], s2[j]); }
+                }
+                Vec<T>::store(out + (long)m * Nout + n, v);
+            }
+        }
+    }
+    if constexpr (STATS) {
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(smem);
+        float acc2[2 * E];
+#pragma unroll
+        for (int j = 0; j < E; ++j) { acc2[j] = s1[j]; acc2[E + j] = s2[j]; }
+        reduce_rowlanes<2 * E>(acc2, red, CPR, RL, ec, er, true);
+        const int n = n0 + ec * E;
+        if (er == 0 && n < Nout) {
+            float* p = partials + (long)pb * 2 * Nout;
+            float a0[E], a1[E];
+#pragma unroll
+            for (int j = 0; j < E; ++j) { a0[j] = acc2[j]; a1[j] = acc2[E + j]; }
+            store_f32<E>(p + n, a0);
+            store_f32<E>(p + Nout + n, a1);
+        }
+    }
+}
+
+// ===========================================================================
+// TN kernel (weight gradient)
+// tile rows are m (the reduction index); bf16: 64 rows x 256 B, f32: 32 rows x (512+64) B
+// ===========================================================================
+#define TN_B 128   // output tile edge (channels of p and of q)
+
+// byte offset of 16-B chunk `ch` of row m in a bf16 [64][128] tile, swizzled for tr reads
+__device__ __forceinline__ int tn_off_bf16(int m, int ch) {
+    const int f = ((m & 3) | (((m >> 3) & 1) << 2)) << 1;
+    return m * 256 + ((ch ^ f) << 4);
+}
+#define TN_F32_ROW 576  // (128 + 16) floats: kq rows land on disjoint bank halves
+
+template <typename T, int PROP, int PROQ, int ACT>
+__global__ void __launch_bounds__(DFD_THREADS)
+k_pw_tn(const T* __restrict__ p, ProArgs pp, int Ni, const T* __restrict__ q, ProArgs pq, int Nj, int M,
+        int i_tiles, int j_tiles, int rows_per_split, float* __restrict__ ws) {
+    constexpr int E = El<T>::EPC;
+    constexpr int BMK = (sizeof(T) == 2) ? 64 : 32;         // reduction rows per step
+    constexpr int ROWB = (sizeof(T) == 2) ? 256 : TN_F32_ROW;
+    constexpr int TILE = BMK * ROWB;
+    constexpr int CPRW = TN_B / E;                           // chunks per tile row: 16 / 32
+    constexpr int RPP = DFD_THREADS / CPRW;                  // rows per staging pass: 16 / 8
+    constexpr int NPASS = BMK / RPP;                         // 4
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int tile_id = blockIdx.x;
+    const int it = tile_id / j_tiles, jt = tile_id - it * j_tiles;
+    const int i0 = it * TN_B, j0 = jt * TN_B;
+    const int split = blockIdx.y;
+    const int mbeg = split * rows_per_split;
+    int mend = mbeg + rows_per_split;
+    if (mend > M) mend = M;
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wi = wave >> 1, wj = wave & 1;
+    const int sc = t % CPRW, sr = t / CPRW;
+    const int ci = i0 + sc * E, cj = j0 + sc * E;   // this thread's channel chunk in p / q
+    const T* p2 = reinterpret_cast<const T*>(pp.a2);
+    const T* q2 = reinterpret_cast<const T*>(pq.a2);
+
+    f32x4_t acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    uint4 rp[NPASS], rp2[NPASS], rq[NPASS], rq2[NPASS];
+    auto g_load = [&](int mb) {
+#pragma unroll
+        for (int i = 0; i < NPASS; ++i) {
+            const int m = mb + sr + RPP * i;
+            rp[i] = make_uint4(0, 0, 0, 0); rq[i] = make_uint4(0, 0, 0, 0);
+            if (PROP == DFD_PRO_AFFINE2) rp2[i] = make_uint4(0, 0, 0, 0);
+            if (PROQ == DFD_PRO_AFFINE2) rq2[i] = make_uint4(0, 0, 0, 0);
+            if (m < mend) {
+                if (ci < Ni) {
+                    rp[i] = *reinterpret_cast<const uint4*>(p + (long)m * Ni + ci);
+                    if constexpr (PROP == DFD_PRO_AFFINE2) rp2[i] = *reinterpret_cast<const uint4*>(p2 + (long)m * Ni + ci);
+                }
+                if (cj < Nj) {
+                    rq[i] = *reinterpret_cast<const uint4*>(q + (long)m * Nj + cj);
+                    if constexpr (PROQ == DFD_PRO_AFFINE2) rq2[i] = *reinterpret_cast<const uint4*>(q2 + (long)m * Nj + cj);
+                }
+            }
+        }
+    };
+    auto s_store = [&](int mb, int buf) {
+        unsigned char* pb_ = smem + buf * 2 * TILE;
+        unsigned char* qb_ = pb_ + TILE;
+#pragma unroll
+        for (int i = 0; i < NPASS; ++i) {
+            const int r = sr + RPP * i, m = mb + r;
+            uint4 vp = rp[i], vq = rq[i];
+            if (m < mend) {
+                if (PROP != DFD_PRO_NONE && ci < Ni) vp = apply_pro<T, PROP, DFD_ACT_NONE>(rp[i], rp2[i], pp.coef, nullptr, ci, Ni);
+                if (PROQ != DFD_PRO_NONE && cj < Nj) {
+                    const float* grow = nullptr;
+                    if constexpr (PROQ == DFD_PRO_BN_ACT_GATE) grow = pq.gate + (long)(m / pq.HW) * Nj;
+                    vq = apply_pro<T, PROQ, ACT>(rq[i], rq2[i], pq.coef, grow, cj, Nj);
+                }
+            }
+            if constexpr (sizeof(T) == 2) {
+                *reinterpret_cast<uint4*>(pb_ + tn_off_bf16(r, sc)) = vp;
+                *reinterpret_cast<uint4*>(qb_ + tn_off_bf16(r, sc)) = vq;
+            } else {
+                *reinterpret_cast<uint4*>(pb_ + r * ROWB + sc * 16) = vp;
+                *reinterpret_cast<uint4*>(qb_ + r * ROWB + sc * 16) = vq;
+            }
+        }
+    };
+
+    const int nsteps = (mend > mbeg) ? (mend - mbeg + BMK - 1) / BMK : 0;
+    if (nsteps > 0) {
+        g_load(mbeg);
+        s_store(mbeg, 0);
+    }
+    __syncthreads();
+    for (int st = 0; st < nsteps; ++st) {
+        const int buf = st & 1;
+        if (st + 1 < nsteps) g_load(mbeg + (st + 1) * BMK);
+        const unsigned char* pb_ = smem + buf * 2 * TILE;
+        const unsigned char* qb_ = pb_ + TILE;
+        if constexpr (sizeof(T) == 2) {
+            // two k-substeps of 32 rows; fragment = 8 consecutive m for one channel:
+            // two transposed 4x16 block reads per operand tile
+            const int g = lane >> 4, li = lane & 15, qrow = li >> 2, pcol = li & 3;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                short8_t fa[4], fb[4];
+#pragma unroll
+                for (int x = 0; x < 4; ++x) {
+                    const int chA = ((wi * 64 + x * 16) >> 3) + (pcol >> 1);
+                    const int chB = ((wj * 64 + x * 16) >> 3) + (pcol >> 1);
+                    const int m_lo = ks * 32 + 8 * g + qrow, m_hi = m_lo + 4;
+                    const int sub = (pcol & 1) << 3;
+                    short4_t a_lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) short4_t*)(pb_ + tn_off_bf16(m_lo, chA) + sub));
+                    short4_t a_hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) short4_t*)(pb_ + tn_off_bf16(m_hi, chA) + sub));
+                    short4_t b_lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) short4_t*)(qb_ + tn_off_bf16(m_lo, chB) + sub));
+                    short4_t b_hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) short4_t*)(qb_ + tn_off_bf16(m_hi, chB) + sub));
+                    fa[x] = (short8_t){a_lo[0], a_lo[1], a_lo[2], a_lo[3], a_hi[0], a_hi[1], a_hi[2], a_hi[3]};
+                    fb[x] = (short8_t){b_lo[0], b_lo[1], b_lo[2], b_lo[3], b_hi[0], b_hi[1], b_hi[2], b_hi[3]};
+                }
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int b = 0; b < 4; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, fa[a]),
+                                                                          __builtin_bit_cast(bf16x8_t, fb[b]), acc[a][b], 0, 0, 0);
+            }
+        } else {
+            const int col = lane & 15, kq = lane >> 4;
+#pragma unroll
+            for (int ks = 0; ks < BMK / 4; ++ks) {
+                float fa[4], fb[4];
+                const int m = ks * 4 + kq;
+#pragma unroll
+                for (int x = 0; x < 4; ++x) {
+                    fa[x] = *reinterpret_cast<const float*>(pb_ + m * ROWB + (wi * 64 + x * 16 + col) * 4);
+                    fb[x] = *reinterpret_cast<const float*>(qb_ + m * ROWB + (wj * 64 + x * 16 + col) * 4);
+                }
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int b = 0; b < 4; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[a], fb[b], acc[a][b], 0, 0, 0);
+            }
+        }
+        if (st + 1 < nsteps) s_store(mbeg + (st + 1) * BMK, buf ^ 1);
+        __syncthreads();
+    }
+    // D: col (lane&15) = j index, row 4*(lane>>4)+r = i index
+    float* o = ws + (long)split * Ni * Nj;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int j = j0 + wj * 64 + b * 16 + (lane & 15);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = i0 + wi * 64 + a * 16 + (lane >> 4) * 4 + r;
+                if (i < Ni && j < Nj) o[(long)i * Nj + j] = acc[a][b][r];
+            }
+        }
+}
+
+// ===========================================================================
+// weight preparation: f32 master [N][K] -> T [N][K] and T [K][N]
+// ===========================================================================
+template <typename T>
+__global__ void k_prep_weights(const float* __restrict__ w, T* __restrict__ w_nk, T* __restrict__ w_kn, int N, int K) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)N * K) return;
+    const int n = (int)(i / K), k = (int)(i - (long)n * K);
+    const float v = w[i];
+    if constexpr (sizeof(T) == 2) {
+        if (w_nk) reinterpret_cast<unsigned short*>(w_nk)[i] = f2bf(v);
+        if (w_kn) reinterpret_cast<unsigned short*>(w_kn)[(long)k * N + n] = f2bf(v);
+    } else {
+        if (w_nk) reinterpret_cast<float*>(w_nk)[i] = v;
+        if (w_kn) reinterpret_cast<float*>(w_kn)[(long)k * N + n] = v;
+    }
+}
+
+extern "C" int dfd_pw_prep_weights(int dtype, const float* w, void* w_nk, void* w_kn, int N, int K, dfd_stream stream) {
+    if (!w || N < 1 || K < 1 || (!w_nk && !w_kn)) return DFD_EINVAL;
+    const long total = (long)N * K;
+    const int threads = 256;
+    const unsigned grid = (unsigned)((total + threads - 1) / threads);
+    if (dtype == DFD_BF16)
+        hipLaunchKernelGGL((k_prep_weights<bf16>), dim3(grid), dim3(threads), 0, (hipStream_t)stream, w, (bf16*)w_nk, (bf16*)w_kn, N, K);
+    else if (dtype == DFD_F32)
+        hipLaunchKernelGGL((k_prep_weights<float>), dim3(grid), dim3(threads), 0, (hipStream_t)stream, w, (float*)w_nk, (float*)w_kn, N, K);
+    else
+        return DFD_EINVAL;
+    return DFD_CHECK_LAUNCH();
+}
+
+// ===========================================================================
+// host dispatch
+// ===========================================================================
+// activations instantiated for the GEMM prologues (EfficientNet: SiLU)
+#define DISPATCH_ACT_PW(ACTV, ...)                                                   \
+    switch (ACTV) {                                                                  \
+        case DFD_ACT_NONE: { constexpr int ACT = DFD_ACT_NONE; __VA_ARGS__; } break; \
+        case DFD_ACT_SILU: { constexpr int ACT = DFD_ACT_SILU; __VA_ARGS__; } break; \
+        default: return DFD_EUNSUPPORTED;                                            \
+    }
+static bool pro_ok(const dfd_prologue* p) {
+    if (!p) return true;
+    switch (p->mode) {
+        case DFD_PRO_NONE: return true;
+        case DFD_PRO_BN_ACT: return p->coef != nullptr;
+        case DFD_PRO_BN_ACT_GATE: return p->coef && p->gate && p->HW > 0;
+        case DFD_PRO_AFFINE2: return p->coef && p->a2;
+        default: return false;
+    }
+}
+static ProArgs pro_args(const dfd_prologue* p) {
+    ProArgs a{nullptr, nullptr, nullptr, 1};
+    if (p) { a.a2 = p->a2; a.coef = p->coef; a.gate = p->gate; a.HW = p->HW > 0 ? p->HW : 1; }
+    return a;
+}
+
+template <typename T, int BN>
+static int pw_nt_launch(const void* a, const dfd_prologue* pro, const void* w, void* out, const void* residual, int M,
+                        int K, int Nout, float* partials, int pcap, int* nparts, hipStream_t st) {
+    const int m_tiles = (M + PW_BM - 1) / PW_BM, n_tiles = (Nout + BN - 1) / BN;
+    int cap = partials ? (pcap < DFD_MAX_PARTIALS ? pcap : DFD_MAX_PARTIALS) : DFD_MAX_PARTIALS;
+    int gx = 2048 / n_tiles;
+    if (gx < 32) gx = 32;
+    if (gx > cap) gx = cap;
+    if (gx > m_tiles) gx = m_tiles;
+    if (partials) *nparts = gx;
+    constexpr int STAGE = PW_BM * 128 + BN * 128;
+    constexpr int OBYTES = PW_BM * (BN * (int)sizeof(T) + 16);
+    constexpr int RED = DFD_THREADS * 2 * El<T>::EPC * 4;
+    int lds = 2 * STAGE;
+    if (lds < OBYTES) lds = OBYTES;
+    if (lds < RED) lds = RED;
+    const ProArgs pa = pro_args(pro);
+    const int mode = pro ? pro->mode : DFD_PRO_NONE;
+    const int act = (pro && (mode == DFD_PRO_BN_ACT || mode == DFD_PRO_BN_ACT_GATE)) ? pro->act : DFD_ACT_NONE;
+    const bool has_res = residual != nullptr, stats = partials != nullptr;
+    dim3 grid(gx * n_tiles);
+#define LAUNCH_NT(PRO, RES, STATS)                                                                                        \
+    hipLaunchKernelGGL((k_pw_nt<T, BN, PRO, ACT, RES, STATS>), grid, dim3(DFD_THREADS), lds, st, (const T*)a, pa, (const T*)w, \
+                       (T*)out, (const T*)residual, M, K, Nout, m_tiles, n_tiles, gx, partials)
+    // combinations used by the engine: forward = {NONE, BN_ACT, BN_ACT_GATE} x stats, no residual;
+    // data gradient = AFFINE2 (+ residual), no stats; plain = NONE
+    if (mode == DFD_PRO_AFFINE2) {
+        constexpr int ACT = DFD_ACT_NONE;
+        if (stats) return DFD_EUNSUPPORTED;
+        if (has_res) LAUNCH_NT(DFD_PRO_AFFINE2, true, false); else LAUNCH_NT(DFD_PRO_AFFINE2, false, false);
+    } else if (mode == DFD_PRO_NONE) {
+        constexpr int ACT = DFD_ACT_NONE;
+        if (has_res && stats) return DFD_EUNSUPPORTED;
+        if (has_res) LAUNCH_NT(DFD_PRO_NONE, true, false);
+        else if (stats) LAUNCH_NT(DFD_PRO_NONE, false, true);
+        else LAUNCH_NT(DFD_PRO_NONE, false, false);
+    } else {
+        if (has_res) return DFD_EUNSUPPORTED;
+        if (mode == DFD_PRO_BN_ACT) {
+            DISPATCH_ACT_PW(act, { if (stats) LAUNCH_NT(DFD_PRO_BN_ACT, false, true); else LAUNCH_NT(DFD_PRO_BN_ACT, false, false); });
+        } else {
+            DISPATCH_ACT_PW(act, { if (stats) LAUNCH_NT(DFD_PRO_BN_ACT_GATE, false, true); else LAUNCH_NT(DFD_PRO_BN_ACT_GATE, false, false); });
+        }
+    }
+#undef LAUNCH_NT
+    return DFD_CHECK_LAUNCH();
+}
+
+template <typename T>
+static int pw_nt_t(const void* a, const dfd_prologue* pro, const void* w, void* out, const void* residual, int M, int K,
+                   int Nout, float* partials, int pcap, int* nparts, hipStream_t st) {
+    if (Nout <= 32) return pw_nt_launch<T, 32>(a, pro, w, out, residual, M, K, Nout, partials, pcap, nparts, st);
+    if (Nout <= 64) return pw_nt_launch<T, 64>(a, pro, w, out, residual, M, K, Nout, partials, pcap, nparts, st);
+    return pw_nt_launch<T, 128>(a, pro, w, out, residual, M, K, Nout, partials, pcap, nparts, st);
+}
+
+extern "C" int dfd_pwconv_fwd(int dtype, const void* a, const dfd_prologue* pro, const void* w, void* out,
+                              const void* residual, int M, int K, int Nout, float* partials, int pcap, int* nparts,
+                              dfd_stream stream) {
+    if (!a || !w || !out || M < 1 || K < 8 || Nout < 8 || K % 8 || Nout % 8 || !pro_ok(pro)) return DFD_EINVAL;
+    if (partials && (!nparts || pcap < 1)) return DFD_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == DFD_BF16) return pw_nt_t<bf16>(a, pro, w, out, residual, M, K, Nout, partials, pcap, nparts, st);
+    if (dtype == DFD_F32) return pw_nt_t<float>(a, pro, w, out, residual, M, K, Nout, partials, pcap, nparts, st);
+    return DFD_EINVAL;
+}
+
+static void tn_plan(int dtype, int M, int Ni, int Nj, int* i_tiles, int* j_tiles, int* splits, int* rows_per_split) {
+    const int bmk = dtype == DFD_BF16 ? 64 : 32;
+    *i_tiles = (Ni + TN_B - 1) / TN_B;
+    *j_tiles = (Nj + TN_B - 1) / TN_B;
+    const int tiles = *i_tiles * *j_tiles;
+    int s = 1024 / tiles;
+    if (s < 1) s = 1;
+    // keep the slab under 64 MiB and give each split at least 8 reduction steps
+    const long per = (long)Ni * Nj * 4;
+    long cap = (64l << 20) / per;
+    if (cap < 1) cap = 1;
+    if (s > cap) s = (int)cap;
+    int max_s = (M + bmk * 8 - 1) / (bmk * 8);
+    if (max_s < 1) max_s = 1;
+    if (s > max_s) s = max_s;
+    int rps = (M + s - 1) / s;
+    rps = ((rps + bmk - 1) / bmk) * bmk;
+    s = (M + rps - 1) / rps;
+    *splits = s;
+    *rows_per_split = rps;
+}
+
+extern "C" size_t dfd_pwconv_wgrad_ws(int M, int Ni, int Nj) {
+    if (M < 1 || Ni < 1 || Nj < 1) return 0;
+    int it, jt, s, rps;
+    size_t best = 0;
+    for (int dt = 0; dt < 2; ++dt) {
+        tn_plan(dt, M, Ni, Nj, &it, &jt, &s, &rps);
+        const size_t b = (size_t)s * Ni * Nj * 4;
+        if (b > best) best = b;
+    }
+    return best;
+}
+
+template <typename T>
+static int pw_tn_t(const void* p, const dfd_prologue* pro_p, int Ni, const void* q, const dfd_prologue* pro_q, int Nj,
+                   int M, float* dw, int accumulate, float* ws, size_t ws_bytes, hipStream_t st) {
+    int it, jt, splits, rps;
+    tn_plan(sizeof(T) == 2 ? DFD_BF16 : DFD_F32, M, Ni, Nj, &it, &jt, &splits, &rps);
+    if ((size_t)splits * Ni * Nj * 4 > ws_bytes) return DFD_EWORKSPACE;
+    constexpr int BMK = (sizeof(T) == 2) ? 64 : 32;
+    constexpr int ROWB = (sizeof(T) == 2) ? 256 : TN_F32_ROW;
+    const int lds = 2 * 2 * BMK * ROWB;
+    const ProArgs pp = pro_args(pro_p), pq = pro_args(pro_q);
+    const int mp = pro_p ? pro_p->mode : DFD_PRO_NONE, mq = pro_q ? pro_q->mode : DFD_PRO_NONE;
+    const int act = (pro_q && (mq == DFD_PRO_BN_ACT || mq == DFD_PRO_BN_ACT_GATE)) ? pro_q->act : DFD_ACT_NONE;
+    if (!(mp == DFD_PRO_NONE || mp == DFD_PRO_AFFINE2)) return DFD_EUNSUPPORTED;
+    if (mq == DFD_PRO_AFFINE2) return DFD_EUNSUPPORTED;
+    dim3 grid(it * jt, splits);
+#define LAUNCH_TN(PP, PQ)                                                                                                \
+    hipLaunchKernelGGL((k_pw_tn<T, PP, PQ, ACT>), grid, dim3(DFD_THREADS), lds, st, (const T*)p, pp, Ni, (const T*)q, pq, Nj, \
+                       M, it, jt, rps, ws)
+    if (mq == DFD_PRO_NONE) {
+        constexpr int ACT = DFD_ACT_NONE;
+        if (mp == DFD_PRO_AFFINE2) LAUNCH_TN(DFD_PRO_AFFINE2, DFD_PRO_NONE); else LAUNCH_TN(DFD_PRO_NONE, DFD_PRO_NONE);
+    } else if (mq == DFD_PRO_BN_ACT) {
+        DISPATCH_ACT_PW(act, { if (mp == DFD_PRO_AFFINE2) LAUNCH_TN(DFD_PRO_AFFINE2, DFD_PRO_BN_ACT); else LAUNCH_TN(DFD_PRO_NONE, DFD_PRO_BN_ACT); });
+    } else {
+        DISPATCH_ACT_PW(act, { if (mp == DFD_PRO_AFFINE2) LAUNCH_TN(DFD_PRO_AFFINE2, DFD_PRO_BN_ACT_GATE); else LAUNCH_TN(DFD_PRO_NONE, DFD_PRO_BN_ACT_GATE); });
+    }
+#undef LAUNCH_TN
+    if (hipGetLastError() != hipSuccess) return DFD_ELAUNCH;
+    return dfd_launch_sum_partials(ws, splits, (long)Ni * Nj, dw, accumulate, st);
+}
+
+extern "C" int dfd_pwconv_wgrad(int dtype, const void* p, const dfd_prologue* pro_p, int Ni, const void* q,
+                                const dfd_prologue* pro_q, int Nj, int M, float* dw, int accumulate, float* ws,
+                                size_t ws_bytes, dfd_stream stream) {
+    if (!p || !q || !dw || !ws || M < 1 || Ni < 8 || Nj < 8 || Ni % 8 || Nj % 8 || !pro_ok(pro_p) || !pro_ok(pro_q))
+        return DFD_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == DFD_BF16) return pw_tn_t<bf16>(p, pro_p, Ni, q, pro_q, Nj, M, dw, accumulate, ws, ws_bytes, st);
+    if (dtype == DFD_F32) return pw_tn_t<float>(p, pro_p, Ni, q, pro_q, Nj, M, dw, accumulate, ws, ws_bytes, st);
+    return DFD_EINVAL;
+}

@@ -1,0 +1,481 @@
+// dfd_rowpass.hip — HBM-streaming passes over the NHWC row matrix [N*HW][C]:
+// BN apply / BN backward reductions / activation backward / SE squeeze.
+// Every kernel moves 16 B per lane; consecutive lanes read consecutive channel
+// vectors of a row, so a wave reads whole contiguous row segments.
+// Per-channel reductions keep the channel assignment of a thread fixed while it
+// strides over rows, accumulate in registers, reduce once through LDS and write ONE
+// partial row per workgroup (fixed summation order => reproducible results).
+#include "dfd_common.h"
+
+// ------------------------------------------------------------------ bn_act_apply
+template <typename T, int ACT, bool HAS_RES, bool HAS_RS>
+__global__ void __launch_bounds__(DFD_THREADS)
+k_bn_act_apply(const T* __restrict__ y, const float* __restrict__ bnstate, const T* __restrict__ res,
+               const float* __restrict__ rs, T* __restrict__ out, long total_vec, int CV, int C, long vec_per_img) {
+    constexpr int V = Vec<T>::N;
+    const long stride = (long)gridDim.x * DFD_THREADS;
+    for (long i = (long)blockIdx.x * DFD_THREADS + threadIdx.x; i < total_vec; i += stride) {
+        const int c0 = (int)(i % CV) * V;
+        float v[V], sc[V], sh[V];
+        Vec<T>::load(y + i * V, v);
+        load_f32<V>(bnstate + c0, sc);
+        load_f32<V>(bnstate + C + c0, sh);
+        float r = 1.f;
+        if constexpr (HAS_RS) r = rs[i / vec_per_img];
+        float q[V];
+        if constexpr (HAS_RES) Vec<T>::load(res + i * V, q);
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            float z = act_fwd<ACT>(fmaf(sc[j], v[j], sh[j]));
+            if constexpr (HAS_RS) z *= r;
+            if constexpr (HAS_RES) z += q[j];
+            v[j] = z;
+        }
+        Vec<T>::store(out + i * V, v);
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(DFD_THREADS)
+k_scale_rows(const T* __restrict__ x, const float* __restrict__ rs, T* __restrict__ out, long total_vec, long vec_per_img) {
+    constexpr int V = Vec<T>::N;
+    const long stride = (long)gridDim.x * DFD_THREADS;
+    for (long i = (long)blockIdx.x * DFD_THREADS + threadIdx.x; i < total_vec; i += stride) {
+        float v[V];
+        Vec<T>::load(x + i * V, v);
+        const float r = rs[i / vec_per_img];
+#pragma unroll
+        for (int j = 0; j < V; ++j) v[j] *= r;
+        Vec<T>::store(out + i * V, v);
+    }
+}
+
+// ------------------------------------------------------------------ bn_bwd_reduce
+// partials[pb][0][c] = sum g*rs ; partials[pb][1][c] = sum g*rs*xhat
+template <typename T, bool HAS_RS>
+__global__ void __launch_bounds__(DFD_THREADS)
+k_bn_bwd_reduce(const T* __restrict__ g, const T* __restrict__ y, const float* __restrict__ bnstate,
+                const float* __restrict__ rs, long rows, int HW, int C, ChanMap cm, float* __restrict__ partials) {
+    constexpr int V = Vec<T>::N;
+    __shared__ float red[DFD_THREADS * 2 * V];
+    const int t = threadIdx.x, vl = t % cm.cvb, rl = t / cm.cvb;
+    const bool active = rl < cm.rpb;
+    const int c0 = (blockIdx.y * cm.cvb + vl) * V;
+    float mean[V], rstd[V];
+    load_f32<V>(bnstate + 2 * C + c0, mean);
+    load_f32<V>(bnstate + 3 * C + c0, rstd);
+    float acc[2 * V];
+#pragma unroll
+    for (int j = 0; j < 2 * V; ++j) acc[j] = 0.f;
+    if (active) {
+        const long step = (long)gridDim.x * cm.rpb;
+        for (long r = (long)blockIdx.x * cm.rpb + rl; r < rows; r += step) {
+            float gv[V], yv[V];
+            Vec<T>::load(g + r * C + c0, gv);
+            Vec<T>::load(y + r * C + c0, yv);
+            float s = 1.f;
+            if constexpr (HAS_RS) s = rs[r / HW];
+#pragma unroll
+            for (int j = 0; j < V; ++j) {
+                float gg = gv[j];
+                if constexpr (HAS_RS) gg *= s;
+                acc[j] += gg;
+                acc[V + j] += gg * (yv[j] - mean[j]) * rstd[j];
+            }
+        }
+    }
+    reduce_rowlanes<2 * V>(acc, red, cm.cvb, cm.rpb, vl, rl, active);
+    if (rl == 0) {
+        float* p = partials + (long)blockIdx.x * 2 * C;
+        float a0[V], a1[V];
+#pragma unroll
+        for (int j = 0; j < V; ++j) { a0[j] = acc[j]; a1[j] = acc[V + j]; }
+        store_f32<V>(p + c0, a0);
+        store_f32<V>(p + C + c0, a1);
+    }
+}
+
+// ------------------------------------------------------------------ act_bn_bwd
+// MODE 0: da = D ; MODE 1: da = D*gate[n,c] + dpool[n,c]*invHW ; MODE 2: da = dpool[n,c]*invHW
+template <typename T, int ACT, int MODE>
+__global__ void __launch_bounds__(DFD_THREADS)
+k_act_bn_bwd(const T* __restrict__ D, const T* __restrict__ y, const float* __restrict__ gate,
+             const float* __restrict__ dpool, const float* __restrict__ bnstate, T* __restrict__ dz,
+             long rows, int HW, int C, float invHW, ChanMap cm, float* __restrict__ partials) {
+    constexpr int V = Vec<T>::N;
+    __shared__ float red[DFD_THREADS * 2 * V];
+    const int t = threadIdx.x, vl = t % cm.cvb, rl = t / cm.cvb;
+    const bool active = rl < cm.rpb;
+    const int c0 = (blockIdx.y * cm.cvb + vl) * V;
+    float sc[V], sh[V], mean[V], rstd[V];
+    load_f32<V>(bnstate + c0, sc);
+    load_f32<V>(bnstate + C + c0, sh);
+    load_f32<V>(bnstate + 2 * C + c0, mean);
+    load_f32<V>(bnstate + 3 * C + c0, rstd);
+    float acc[2 * V];
+#pragma unroll
+    for (int j = 0; j < 2 * V; ++j) acc[j] = 0.f;
+    if (active) {
+        const long step = (long)gridDim.x * cm.rpb;
+        for (long r = (long)blockIdx.x * cm.rpb + rl; r < rows; r += step) {
+            float dv[V], yv[V], gt[V], dp[V];
+            Vec<T>::load(y + r * C + c0, yv);
+            if constexpr (MODE != 2) Vec<T>::load(D + r * C + c0, dv);
+            if constexpr (MODE != 0) {
+                const long n = r / HW;
+                load_f32<V>(dpool + n * C + c0, dp);
+                if constexpr (MODE == 1) load_f32<V>(gate + n * C + c0, gt);
+            }
+#pragma unroll
+            for (int j = 0; j < V; ++j) {
+                float da;
+                if constexpr (MODE == 0) da = dv[j];
+                else if constexpr (MODE == 1) da = fmaf(dv[j], gt[j], dp[j] * invHW);
+                else da = dp[j] * invHW;
+                const float z = fmaf(sc[j], yv[j], sh[j]);
+                const float d = round_to<T>(da * act_grad<ACT>(z));
+                dv[j] = d;
+                acc[j] += d;
+                acc[V + j] += d * (yv[j] - mean[j]) * rstd[j];
+            }
+            Vec<T>::store(dz + r * C + c0, dv);
+        }
+    }
+    reduce_rowlanes<2 * V>(acc, red, cm.cvb, cm.rpb, vl, rl, active);
+    if (rl == 0) {
+        float* p = partials + (long)blockIdx.x * 2 * C;
+        float a0[V], a1[V];
+#pragma unroll
+        for (int j = 0; j < V; ++j) { a0[j] = acc[j]; a1[j] = acc[V + j]; }
+        store_f32<V>(p + c0, a0);
+        store_f32<V>(p + C + c0, a1);
+    }
+}
+
+// ------------------------------------------------------------------ pool kernels
+// grid = (nvc, N): one workgroup owns all HW rows of image n for its channel chunk.
+// BWD == false: pooled[n,c] = (1/HW) sum act(scale*y+shift)
+// BWD == true : dgate[n,c]  = sum D * act(scale*y+shift)
+template <typename T, int ACT, bool BWD>
+__global__ void __launch_bounds__(DFD_THREADS)
+k_pool(const T* __restrict__ D, const T* __restrict__ y, const float* __restrict__ bnstate,
+       float* __restrict__ out, int HW, int C, float mul, ChanMap cm) {
+    constexpr int V = Vec<T>::N;
+    __shared__ float red[DFD_THREADS * V];
+    const int t = threadIdx.x, vl = t % cm.cvb, rl = t / cm.cvb;
+    const bool active = rl < cm.rpb;
+    const int c0 = (blockIdx.x * cm.cvb + vl) * V;
+    const long n = blockIdx.y;
+    float sc[V], sh[V];
+    load_f32<V>(bnstate + c0, sc);
+    load_f32<V>(bnstate + C + c0, sh);
+    float acc[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) acc[j] = 0.f;
+    if (active) {
+        const T* yb = y + n * HW * (long)C + c0;
+        const T* db = BWD ? D + n * HW * (long)C + c0 : nullptr;
+        int r = rl;
+        // two rows in flight per lane
+        for (; r + cm.rpb < HW; r += 2 * cm.rpb) {
+            float y0[V], y1[V], d0[V], d1[V];
+            Vec<T>::load(yb + (long)r * C, y0);
+            Vec<T>::load(yb + (long)(r + cm.rpb) * C, y1);
+            if constexpr (BWD) {
+                Vec<T>::load(db + (long)r * C, d0);
+                Vec<T>::load(db + (long)(r + cm.rpb) * C, d1);
+            }
+#pragma unroll
+            for (int j = 0; j < V; ++j) {
+                float a0 = round_to<T>(act_fwd<ACT>(fmaf(sc[j], y0[j], sh[j])));
+                float a1 = round_to<T>(act_fwd<ACT>(fmaf(sc[j], y1[j], sh[j])));
+                if constexpr (BWD) acc[j] += a0 * d0[j] + a1 * d1[j];
+                else acc[j] += a0 + a1;
+            }
+        }
+        for (; r < HW; r += cm.rpb) {
+            float y0[V], d0[V];
+            Vec<T>::load(yb + (long)r * C, y0);
+            if constexpr (BWD) Vec<T>::load(db + (long)r * C, d0);
+#pragma unroll
+            for (int j = 0; j < V; ++j) {
+                float a0 = round_to<T>(act_fwd<ACT>(fmaf(sc[j], y0[j], sh[j])));
+                if constexpr (BWD) acc[j] += a0 * d0[j];
+                else acc[j] += a0;
+            }
+        }
+    }
+    reduce_rowlanes<V>(acc, red, cm.cvb, cm.rpb, vl, rl, active);
+    if (rl == 0) {
+#pragma unroll
+        for (int j = 0; j < V; ++j) acc[j] *= mul;
+        store_f32<V>(out + n * C + c0, acc);
+    }
+}
+
+// ------------------------------------------------------------------ finalize kernels
+// one thread per channel, partial rows summed in a fixed order, in double.
+__global__ void k_bn_finalize(const float* __restrict__ partials, int nparts, int C, double count,
+                              const float* __restrict__ gamma, const float* __restrict__ beta,
+                              float* __restrict__ rmean, float* __restrict__ rvar, float momentum, float eps,
+                              float* __restrict__ bnstate) {
+    // 4 lanes cooperate on one channel: lane q sums partial rows q, q+4, ...
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int c = gid >> 2, q = gid & 3;
+    double s = 0.0, ss = 0.0;
+    if (c < C) {
+        for (int p = q; p < nparts; p += 4) {
+            s += (double)partials[(long)p * 2 * C + c];
+            ss += (double)partials[(long)p * 2 * C + C + c];
+        }
+    }
+    s += __shfl_xor(s, 1); ss += __shfl_xor(ss, 1);
+    s += __shfl_xor(s, 2); ss += __shfl_xor(ss, 2);
+    if (c < C && q == 0) {
+        const double mean = s / count;
+        double var = ss / count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+        const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+        const float scale = g * rstd;
+        bnstate[c] = scale;
+        bnstate[C + c] = b - (float)mean * scale;
+        bnstate[2 * C + c] = (float)mean;
+        bnstate[3 * C + c] = rstd;
+        if (rmean) {
+            const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+            rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)mean;
+            rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unbiased;
+        }
+    }
+}
+
+__global__ void k_bn_eval_coeffs(const float* __restrict__ gamma, const float* __restrict__ beta,
+                                 const float* __restrict__ rmean, const float* __restrict__ rvar, float eps, int C,
+                                 float* __restrict__ bnstate) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float rstd = 1.0f / sqrtf(rvar[c] + eps);
+    const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+    const float scale = g * rstd;
+    bnstate[c] = scale;
+    bnstate[C + c] = b - rmean[c] * scale;
+    bnstate[2 * C + c] = rmean[c];
+    bnstate[3 * C + c] = rstd;
+}
+
+__global__ void k_bn_bwd_finalize(const float* __restrict__ partials, int nparts, int C, double count,
+                                  const float* __restrict__ gamma, const float* __restrict__ bnstate, int train,
+                                  float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate,
+                                  float* __restrict__ coef) {
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int c = gid >> 2, q = gid & 3;
+    double s1 = 0.0, s2 = 0.0;
+    if (c < C) {
+        for (int p = q; p < nparts; p += 4) {
+            s1 += (double)partials[(long)p * 2 * C + c];
+            s2 += (double)partials[(long)p * 2 * C + C + c];
+        }
+    }
+    s1 += __shfl_xor(s1, 1); s2 += __shfl_xor(s2, 1);
+    s1 += __shfl_xor(s1, 2); s2 += __shfl_xor(s2, 2);
+    if (c < C && q == 0) {
+        if (dgamma) dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)s2;
+        if (dbeta) dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)s1;
+        const double g = gamma ? (double)gamma[c] : 1.0;
+        const double mean = bnstate[2 * C + c], rstd = bnstate[3 * C + c];
+        const double a = g * rstd;
+        double b = 0.0, cc = 0.0;
+        if (train) {
+            b = -g * rstd * rstd * s2 / count;
+            cc = -g * rstd * s1 / count + g * rstd * rstd * mean * s2 / count;
+        }
+        coef[c] = (float)a;
+        coef[C + c] = (float)b;
+        coef[2 * C + c] = (float)cc;
+    }
+}
+
+// ------------------------------------------------------------------ host side
+static inline int grid_for(long items, int per_block, int cap) {
+    long b = (items + per_block - 1) / per_block;
+    if (b < 1) b = 1;
+    if (b > cap) b = cap;
+    return (int)b;
+}
+static inline bool shape_ok(int dtype, int N, int HW, int C) {
+    if (dtype != DFD_F32 && dtype != DFD_BF16) return false;
+    if (N <= 0 || HW <= 0 || C <= 0) return false;
+    return C % 8 == 0;
+}
+
+
+template <typename T>
+static int bn_act_apply_t(const void* y, const float* bnstate, int act, const void* residual, const float* rs,
+                          void* out, int N, int HW, int C, hipStream_t st) {
+    constexpr int V = Vec<T>::N;
+    const int CV = C / V;
+    const long total = (long)N * HW * CV, vpi = (long)HW * CV;
+    const int grid = grid_for(total, DFD_THREADS * 4, 16384);
+#define LAUNCH_APPLY(RES, RS) \
+    hipLaunchKernelGGL((k_bn_act_apply<T, ACT, RES, RS>), dim3(grid), dim3(DFD_THREADS), 0, st, (const T*)y, bnstate, \
+                       (const T*)residual, rs, (T*)out, total, CV, C, vpi)
+    DISPATCH_ACT(act, {
+        if (residual && rs) LAUNCH_APPLY(true, true);
+        else if (residual) LAUNCH_APPLY(true, false);
+        else if (rs) LAUNCH_APPLY(false, true);
+        else LAUNCH_APPLY(false, false);
+    });
+#undef LAUNCH_APPLY
+    return DFD_CHECK_LAUNCH();
+}
+
+extern "C" int dfd_bn_act_apply(int dtype, const void* y, const float* bnstate, int act, const void* residual,
+                                const float* row_scale, void* out, int N, int HW, int C, dfd_stream stream) {
+    if (!shape_ok(dtype, N, HW, C) || !y || !bnstate || !out) return DFD_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    return dtype == DFD_BF16 ? bn_act_apply_t<bf16>(y, bnstate, act, residual, row_scale, out, N, HW, C, st)
+                             : bn_act_apply_t<float>(y, bnstate, act, residual, row_scale, out, N, HW, C, st);
+}
+
+template <typename T>
+static int scale_rows_t(const void* x, const float* rs, void* out, int N, int HW, int C, hipStream_t st) {
+    constexpr int V = Vec<T>::N;
+    const long total = (long)N * HW * (C / V), vpi = (long)HW * (C / V);
+    const int grid = grid_for(total, DFD_THREADS * 4, 16384);
+    hipLaunchKernelGGL((k_scale_rows<T>), dim3(grid), dim3(DFD_THREADS), 0, st, (const T*)x, rs, (T*)out, total, vpi);
+    return DFD_CHECK_LAUNCH();
+}
+extern "C" int dfd_scale_rows(int dtype, const void* x, const float* row_scale, void* out, int N, int HW, int C,
+                              dfd_stream stream) {
+    if (!shape_ok(dtype, N, HW, C) || !x || !row_scale || !out) return DFD_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    return dtype == DFD_BF16 ? scale_rows_t<bf16>(x, row_scale, out, N, HW, C, st)
+                             : scale_rows_t<float>(x, row_scale, out, N, HW, C, st);
+}
+
+static inline int pick_parts(long rows, int rpb, int pcap) {
+    int cap = pcap < DFD_MAX_PARTIALS ? pcap : DFD_MAX_PARTIALS;
+    // at least ~4 row iterations per workgroup, at most `cap` workgroups
+    long want = (rows + (long)rpb * 4 - 1) / ((long)rpb * 4);
+    if (want < 1) want = 1;
+    if (want > cap) want = cap;
+    return (int)want;
+}
+
+template <typename T>
+static int bn_bwd_reduce_t(const void* g, const void* y, const float* bnstate, const float* rs, int N, int HW, int C,
+                           float* partials, int pcap, int* nparts, hipStream_t st) {
+    const ChanMap cm = make_chanmap(C, Vec<T>::N);
+    const long rows = (long)N * HW;
+    const int P = pick_parts(rows, cm.rpb, pcap);
+    *nparts = P;
+    dim3 grid(P, cm.nvc);
+    if (rs)
+        hipLaunchKernelGGL((k_bn_bwd_reduce<T, true>), grid, dim3(DFD_THREADS), 0, st, (const T*)g, (const T*)y, bnstate, rs,
+                           rows, HW, C, cm, partials);
+    else
+        hipLaunchKernelGGL((k_bn_bwd_reduce<T, false>), grid, dim3(DFD_THREADS), 0, st, (const T*)g, (const T*)y, bnstate, rs,
+                           rows, HW, C, cm, partials);
+    return DFD_CHECK_LAUNCH();
+}
+extern "C" int dfd_bn_bwd_reduce(int dtype, const void* g, const void* y, const float* bnstate, const float* row_scale,
+                                 int N, int HW, int C, float* partials, int pcap, int* nparts, dfd_stream stream) {
+    if (!shape_ok(dtype, N, HW, C) || !g || !y || !bnstate || !partials || !nparts || pcap < 1) return DFD_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    return dtype == DFD_BF16 ? bn_bwd_reduce_t<bf16>(g, y, bnstate, row_scale, N, HW, C, partials, pcap, nparts, st)
+                             : bn_bwd_reduce_t<float>(g, y, bnstate, row_scale, N, HW, C, partials, pcap, nparts, st);
+}
+
+template <typename T>
+static int act_bn_bwd_t(const void* D, const void* y, const float* gate, const float* dpool, const float* bnstate,
+                        int act, void* dz, int N, int HW, int C, float* partials, int pcap, int* nparts,
+                        hipStream_t st) {
+    const ChanMap cm = make_chanmap(C, Vec<T>::N);
+    const long rows = (long)N * HW;
+    const int P = pick_parts(rows, cm.rpb, pcap);
+    *nparts = P;
+    dim3 grid(P, cm.nvc);
+    const float invHW = 1.0f / (float)HW;
+    int mode;
+    if (D && gate && dpool) mode = 1;
+    else if (D && !gate && !dpool) mode = 0;
+    else if (!D && !gate && dpool) mode = 2;
+    else return DFD_EINVAL;
+#define LAUNCH_ABB(MODE) \
+    hipLaunchKernelGGL((k_act_bn_bwd<T, ACT, MODE>), grid, dim3(DFD_THREADS), 0, st, (const T*)D, (const T*)y, gate, dpool, \
+                       bnstate, (T*)dz, rows, HW, C, invHW, cm, partials)
+    DISPATCH_ACT(act, {
+        if (mode == 0) LAUNCH_ABB(0);
+        else if (mode == 1) LAUNCH_ABB(1);
+        else LAUNCH_ABB(2);
+    });
+#undef LAUNCH_ABB
+    return DFD_CHECK_LAUNCH();
+}
+extern "C" int dfd_act_bn_bwd(int dtype, const void* D, const void* y, const float* gate, const float* dpool,
+                              const float* bnstate, int act, void* dz, int N, int HW, int C, float* partials, int pcap,
+                              int* nparts, dfd_stream stream) {
+    if (!shape_ok(dtype, N, HW, C) || !y || !bnstate || !dz || !partials || !nparts || pcap < 1) return DFD_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    return dtype == DFD_BF16
+               ? act_bn_bwd_t<bf16>(D, y, gate, dpool, bnstate, act, dz, N, HW, C, partials, pcap, nparts, st)
+               : act_bn_bwd_t<float>(D, y, gate, dpool, bnstate, act, dz, N, HW, C, partials, pcap, nparts, st);
+}
+
+template <typename T, bool BWD>
+static int pool_t(const void* D, const void* y, const float* bnstate, int act, float* out, int N, int HW, int C,
+                  hipStream_t st) {
+    const ChanMap cm = make_chanmap(C, Vec<T>::N);
+    dim3 grid(cm.nvc, N);
+    const float mul = BWD ? 1.0f : 1.0f / (float)HW;
+    DISPATCH_ACT(act, {
+        hipLaunchKernelGGL((k_pool<T, ACT, BWD>), grid, dim3(DFD_THREADS), 0, st, (const T*)D, (const T*)y, bnstate, out, HW,
+                           C, mul, cm);
+    });
+    return DFD_CHECK_LAUNCH();
+}
+extern "C" int dfd_pool_act(int dtype, const void* y, const float* bnstate, int act, float* pooled, int N, int HW,
+                            int C, dfd_stream stream) {
+    if (!shape_ok(dtype, N, HW, C) || !y || !bnstate || !pooled) return DFD_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    return dtype == DFD_BF16 ? pool_t<bf16, false>(nullptr, y, bnstate, act, pooled, N, HW, C, st)
+                             : pool_t<float, false>(nullptr, y, bnstate, act, pooled, N, HW, C, st);
+}
+extern "C" int dfd_pool_bwd_reduce(int dtype, const void* D, const void* y, const float* bnstate, int act,
+                                   float* dgate, int N, int HW, int C, dfd_stream stream) {
+    if (!shape_ok(dtype, N, HW, C) || !D || !y || !bnstate || !dgate) return DFD_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    return dtype == DFD_BF16 ? pool_t<bf16, true>(D, y, bnstate, act, dgate, N, HW, C, st)
+                             : pool_t<float, true>(D, y, bnstate, act, dgate, N, HW, C, st);
+}
+
+extern "C" int dfd_bn_finalize(const float* partials, int nparts, int C, double count, const float* gamma,
+                               const float* beta, float* running_mean, float* running_var, float momentum, float eps,
+                               float* bnstate, dfd_stream stream) {
+    if (!partials || nparts < 1 || C < 1 || count <= 0 || !bnstate) return DFD_EINVAL;
+    if ((running_mean == nullptr) != (running_var == nullptr)) return DFD_EINVAL;
+    const int threads = 256, grid = (C * 4 + threads - 1) / threads;
+    hipLaunchKernelGGL(k_bn_finalize, dim3(grid), dim3(threads), 0, (hipStream_t)stream, partials, nparts, C, count, gamma,
+                       beta, running_mean, running_var, momentum, eps, bnstate);
+    return DFD_CHECK_LAUNCH();
+}
+extern "C" int dfd_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean,
+                                  const float* running_var, float eps, int C, float* bnstate, dfd_stream stream) {
+    if (!running_mean || !running_var || C < 1 || !bnstate) return DFD_EINVAL;
+    const int threads = 256, grid = (C + threads - 1) / threads;
+    hipLaunchKernelGGL(k_bn_eval_coeffs, dim3(grid), dim3(threads), 0, (hipStream_t)stream, gamma, beta, running_mean,
+                       running_var, eps, C, bnstate);
+    return DFD_CHECK_LAUNCH();
+}
+extern "C" int dfd_bn_bwd_finalize(const float* partials, int nparts, int C, double count, const float* gamma,
+                                   const float* bnstate, int train, float* dgamma, float* dbeta, int accumulate,
+                                   float* coef, dfd_stream stream) {
+    if (!partials || nparts < 1 || C < 1 || count <= 0 || !bnstate || !coef) return DFD_EINVAL;
+    const int threads = 256, grid = (C * 4 + threads - 1) / threads;
+    hipLaunchKernelGGL(k_bn_bwd_finalize, dim3(grid), dim3(threads), 0, (hipStream_t)stream, partials, nparts, C, count,
+                       gamma, bnstate, train, dgamma, dbeta, accumulate, coef);
+    return DFD_CHECK_LAUNCH();
+}
+
+extern "C" int dfd_version(void) { return 100; }

@@ -1,0 +1,385 @@
+"""Torch-tensor front end of the C ABI (include/dfd_hip.h).
+
+Every function here takes NHWC tensors ([N, H, W, C] contiguous, f32 or bf16) that
+live on a HIP device, allocates outputs with torch (device memory is torch's job),
+and enqueues exactly the kernels of libdfd_hip.so on torch's current stream.  There
+is no fallback: a CPU tensor or a missing library raises.
+"""
+
+from __future__ import annotations
+
+import ctypes
+from dataclasses import dataclass
+
+import torch
+
+from . import _lib
+from ._lib import (
+    ACT_NONE, ACT_SILU, BF16, F32, MAX_PARTIALS, PRO_AFFINE2, PRO_BN_ACT, PRO_BN_ACT_GATE, PRO_NONE,
+    DwShape, Prologue, StemShape, check,
+)
+
+_scratch: dict[tuple[int, str], torch.Tensor] = {}
+
+
+def _L():
+    return _lib.load()
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _dt(t: torch.Tensor) -> int:
+    if t.dtype == torch.float32:
+        return F32
+    if t.dtype == torch.bfloat16:
+        return BF16
+    raise TypeError(f"unsupported activation dtype {t.dtype}")
+
+
+def _p(t: torch.Tensor | None):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("dfd kernels need tensors on a HIP device (no CPU fallback)")
+    return t.data_ptr()
+
+
+def _chk_nhwc(t: torch.Tensor) -> None:
+    if t.dim() != 4 or not t.is_contiguous():
+        raise ValueError("expected a contiguous [N, H, W, C] tensor")
+
+
+def scratch(device: torch.device, name: str, nbytes: int) -> torch.Tensor:
+    """A grow-only f32 scratch buffer per (device, purpose); reuse is stream-ordered."""
+    key = (device.index if device.index is not None else torch.cuda.current_device(), name)
+    buf = _scratch.get(key)
+    need = (nbytes + 3) // 4
+    if buf is None or buf.numel() < need:
+        buf = torch.empty(max(need, 1), dtype=torch.float32, device=device)
+        _scratch[key] = buf
+    return buf
+
+
+def partials_buf(device: torch.device, C: int) -> torch.Tensor:
+    return scratch(device, "partials", MAX_PARTIALS * 2 * C * 4)
+
+
+@dataclass
+class BNParams:
+    """The tensors of one BatchNorm2d plus its hyper-parameters."""
+
+    weight: torch.Tensor
+    bias: torch.Tensor
+    running_mean: torch.Tensor
+    running_var: torch.Tensor
+    momentum: float
+    eps: float
+
+
+# ------------------------------------------------------------------ BatchNorm
+def bn_finalize(partials: torch.Tensor, nparts: int, count: int, bn: BNParams, update_running: bool = True) -> torch.Tensor:
+    C = bn.weight.numel()
+    state = torch.empty((4, C), dtype=torch.float32, device=partials.device)
+    rm = bn.running_mean if update_running else None
+    rv = bn.running_var if update_running else None
+    check(_L().dfd_bn_finalize(_p(partials), nparts, C, float(count), _p(bn.weight), _p(bn.bias), _p(rm), _p(rv),
+                               bn.momentum, bn.eps, _p(state), _stream()), "dfd_bn_finalize")
+    return state
+
+
+def bn_eval_coeffs(bn: BNParams) -> torch.Tensor:
+    C = bn.weight.numel()
+    state = torch.empty((4, C), dtype=torch.float32, device=bn.weight.device)
+    check(_L().dfd_bn_eval_coeffs(_p(bn.weight), _p(bn.bias), _p(bn.running_mean), _p(bn.running_var), bn.eps, C,
+                                  _p(state), _stream()), "dfd_bn_eval_coeffs")
+    return state
+
+
+def bn_bwd_finalize(partials: torch.Tensor, nparts: int, count: int, gamma: torch.Tensor, state: torch.Tensor,
+                    train: bool, want_param_grads: bool = True):
+    C = gamma.numel()
+    coef = torch.empty((3, C), dtype=torch.float32, device=gamma.device)
+    dgamma = torch.empty(C, dtype=torch.float32, device=gamma.device) if want_param_grads else None
+    dbeta = torch.empty(C, dtype=torch.float32, device=gamma.device) if want_param_grads else None
+    check(_L().dfd_bn_bwd_finalize(_p(partials), nparts, C, float(count), _p(gamma), _p(state), int(train),
+                                   _p(dgamma), _p(dbeta), 0, _p(coef), _stream()), "dfd_bn_bwd_finalize")
+    return coef, dgamma, dbeta
+
+
+def bn_act_apply(y: torch.Tensor, state: torch.Tensor, act: int, residual: torch.Tensor | None = None,
+                 row_scale: torch.Tensor | None = None) -> torch.Tensor:
+    _chk_nhwc(y)
+    N, H, W, C = y.shape
+    out = torch.empty_like(y)
+    check(_L().dfd_bn_act_apply(_dt(y), _p(y), _p(state), act, _p(residual), _p(row_scale), _p(out), N, H * W, C,
+                                _stream()), "dfd_bn_act_apply", str(tuple(y.shape)))
+    return out
+
+
+def bn_bwd_reduce(g: torch.Tensor, y: torch.Tensor, state: torch.Tensor, row_scale: torch.Tensor | None = None):
+    _chk_nhwc(y)
+    N, H, W, C = y.shape
+    parts = partials_buf(y.device, C)
+    n = ctypes.c_int(0)
+    check(_L().dfd_bn_bwd_reduce(_dt(y), _p(g), _p(y), _p(state), _p(row_scale), N, H * W, C, _p(parts), MAX_PARTIALS,
+                                 ctypes.byref(n), _stream()), "dfd_bn_bwd_reduce", str(tuple(y.shape)))
+    return parts, n.value
+
+
+def act_bn_bwd(D: torch.Tensor | None, y: torch.Tensor, gate: torch.Tensor | None, dpool: torch.Tensor | None,
+               state: torch.Tensor, act: int):
+    _chk_nhwc(y)
+    N, H, W, C = y.shape
+    dz = torch.empty_like(y)
+    parts = partials_buf(y.device, C)
+    n = ctypes.c_int(0)
+    check(_L().dfd_act_bn_bwd(_dt(y), _p(D), _p(y), _p(gate), _p(dpool), _p(state), act, _p(dz), N, H * W, C, _p(parts),
+                              MAX_PARTIALS, ctypes.byref(n), _stream()), "dfd_act_bn_bwd", str(tuple(y.shape)))
+    return dz, parts, n.value
+
+
+def pool_act(y: torch.Tensor, state: torch.Tensor, act: int) -> torch.Tensor:
+    _chk_nhwc(y)
+    N, H, W, C = y.shape
+    pooled = torch.empty((N, C), dtype=torch.float32, device=y.device)
+    check(_L().dfd_pool_act(_dt(y), _p(y), _p(state), act, _p(pooled), N, H * W, C, _stream()), "dfd_pool_act")
+    return pooled
+
+
+def pool_bwd_reduce(D: torch.Tensor, y: torch.Tensor, state: torch.Tensor, act: int) -> torch.Tensor:
+    _chk_nhwc(y)
+    N, H, W, C = y.shape
+    dgate = torch.empty((N, C), dtype=torch.float32, device=y.device)
+    check(_L().dfd_pool_bwd_reduce(_dt(y), _p(D), _p(y), _p(state), act, _p(dgate), N, H * W, C, _stream()),
+          "dfd_pool_bwd_reduce")
+    return dgate
+
+
+def scale_rows(x: torch.Tensor, row_scale: torch.Tensor) -> torch.Tensor:
+    _chk_nhwc(x)
+    N, H, W, C = x.shape
+    out = torch.empty_like(x)
+    check(_L().dfd_scale_rows(_dt(x), _p(x), _p(row_scale), _p(out), N, H * W, C, _stream()), "dfd_scale_rows")
+    return out
+
+
+# ------------------------------------------------------------------ squeeze-excite
+def se_fc_fwd(pooled: torch.Tensor, w1, b1, w2, b2, act: int):
+    N, C = pooled.shape
+    R = w1.shape[0]
+    hpre = torch.empty((N, R), dtype=torch.float32, device=pooled.device)
+    gate = torch.empty((N, C), dtype=torch.float32, device=pooled.device)
+    check(_L().dfd_se_fc_fwd(_p(pooled), _p(w1), _p(b1), _p(w2), _p(b2), N, C, R, act, _p(hpre), _p(gate), _stream()),
+          "dfd_se_fc_fwd", f"C={C} R={R}")
+    return hpre, gate
+
+
+def se_fc_bwd(dgate, gate, hpre, pooled, w1, w2, act: int, want_param_grads: bool = True):
+    N, C = pooled.shape
+    R = w1.shape[0]
+    dev = pooled.device
+    dpooled = torch.empty((N, C), dtype=torch.float32, device=dev)
+    ws = scratch(dev, "se_ws", (N * C + 2 * N * R) * 4)
+    if want_param_grads:
+        dw1 = torch.empty((R, C), dtype=torch.float32, device=dev)
+        db1 = torch.empty(R, dtype=torch.float32, device=dev)
+        dw2 = torch.empty((C, R), dtype=torch.float32, device=dev)
+        db2 = torch.empty(C, dtype=torch.float32, device=dev)
+    else:
+        dw1 = db1 = dw2 = db2 = None
+    check(_L().dfd_se_fc_bwd(_p(dgate), _p(gate), _p(hpre), _p(pooled), _p(w1), _p(w2), N, C, R, act, _p(dpooled),
+                             _p(dw1), _p(db1), _p(dw2), _p(db2), 0, _p(ws), _stream()), "dfd_se_fc_bwd")
+    return dpooled, dw1, db1, dw2, db2
+
+
+# ------------------------------------------------------------------ depthwise
+def _dw_shape(x_shape, Ho: int, Wo: int, k: int, stride: int, pad_top: int, pad_left: int) -> DwShape:
+    N, H, W, C = x_shape
+    return DwShape(N, H, W, C, Ho, Wo, k, stride, pad_top, pad_left)
+
+
+def dwconv_fwd(x: torch.Tensor, in_state: torch.Tensor | None, in_act: int, w: torch.Tensor, k: int, stride: int,
+               pad_top: int, pad_left: int, Ho: int, Wo: int, stats: bool = True):
+    """y = dwconv(act(bn(x))); w is torch's [C,1,k,k] f32 weight. Returns (y, partials, nparts)."""
+    _chk_nhwc(x)
+    N, H, W, C = x.shape
+    y = torch.empty((N, Ho, Wo, C), dtype=x.dtype, device=x.device)
+    shp = _dw_shape(x.shape, Ho, Wo, k, stride, pad_top, pad_left)
+    parts = partials_buf(x.device, C) if stats else None
+    n = ctypes.c_int(0)
+    check(_L().dfd_dwconv_fwd(_dt(x), _p(x), _p(in_state), in_act, _p(w), _p(y), ctypes.byref(shp), _p(parts),
+                              MAX_PARTIALS, ctypes.byref(n), _stream()), "dfd_dwconv_fwd", f"{tuple(x.shape)} k{k}s{stride}")
+    return y, parts, n.value
+
+
+def dwconv_bwd_data(dz: torch.Tensor, y: torch.Tensor | None, coef: torch.Tensor | None, w: torch.Tensor,
+                    xin: torch.Tensor | None, in_state: torch.Tensor | None, in_act: int, in_shape, k: int, stride: int,
+                    pad_top: int, pad_left: int):
+    """Returns (dzin, partials, nparts); xin=None: plain input gradient, no statistics."""
+    N, H, W, C = in_shape
+    Ho, Wo = dz.shape[1], dz.shape[2]
+    dzin = torch.empty((N, H, W, C), dtype=dz.dtype, device=dz.device)
+    shp = _dw_shape(in_shape, Ho, Wo, k, stride, pad_top, pad_left)
+    parts = partials_buf(dz.device, C) if xin is not None else None
+    n = ctypes.c_int(0)
+    check(_L().dfd_dwconv_bwd_data(_dt(dz), _p(dz), _p(y), _p(coef), _p(w), _p(xin), _p(in_state), in_act, _p(dzin),
+                                   ctypes.byref(shp), _p(parts), MAX_PARTIALS, ctypes.byref(n), _stream()),
+          "dfd_dwconv_bwd_data", f"{tuple(in_shape)} k{k}s{stride}")
+    return dzin, parts, n.value
+
+
+def dwconv_bwd_weight(dz: torch.Tensor, y: torch.Tensor | None, coef: torch.Tensor | None, xin: torch.Tensor,
+                      in_state: torch.Tensor | None, in_act: int, k: int, stride: int, pad_top: int, pad_left: int) -> torch.Tensor:
+    N, H, W, C = xin.shape
+    Ho, Wo = dz.shape[1], dz.shape[2]
+    shp = _dw_shape(xin.shape, Ho, Wo, k, stride, pad_top, pad_left)
+    nbytes = _L().dfd_dwconv_bwd_weight_ws(ctypes.byref(shp))
+    ws = scratch(dz.device, "wgrad_ws", nbytes)
+    dw = torch.empty((C, 1, k, k), dtype=torch.float32, device=dz.device)
+    check(_L().dfd_dwconv_bwd_weight(_dt(dz), _p(dz), _p(y), _p(coef), _p(xin), _p(in_state), in_act, _p(dw),
+                                     ctypes.byref(shp), 0, _p(ws), ws.numel() * 4, _stream()), "dfd_dwconv_bwd_weight")
+    return dw
+
+
+# ------------------------------------------------------------------ pointwise
+def _pro(mode: int = PRO_NONE, act: int = ACT_NONE, HW: int = 1, a2=None, coef=None, gate=None) -> Prologue:
+    return Prologue(mode, act, HW, 0, _p(a2), _p(coef), _p(gate))
+
+
+def pro_bn_act(state: torch.Tensor, act: int) -> Prologue:
+    return _pro(PRO_BN_ACT, act, 1, None, state, None)
+
+
+def pro_bn_act_gate(state: torch.Tensor, act: int, gate: torch.Tensor, HW: int) -> Prologue:
+    return _pro(PRO_BN_ACT_GATE, act, HW, None, state, gate)
+
+
+def pro_affine2(a2: torch.Tensor, coef: torch.Tensor) -> Prologue:
+    return _pro(PRO_AFFINE2, ACT_NONE, 1, a2, coef, None)
+
+
+def prep_weights(w: torch.Tensor, dtype: torch.dtype, want_nk: bool = True, want_kn: bool = True):
+    """f32 master [Nout, K(,1,1)] -> (w_nk, w_kn) in the activation dtype."""
+    Nn, K = w.shape[0], w.shape[1]
+    w_nk = torch.empty((Nn, K), dtype=dtype, device=w.device) if want_nk else None
+    w_kn = torch.empty((K, Nn), dtype=dtype, device=w.device) if want_kn else None
+    code = BF16 if dtype == torch.bfloat16 else F32
+    check(_L().dfd_pw_prep_weights(code, _p(w), _p(w_nk), _p(w_kn), Nn, K, _stream()), "dfd_pw_prep_weights")
+    return w_nk, w_kn
+
+
+def pwconv(a: torch.Tensor, pro: Prologue | None, w_nk: torch.Tensor, residual: torch.Tensor | None = None,
+           stats: bool = False):
+    """out[..., Nout] = P(a)[..., K] @ w_nk[Nout, K]^T (+ residual). Returns (out, partials, nparts)."""
+    K = a.shape[-1]
+    M = a.numel() // K
+    Nout = w_nk.shape[0]
+    out = torch.empty((*a.shape[:-1], Nout), dtype=a.dtype, device=a.device)
+    parts = partials_buf(a.device, Nout) if stats else None
+    n = ctypes.c_int(0)
+    check(_L().dfd_pwconv_fwd(_dt(a), _p(a), ctypes.byref(pro) if pro is not None else None, _p(w_nk), _p(out),
+                              _p(residual), M, K, Nout, _p(parts), MAX_PARTIALS, ctypes.byref(n), _stream()),
+          "dfd_pwconv_fwd", f"M={M} K={K} N={Nout}")
+    return out, parts, n.value
+
+
+def pwconv_wgrad(p: torch.Tensor, pro_p: Prologue | None, q: torch.Tensor, pro_q: Prologue | None) -> torch.Tensor:
+    """dw[Ni, Nj] = sum_m P(p)[m, i] * Q(q)[m, j]."""
+    Ni, Nj = p.shape[-1], q.shape[-1]
+    M = p.numel() // Ni
+    nbytes = _L().dfd_pwconv_wgrad_ws(M, Ni, Nj)
+    ws = scratch(p.device, "wgrad_ws", nbytes)
+    dw = torch.empty((Ni, Nj), dtype=torch.float32, device=p.device)
+    check(_L().dfd_pwconv_wgrad(_dt(p), _p(p), ctypes.byref(pro_p) if pro_p is not None else None, Ni, _p(q),
+                                ctypes.byref(pro_q) if pro_q is not None else None, Nj, M, _p(dw), 0, _p(ws),
+                                ws.numel() * 4, _stream()), "dfd_pwconv_wgrad", f"M={M} Ni={Ni} Nj={Nj}")
+    return dw
+
+
+# ------------------------------------------------------------------ stem
+def _stem_shape(x_shape, Cout: int, Ho: int, Wo: int, k: int, stride: int, pt: int, pl: int) -> StemShape:
+    N, H, W, _ = x_shape
+    return StemShape(N, H, W, Cout, Ho, Wo, k, stride, pt, pl)
+
+
+def stem_conv_fwd(x: torch.Tensor, w: torch.Tensor, out_dtype: torch.dtype, stride: int, pad_top: int, pad_left: int,
+                  Ho: int, Wo: int, stats: bool = True):
+    """x: [N,H,W,3] f32; w: [Cout,3,k,k] f32."""
+    _chk_nhwc(x)
+    if x.dtype != torch.float32 or x.shape[3] != 3:
+        raise ValueError("stem input must be f32 [N,H,W,3]")
+    Cout, k = w.shape[0], w.shape[2]
+    y = torch.empty((x.shape[0], Ho, Wo, Cout), dtype=out_dtype, device=x.device)
+    shp = _stem_shape(x.shape, Cout, Ho, Wo, k, stride, pad_top, pad_left)
+    parts = partials_buf(x.device, Cout) if stats else None
+    n = ctypes.c_int(0)
+    check(_L().dfd_stem_conv_fwd(_dt(y), _p(x), _p(w), _p(y), ctypes.byref(shp), _p(parts), MAX_PARTIALS,
+                                 ctypes.byref(n), _stream()), "dfd_stem_conv_fwd")
+    return y, parts, n.value
+
+
+def stem_conv_wgrad(x: torch.Tensor, dz: torch.Tensor, y: torch.Tensor | None, coef: torch.Tensor | None, k: int,
+                    stride: int, pad_top: int, pad_left: int) -> torch.Tensor:
+    Cout, Ho, Wo = dz.shape[3], dz.shape[1], dz.shape[2]
+    shp = _stem_shape(x.shape, Cout, Ho, Wo, k, stride, pad_top, pad_left)
+    nbytes = _L().dfd_stem_conv_wgrad_ws(ctypes.byref(shp))
+    ws = scratch(dz.device, "wgrad_ws", nbytes)
+    dw = torch.empty((Cout, 3, k, k), dtype=torch.float32, device=dz.device)
+    check(_L().dfd_stem_conv_wgrad(_dt(dz), _p(x), _p(dz), _p(y), _p(coef), _p(dw), ctypes.byref(shp), 0, _p(ws),
+                                   ws.numel() * 4, _stream()), "dfd_stem_conv_wgrad")
+    return dw
+
+
+# ------------------------------------------------------------------ head / loss / optimizer
+def dropout(x: torch.Tensor, u: torch.Tensor, p: float) -> torch.Tensor:
+    out = torch.empty_like(x)
+    check(_L().dfd_dropout(_p(x), _p(u), p, _p(out), x.numel(), _stream()), "dfd_dropout")
+    return out
+
+
+def linear_fwd(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor | None) -> torch.Tensor:
+    N, K = x.shape
+    J = w.shape[0]
+    out = torch.empty((N, J), dtype=torch.float32, device=x.device)
+    check(_L().dfd_linear_fwd(_p(x), _p(w), _p(b), _p(out), N, K, J, _stream()), "dfd_linear_fwd")
+    return out
+
+
+def linear_bwd(dout: torch.Tensor, x: torch.Tensor, w: torch.Tensor, need_dx: bool, need_dw: bool, has_bias: bool):
+    N, K = x.shape
+    J = w.shape[0]
+    dev = x.device
+    dx = torch.empty((N, K), dtype=torch.float32, device=dev) if need_dx else None
+    dw = torch.empty((J, K), dtype=torch.float32, device=dev) if need_dw else None
+    db = torch.empty(J, dtype=torch.float32, device=dev) if (need_dw and has_bias) else None
+    check(_L().dfd_linear_bwd(_p(dout), _p(x), _p(w), _p(dx), _p(dw), _p(db), N, K, J, 0, _stream()), "dfd_linear_bwd")
+    return dx, dw, db
+
+
+def ce_loss(logits: torch.Tensor, targets: torch.Tensor, label_smoothing: float, grad_scale: float = 1.0,
+            want_grad: bool = True):
+    N, J = logits.shape
+    dev = logits.device
+    row_loss = torch.empty(N, dtype=torch.float32, device=dev)
+    loss = torch.empty((), dtype=torch.float32, device=dev)
+    dlogits = torch.empty_like(logits) if want_grad else None
+    check(_L().dfd_ce_loss(_p(logits), _p(targets), N, J, label_smoothing, grad_scale, _p(row_loss), _p(loss),
+                           _p(dlogits), _stream()), "dfd_ce_loss")
+    return loss, dlogits
+
+
+def softmax_argmax(logits: torch.Tensor, want_probs: bool = True):
+    N, J = logits.shape
+    probs = torch.empty_like(logits) if want_probs else None
+    preds = torch.empty(N, dtype=torch.int64, device=logits.device)
+    check(_L().dfd_softmax_argmax(_p(logits), N, J, _p(probs), _p(preds), _stream()), "dfd_softmax_argmax")
+    return probs, preds
+
+
+def adamw_step(table: torch.Tensor, hp: torch.Tensor) -> None:
+    check(_L().dfd_adamw_step(_p(table), table.shape[0], _p(hp), _stream()), "dfd_adamw_step")
+
+
+__all__ = [name for name in dir() if not name.startswith("_")]

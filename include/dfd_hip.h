@@ -1,0 +1,223 @@
+/* dfd_hip.h — C ABI of libdfd_hip.so: the MI355X (gfx950) kernels behind the
+ * DeepfakeDetection image-classifier hot loop.
+ *
+ * The reference (thourihan/DeepfakeDetection) has no FFI of its own: its hot loop
+ * calls third-party nn.Modules (efficientnet_pytorch 0.7.1 / timm 1.0.20) whose
+ * arithmetic runs in ATen/cuDNN.  Every entry point below therefore cites the
+ * reference CALL SITE whose arithmetic it carries:
+ *
+ *   forward          logits = model(inputs)            trainers/efficientnet.py:297, :254
+ *                                                      orchestration/orchestrator.py:529, :590
+ *   loss             criterion(logits, targets)        trainers/efficientnet.py:298, :412
+ *   backward         scaler.scale(loss).backward()     trainers/efficientnet.py:302
+ *   optimizer        scaler.step(opt)                  trainers/efficientnet.py:305-306, :487-491
+ *   inference tail   softmax(dim=1) / argmax           orchestration/orchestrator.py:591-592
+ *
+ * Rules of the boundary ("B-inner"):
+ *   - plain pointers and sizes only; no torch types.
+ *   - every buffer (inputs, outputs, workspaces, partial-sum slabs) is allocated by
+ *     the caller; the library never allocates, frees or keeps a pointer past return.
+ *   - every call only enqueues work on `stream` and never synchronises; it is safe
+ *     under hipGraph stream capture and re-entrant across host threads.
+ *   - return value: DFD_OK or a negative DFD_E* code; no exceptions cross the ABI.
+ *   - layouts: activations NHWC ([N*H*W][C] row-major) of dtype DFD_F32 or DFD_BF16,
+ *     C % 8 == 0; depthwise weights [C][k][k] f32 (torch's [C,1,k,k]); pointwise
+ *     weights [Cout][Cin]; BN statistics / coefficients / SE gates f32.
+ *   - reductions over rows (BN statistics, weight gradients) are written as
+ *     per-workgroup partial slabs and summed by a second kernel in a fixed order:
+ *     results are bitwise reproducible run to run.
+ */
+#ifndef DFD_HIP_H
+#define DFD_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* dfd_stream;          /* a hipStream_t */
+
+#define DFD_OK            0
+#define DFD_EINVAL       (-1)      /* bad argument / shape not divisible as required */
+#define DFD_EUNSUPPORTED (-2)      /* kernel size / stride / activation not implemented */
+#define DFD_ELAUNCH      (-3)      /* hipGetLastError() != hipSuccess after the launch */
+#define DFD_EWORKSPACE   (-4)      /* caller's workspace too small */
+
+#define DFD_F32   0
+#define DFD_BF16  1
+
+#define DFD_ACT_NONE 0
+#define DFD_ACT_SILU 1
+#define DFD_ACT_RELU 2
+#define DFD_ACT_GELU 3
+
+/* upper bound on the number of partial-sum rows any kernel writes */
+#define DFD_MAX_PARTIALS 1024
+
+/* BN state: float[4][C] = scale, shift, mean, rstd  (z = scale*y + shift)
+ * BN backward coefficients: float[3][C] = a, b, c   (dy = a*g + b*y + c)      */
+#define DFD_BNSTATE_ROWS 4
+#define DFD_BNCOEF_ROWS  3
+
+int dfd_version(void);
+
+/* ---------------------------------------------------------------- BatchNorm ---
+ * F.batch_norm inside every conv-bn(-act) triple of the reference's modules
+ * (efficientnet_pytorch MBConvBlock._bn0/_bn1/_bn2; timm BatchNormAct2d).      */
+
+/* training mode: partial (sum, sumsq) slabs [nparts][2][C] -> bnstate, running stats */
+int dfd_bn_finalize(const float* partials, int nparts, int C, double count,
+                    const float* gamma, const float* beta,
+                    float* running_mean, float* running_var, float momentum, float eps,
+                    float* bnstate, dfd_stream stream);
+/* eval mode: running stats -> bnstate */
+int dfd_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean,
+                       const float* running_var, float eps, int C, float* bnstate,
+                       dfd_stream stream);
+/* backward: partial (sum g, sum g*xhat) slabs -> dgamma, dbeta, coef.  train==0:
+ * statistics were constants (eval-mode BN), so dy = gamma*rstd*g.               */
+int dfd_bn_bwd_finalize(const float* partials, int nparts, int C, double count,
+                        const float* gamma, const float* bnstate, int train,
+                        float* dgamma, float* dbeta, int accumulate, float* coef,
+                        dfd_stream stream);
+
+/* out = act(scale*y + shift) [* row_scale[n]] [+ residual]; all [N][HW][C].     */
+int dfd_bn_act_apply(int dtype, const void* y, const float* bnstate, int act,
+                     const void* residual, const float* row_scale, void* out,
+                     int N, int HW, int C, dfd_stream stream);
+/* partial sums of (g*rs, g*rs*xhat) per channel, xhat = (y-mean)*rstd            */
+int dfd_bn_bwd_reduce(int dtype, const void* g, const void* y, const float* bnstate,
+                      const float* row_scale, int N, int HW, int C,
+                      float* partials, int pcap, int* nparts, dfd_stream stream);
+/* dz = (D*gate[n,c] + dpool[n,c]/HW) * act'(scale*y+shift); writes dz and the partial
+ * sums (dz, dz*xhat).  D, gate, dpool are each optional (NULL): D==NULL means the
+ * incoming gradient is dpool/HW only (global-average-pool backward).             */
+int dfd_act_bn_bwd(int dtype, const void* D, const void* y, const float* gate,
+                   const float* dpool, const float* bnstate, int act, void* dz,
+                   int N, int HW, int C, float* partials, int pcap, int* nparts,
+                   dfd_stream stream);
+/* pooled[n,c] = mean_hw act(scale*y+shift): SE squeeze and the classifier's
+ * global average pool.                                                           */
+int dfd_pool_act(int dtype, const void* y, const float* bnstate, int act, float* pooled,
+                 int N, int HW, int C, dfd_stream stream);
+/* dgate[n,c] = sum_hw D * act(scale*y+shift)                                      */
+int dfd_pool_bwd_reduce(int dtype, const void* D, const void* y, const float* bnstate,
+                        int act, float* dgate, int N, int HW, int C, dfd_stream stream);
+/* out = x * row_scale[n] (drop-connect on the gradient side)                      */
+int dfd_scale_rows(int dtype, const void* x, const float* row_scale, void* out,
+                   int N, int HW, int C, dfd_stream stream);
+
+/* ------------------------------------------------------------ squeeze-excite ---
+ * MBConvBlock._se_reduce/_se_expand (efficientnet_pytorch), SqueezeExcite (timm):
+ * gate = sigmoid(W2 * act(W1*pooled + b1) + b2).                                 */
+int dfd_se_fc_fwd(const float* pooled, const float* w1, const float* b1, const float* w2,
+                  const float* b2, int N, int C, int R, int act, float* hpre, float* gate,
+                  dfd_stream stream);
+/* ws: float[N*C + 2*N*R] scratch; R <= 128, C <= 4096 */
+int dfd_se_fc_bwd(const float* dgate, const float* gate, const float* hpre,
+                  const float* pooled, const float* w1, const float* w2,
+                  int N, int C, int R, int act, float* dpooled,
+                  float* dw1, float* db1, float* dw2, float* db2, int accumulate,
+                  float* ws, dfd_stream stream);
+
+/* ----------------------------------------------------------- depthwise conv ---
+ * F.conv2d(groups=C) of MBConvBlock._depthwise_conv / timm conv_dw, k in {3,5},
+ * stride in {1,2}, arbitrary (asymmetric "SAME") top/left padding.               */
+typedef struct {
+    int N, H, W, C;        /* input  [N][H][W][C]   */
+    int Ho, Wo;            /* output [N][Ho][Wo][C] */
+    int k, stride, pad_top, pad_left;
+} dfd_dwconv_shape;
+
+/* y = dwconv(act(scale*x+shift)) (in_bnstate==NULL: x used as is); optional stats */
+int dfd_dwconv_fwd(int dtype, const void* x, const float* in_bnstate, int in_act,
+                   const float* w, void* y, const dfd_dwconv_shape* s,
+                   float* partials, int pcap, int* nparts, dfd_stream stream);
+/* dy = a*dz + b*y + c (coef; coef==NULL: dy = dz).  da = dwconv^T(dy).
+ * xin != NULL: dzin = da * act'(scale*xin+shift) and partial sums (dzin, dzin*xhat);
+ * xin == NULL: dzin = da.                                                        */
+int dfd_dwconv_bwd_data(int dtype, const void* dz, const void* y, const float* coef,
+                        const float* w, const void* xin, const float* in_bnstate, int in_act,
+                        void* dzin, const dfd_dwconv_shape* s,
+                        float* partials, int pcap, int* nparts, dfd_stream stream);
+/* dw[c][kh][kw] = sum dy * act(scale*xin+shift) (in_bnstate==NULL: xin as is)      */
+int dfd_dwconv_bwd_weight(int dtype, const void* dz, const void* y, const float* coef,
+                          const void* xin, const float* in_bnstate, int in_act,
+                          float* dw, const dfd_dwconv_shape* s, int accumulate,
+                          float* ws, size_t ws_bytes, dfd_stream stream);
+size_t dfd_dwconv_bwd_weight_ws(const dfd_dwconv_shape* s);
+
+/* ----------------------------------------------------------- pointwise conv ---
+ * 1x1 convolutions (_expand_conv, _project_conv, _conv_head; timm conv_pw/conv_pwl/
+ * conv_head) as MFMA GEMMs over the NHWC row matrix, with the producer's BN + act
+ * (+ SE gate) applied to the A operand on the way in.                            */
+#define DFD_PRO_NONE        0   /* a                                              */
+#define DFD_PRO_BN_ACT      1   /* act(scale[k]*a + shift[k])                     */
+#define DFD_PRO_BN_ACT_GATE 2   /* act(scale[k]*a + shift[k]) * gate[row/HW][k]   */
+#define DFD_PRO_AFFINE2     3   /* ca[k]*a + cb[k]*a2 + cc[k]                     */
+typedef struct {
+    int mode;
+    int act;
+    int HW;                 /* rows per image (gate lookup) */
+    int _pad;
+    const void* a2;         /* AFFINE2: second operand, same shape/dtype as a */
+    const float* coef;      /* BN_ACT*: bnstate [4][K]; AFFINE2: coef [3][K]  */
+    const float* gate;      /* BN_ACT_GATE: [N][K] */
+} dfd_prologue;
+
+/* out[M][Nout] = P(a)[M][K] * w[Nout][K]^T (+ residual); w in `dtype`.
+ * partials != NULL: (sum, sumsq) per output channel of the rounded output.       */
+int dfd_pwconv_fwd(int dtype, const void* a, const dfd_prologue* pro, const void* w,
+                   void* out, const void* residual, int M, int K, int Nout,
+                   float* partials, int pcap, int* nparts, dfd_stream stream);
+/* dw[Ni][Nj] = sum_m P(p)[m][i] * Q(q)[m][j]                                       */
+int dfd_pwconv_wgrad(int dtype, const void* p, const dfd_prologue* pro_p, int Ni,
+                     const void* q, const dfd_prologue* pro_q, int Nj, int M,
+                     float* dw, int accumulate, float* ws, size_t ws_bytes,
+                     dfd_stream stream);
+size_t dfd_pwconv_wgrad_ws(int M, int Ni, int Nj);
+/* f32 master [N][K] -> w_nk [N][K] and w_kn [K][N] in `dtype` (either may be NULL) */
+int dfd_pw_prep_weights(int dtype, const float* w, void* w_nk, void* w_kn, int N, int K,
+                        dfd_stream stream);
+
+/* ------------------------------------------------------------------- stem ---
+ * _conv_stem / conv_stem: k x k stride-2 convolution on the 3-channel f32 image.  */
+typedef struct {
+    int N, H, W, Cout, Ho, Wo, k, stride, pad_top, pad_left;
+} dfd_stem_shape;
+int dfd_stem_conv_fwd(int dtype, const float* x, const float* w, void* y,
+                      const dfd_stem_shape* s, float* partials, int pcap, int* nparts,
+                      dfd_stream stream);
+int dfd_stem_conv_wgrad(int dtype, const float* x, const void* dz, const void* y,
+                        const float* coef, float* dw, const dfd_stem_shape* s,
+                        int accumulate, float* ws, size_t ws_bytes, dfd_stream stream);
+size_t dfd_stem_conv_wgrad_ws(const dfd_stem_shape* s);
+
+/* ------------------------------------------------- classifier, loss, optimizer --- */
+/* out = u >= p ? x/(1-p) : 0   (forward and, with x = grad, backward)              */
+int dfd_dropout(const float* x, const float* u, float p, float* out, int n, dfd_stream stream);
+int dfd_linear_fwd(const float* x, const float* w, const float* b, float* out,
+                   int N, int K, int J, dfd_stream stream);
+int dfd_linear_bwd(const float* dout, const float* x, const float* w, float* dx,
+                   float* dw, float* db, int N, int K, int J, int accumulate,
+                   dfd_stream stream);
+/* nn.CrossEntropyLoss(label_smoothing) mean-reduced; dlogits (optional) is
+ * d(loss*grad_scale)/dlogits.                                                     */
+int dfd_ce_loss(const float* logits, const int64_t* targets, int N, int J,
+                float label_smoothing, float grad_scale, float* row_loss, float* loss,
+                float* dlogits, dfd_stream stream);
+int dfd_softmax_argmax(const float* logits, int N, int J, float* probs, int64_t* preds,
+                       dfd_stream stream);
+/* torch.optim.AdamW step over a chunk table: int64 rows {param, grad, exp_avg,
+ * exp_avg_sq, count}; hp = {lr, beta1, beta2, eps, weight_decay, 1-beta1^t,
+ * 1-beta2^t, grad_scale} in device memory (so a captured graph sees new values).   */
+#define DFD_ADAMW_TABLE_COLS 5
+#define DFD_ADAMW_HP_LEN 8
+int dfd_adamw_step(const int64_t* table, int nchunks, const float* hp, dfd_stream stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DFD_HIP_H */

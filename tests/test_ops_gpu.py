@@ -1,0 +1,389 @@
+"""Kernel-level parity: every C-ABI entry point against the CPU oracle (oracle/ops_ref.py).
+
+Tolerances: f32 kernels rel 2e-4 of the tensor's max magnitude (summation order differs);
+bf16 kernels 1.6e-2 (two bf16 ulps: one rounding in the kernel, one in the oracle's
+emulation), stated per assert.
+"""
+
+from __future__ import annotations
+
+import pytest
+import torch
+
+from oracle import ops_ref as R
+
+pytestmark = pytest.mark.gpu
+
+DT = [torch.float32, torch.bfloat16]
+
+
+def _k():
+    from deepfakedetection_amd import kernels
+
+    return kernels
+
+
+def tol(rd):
+    return 2e-4 if rd == torch.float32 else 1.6e-2
+
+
+def close(got: torch.Tensor, want: torch.Tensor, rel: float, what: str = "") -> None:
+    got = got.detach().float().cpu()
+    want = want.detach().float().cpu()
+    assert got.shape == want.shape, f"{what}: shape {tuple(got.shape)} vs {tuple(want.shape)}"
+    scale = max(float(want.abs().max()), 1e-6)
+    err = float((got - want).abs().max()) / scale
+    assert err <= rel, f"{what}: max err {err:.3e} of max |ref| {scale:.3e} > {rel:.1e}"
+
+
+def gen(shape, seed, rd, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).to(rd)
+
+
+def dev(t):
+    return t.cuda() if t is not None else None
+
+
+def sum_parts(parts, n, C):
+    return parts[: n * 2 * C].view(n, 2, C).double().sum(0).float().cpu()
+
+
+def rand_state(C, seed):
+    g = torch.Generator().manual_seed(seed)
+    scale = 0.5 + torch.rand(C, generator=g)
+    shift = torch.randn(C, generator=g) * 0.3
+    mean = torch.randn(C, generator=g) * 0.2
+    rstd = 0.5 + torch.rand(C, generator=g)
+    return torch.stack([scale, shift, mean, rstd])
+
+
+DW_CASES = [
+    # N, H, W, C, k, s, pt, pl
+    (2, 14, 14, 40, 3, 1, 1, 1),
+    (2, 15, 13, 24, 3, 2, 0, 0),     # TF-SAME asymmetric, odd sizes
+    (1, 28, 28, 144, 5, 1, 2, 2),
+    (2, 16, 16, 48, 5, 2, 1, 1),     # asymmetric (1,2)
+    (2, 7, 7, 1152, 5, 1, 2, 2),
+    (1, 56, 56, 96, 3, 2, 1, 1),     # timm symmetric stride 2
+    (3, 9, 9, 8, 3, 1, 1, 1),        # smallest channel count
+]
+
+
+def out_size(H, k, s, pt, flavour_same):
+    return -(-H // s) if flavour_same else (H + 2 * pt - k) // s + 1
+
+
+@pytest.mark.parametrize("rd", DT)
+@pytest.mark.parametrize("case", DW_CASES)
+def test_dwconv_fwd(case, rd):
+    K = _k()
+    N, H, W, C, k, s, pt, pl = case
+    Ho, Wo = -(-H // s), -(-W // s)
+    x = gen((N, H, W, C), 1, rd)
+    w = gen((C, 1, k, k), 2, torch.float32, 0.3)
+    st = rand_state(C, 3)
+    want = R.dwconv_fwd(x.float(), st, R.ACT_SILU, w, k, s, pt, pl, Ho, Wo, rd)
+    y, parts, n = K.dwconv_fwd(dev(x), dev(st), R.ACT_SILU, dev(w), k, s, pt, pl, Ho, Wo, stats=True)
+    close(y, want, tol(rd), "dwconv_fwd y")
+    close(sum_parts(parts, n, C), R.stats_sums(y.float().cpu()), 1e-3, "dwconv_fwd stats")
+    # no prologue, no stats
+    want2 = R.dwconv_fwd(x.float(), None, 0, w, k, s, pt, pl, Ho, Wo, rd)
+    y2, _, _ = K.dwconv_fwd(dev(x), None, 0, dev(w), k, s, pt, pl, Ho, Wo, stats=False)
+    close(y2, want2, tol(rd), "dwconv_fwd raw")
+
+
+@pytest.mark.parametrize("rd", DT)
+@pytest.mark.parametrize("case", DW_CASES)
+def test_dwconv_bwd(case, rd):
+    K = _k()
+    N, H, W, C, k, s, pt, pl = case
+    Ho, Wo = -(-H // s), -(-W // s)
+    xin = gen((N, H, W, C), 4, rd)
+    dz = gen((N, Ho, Wo, C), 5, rd)
+    yraw = gen((N, Ho, Wo, C), 6, rd)
+    w = gen((C, 1, k, k), 7, torch.float32, 0.3)
+    st = rand_state(C, 8)
+    g = torch.Generator().manual_seed(9)
+    coef = torch.stack([0.5 + torch.rand(C, generator=g), torch.randn(C, generator=g) * 0.1,
+                        torch.randn(C, generator=g) * 0.05])
+    dy = R.rnd(coef[0] * dz.float() + coef[1] * yraw.float() + coef[2], rd)
+    z = st[0] * xin.float() + st[1]
+    xact = R.rnd(R.act_fwd(z, R.ACT_SILU), rd)
+    da, dw = R.dwconv_bwd(dy, xact, w, k, s, pt, pl, rd)
+    want_dzin = R.rnd(da * R.act_grad(z, R.ACT_SILU), rd)
+    dzin, parts, n = K.dwconv_bwd_data(dev(dz), dev(yraw), dev(coef), dev(w), dev(xin), dev(st), R.ACT_SILU,
+                                       (N, H, W, C), k, s, pt, pl)
+    close(dzin, want_dzin, tol(rd), "dwconv_bwd_data")
+    got = dzin.float().cpu()
+    xhat = (xin.float() - st[2]) * st[3]
+    want_sums = torch.stack([got.reshape(-1, C).double().sum(0), (got * xhat).reshape(-1, C).double().sum(0)]).float()
+    close(sum_parts(parts, n, C), want_sums, 2e-3, "dwconv_bwd_data stats")
+    # plain variant: no coef, no epilogue
+    da2, _ = R.dwconv_bwd(dz.float(), xact, w, k, s, pt, pl, rd)
+    dzin2, _, _ = K.dwconv_bwd_data(dev(dz), None, None, dev(w), None, None, 0, (N, H, W, C), k, s, pt, pl)
+    close(dzin2, R.rnd(da2, rd), tol(rd), "dwconv_bwd_data plain")
+    got_dw = K.dwconv_bwd_weight(dev(dz), dev(yraw), dev(coef), dev(xin), dev(st), R.ACT_SILU, k, s, pt, pl)
+    close(got_dw, dw, 5e-3 if rd == torch.bfloat16 else 2e-4, "dwconv_bwd_weight")
+
+
+PW_CASES = [
+    # N, HW, K, Nout
+    (2, 49, 16, 96),
+    (3, 100, 96, 24),
+    (2, 196, 240, 40),
+    (1, 333, 1152, 320),
+    (4, 64, 24, 144),
+    (2, 49, 320, 1280),
+    (2, 130, 40, 8),
+]
+
+
+@pytest.mark.parametrize("rd", DT)
+@pytest.mark.parametrize("mode", [0, 1, 2, 3])
+@pytest.mark.parametrize("case", PW_CASES)
+def test_pwconv_fwd(case, mode, rd):
+    K = _k()
+    N, HW, Kd, No = case
+    a = gen((N, HW, 1, Kd), 11, rd)
+    a2 = gen((N, HW, 1, Kd), 12, rd)
+    w = gen((No, Kd), 13, torch.float32, Kd ** -0.5)
+    st = rand_state(Kd, 14)
+    gate = torch.rand((N, Kd), generator=torch.Generator().manual_seed(15))
+    coef3 = rand_state(Kd, 16)[:3].contiguous()
+    if mode == 0:
+        pro, A = None, a.float()
+    elif mode == 1:
+        pro, A = K.pro_bn_act(dev(st), R.ACT_SILU), R.prologue(a.float().view(N, HW, Kd), 1, rd, R.ACT_SILU, st)
+    elif mode == 2:
+        dgate = dev(gate)
+        pro = K.pro_bn_act_gate(dev(st), R.ACT_SILU, dgate, HW)
+        A = R.prologue(a.float().view(N, HW, Kd), 2, rd, R.ACT_SILU, st, gate=gate)
+    else:
+        da2, dcoef = dev(a2), dev(coef3)
+        pro = K.pro_affine2(da2, dcoef)
+        A = R.prologue(a.float().view(N, HW, Kd), 3, rd, coef=coef3, a2=a2.float().view(N, HW, Kd))
+    w_nk, _ = K.prep_weights(dev(w), rd, True, False)
+    want = R.rnd(A.reshape(N, HW, 1, Kd) @ R.rnd(w, rd).t(), rd)
+    stats = mode != 3
+    out, parts, n = K.pwconv(dev(a), pro, w_nk, None, stats=stats)
+    close(out, want, tol(rd), f"pwconv mode {mode}")
+    if stats:
+        close(sum_parts(parts, n, No), R.stats_sums(out.float().cpu()), 1e-3, "pwconv stats")
+    if mode in (0, 3):
+        res = gen((N, HW, 1, No), 17, rd)
+        out2, _, _ = K.pwconv(dev(a), pro, w_nk, dev(res), stats=False)
+        close(out2, R.rnd(want + res.float(), rd), tol(rd), "pwconv residual")
+
+
+@pytest.mark.parametrize("rd", DT)
+@pytest.mark.parametrize("qmode", [0, 1, 2])
+@pytest.mark.parametrize("case", PW_CASES)
+def test_pwconv_wgrad(case, qmode, rd):
+    K = _k()
+    N, HW, Nj, Ni = case
+    p = gen((N, HW, 1, Ni), 21, rd)
+    p2 = gen((N, HW, 1, Ni), 22, rd)
+    q = gen((N, HW, 1, Nj), 23, rd)
+    coef3 = rand_state(Ni, 24)[:3].contiguous()
+    st = rand_state(Nj, 25)
+    gate = torch.rand((N, Nj), generator=torch.Generator().manual_seed(26))
+    dp2, dcoef, dst, dgate = dev(p2), dev(coef3), dev(st), dev(gate)
+    P = R.prologue(p.float().view(N, HW, Ni), 3, rd, coef=coef3, a2=p2.float().view(N, HW, Ni))
+    if qmode == 0:
+        pq, Q = None, q.float().view(N, HW, Nj)
+    elif qmode == 1:
+        pq, Q = K.pro_bn_act(dst, R.ACT_SILU), R.prologue(q.float().view(N, HW, Nj), 1, rd, R.ACT_SILU, st)
+    else:
+        pq = K.pro_bn_act_gate(dst, R.ACT_SILU, dgate, HW)
+        Q = R.prologue(q.float().view(N, HW, Nj), 2, rd, R.ACT_SILU, st, gate=gate)
+    want = P.reshape(-1, Ni).t().double() @ Q.reshape(-1, Nj).double()
+    got = K.pwconv_wgrad(dev(p), K.pro_affine2(dp2, dcoef), dev(q), pq)
+    close(got, want.float(), 3e-3 if rd == torch.bfloat16 else 2e-4, f"pwconv_wgrad q{qmode}")
+    # plain p
+    want2 = p.float().reshape(-1, Ni).t().double() @ Q.reshape(-1, Nj).double()
+    got2 = K.pwconv_wgrad(dev(p), None, dev(q), pq)
+    close(got2, want2.float(), 3e-3 if rd == torch.bfloat16 else 2e-4, "pwconv_wgrad plain p")
+
+
+ROW_CASES = [(2, 7, 7, 1152), (3, 14, 14, 40), (2, 28, 28, 144), (1, 56, 56, 24), (4, 5, 3, 672), (2, 7, 7, 1280)]
+
+
+@pytest.mark.parametrize("rd", DT)
+@pytest.mark.parametrize("case", ROW_CASES)
+def test_rowpass(case, rd):
+    K = _k()
+    N, H, W, C = case
+    y = gen((N, H, W, C), 31, rd)
+    g = gen((N, H, W, C), 32, rd)
+    res = gen((N, H, W, C), 33, rd)
+    gamma = 0.5 + torch.rand(C, generator=torch.Generator().manual_seed(34))
+    beta = torch.randn(C, generator=torch.Generator().manual_seed(35)) * 0.2
+    rs = 0.5 + torch.rand(N, generator=torch.Generator().manual_seed(36))
+    st = R.bn_state(y.float(), gamma, beta, 1e-3)
+    # apply (+res, +row scale)
+    z = st[0] * y.float() + st[1]
+    close(K.bn_act_apply(dev(y), dev(st), R.ACT_SILU), R.rnd(R.act_fwd(z, 1), rd), tol(rd), "apply silu")
+    want = R.rnd(z * rs[:, None, None, None] + res.float(), rd)
+    close(K.bn_act_apply(dev(y), dev(st), 0, dev(res), dev(rs)), want, tol(rd), "apply res rs")
+    # bn_bwd_reduce + finalize
+    parts, n = K.bn_bwd_reduce(dev(g), dev(y), dev(st), None)
+    coef, dgam, dbet = K.bn_bwd_finalize(parts, n, N * H * W, dev(gamma), dev(st), True)
+    wc, wdg, wdb = R.bn_bwd_coef(g.float(), y.float(), gamma, st)
+    close(coef, wc, 2e-3, "bn bwd coef")
+    close(dgam, wdg, 2e-3, "dgamma")
+    close(dbet, wdb, 2e-3, "dbeta")
+    parts, n = K.bn_bwd_reduce(dev(g), dev(y), dev(st), dev(rs))
+    coef2, _, _ = K.bn_bwd_finalize(parts, n, N * H * W, dev(gamma), dev(st), True)
+    wc2, _, _ = R.bn_bwd_coef(g.float() * rs[:, None, None, None], y.float(), gamma, st)
+    close(coef2, wc2, 2e-3, "bn bwd coef rs")
+    # act_bn_bwd, three modes
+    gate = torch.rand((N, C), generator=torch.Generator().manual_seed(37))
+    dpool = torch.randn((N, C), generator=torch.Generator().manual_seed(38))
+    xhat = (y.float() - st[2]) * st[3]
+    for mode, (D, gt, dp) in enumerate([(g, None, None), (g, gate, dpool), (None, None, dpool)]):
+        if mode == 0:
+            da = g.float()
+        elif mode == 1:
+            da = g.float() * gate[:, None, None, :] + dpool[:, None, None, :] / (H * W)
+        else:
+            da = (dpool[:, None, None, :] / (H * W)).expand(N, H, W, C)
+        want = R.rnd(da * R.act_grad(z, 1), rd)
+        dz, parts, n = K.act_bn_bwd(dev(D), dev(y), dev(gt), dev(dp), dev(st), R.ACT_SILU)
+        close(dz, want, tol(rd), f"act_bn_bwd mode {mode}")
+        got = dz.float().cpu()
+        ws = torch.stack([got.reshape(-1, C).double().sum(0), (got * xhat).reshape(-1, C).double().sum(0)]).float()
+        close(sum_parts(parts, n, C), ws, 2e-3, f"act_bn_bwd sums {mode}")
+    # pools
+    a = R.rnd(R.act_fwd(z, 1), rd)
+    close(K.pool_act(dev(y), dev(st), R.ACT_SILU), a.mean((1, 2)), 1e-3, "pool_act")
+    close(K.pool_bwd_reduce(dev(g), dev(y), dev(st), R.ACT_SILU), (a * g.float()).sum((1, 2)), 2e-3, "pool_bwd")
+    close(K.scale_rows(dev(g), dev(rs)), R.rnd(g.float() * rs[:, None, None, None], rd), tol(rd), "scale_rows")
+
+
+@pytest.mark.parametrize("case", [(4, 32, 8), (3, 1152, 48), (2, 96, 4), (5, 2304, 96)])
+def test_bn_finalize_and_eval(case):
+    K = _k()
+    N, C, _ = case
+    y = gen((N, 6, 5, C), 41, torch.float32, 2.0) + 0.7
+    w = gen((C, 1, 3, 3), 42, torch.float32)
+    gamma = 0.5 + torch.rand(C)
+    beta = torch.randn(C) * 0.1
+    rm, rv = torch.randn(C) * 0.1, 0.5 + torch.rand(C)
+    bn = K.BNParams(dev(gamma), dev(beta), dev(rm.clone()), dev(rv.clone()), 0.01, 1e-3)
+    yy, parts, n = K.dwconv_fwd(dev(y), None, 0, dev(w), 3, 1, 1, 1, 6, 5, stats=True)
+    st = K.bn_finalize(parts, n, N * 30, bn)
+    yc = yy.float().cpu()
+    close(st, R.bn_state(yc, gamma, beta, 1e-3), 1e-4, "bn_finalize state")
+    flat = yc.reshape(-1, C)
+    close(bn.running_mean, 0.99 * rm + 0.01 * flat.mean(0), 1e-5, "running_mean")
+    close(bn.running_var, 0.99 * rv + 0.01 * flat.var(0, unbiased=True), 1e-4, "running_var")
+    bn2 = K.BNParams(dev(gamma), dev(beta), dev(rm), dev(rv), 0.01, 1e-3)
+    st2 = K.bn_eval_coeffs(bn2)
+    rstd = 1 / torch.sqrt(rv + 1e-3)
+    close(st2, torch.stack([gamma * rstd, beta - rm * gamma * rstd, rm, rstd]), 1e-5, "bn_eval")
+
+
+@pytest.mark.parametrize("case", [(4, 32, 8), (3, 1152, 48), (2, 96, 4), (5, 2304, 96)])
+def test_se_fc(case):
+    K = _k()
+    N, C, Rr = case
+    g = torch.Generator().manual_seed(51)
+    pooled = torch.rand((N, C), generator=g)
+    w1 = (torch.randn((Rr, C), generator=g) * C ** -0.5).requires_grad_(True)
+    b1 = (torch.randn(Rr, generator=g) * 0.1).requires_grad_(True)
+    w2 = (torch.randn((C, Rr), generator=g) * Rr ** -0.5).requires_grad_(True)
+    b2 = (torch.randn(C, generator=g) * 0.1).requires_grad_(True)
+    pr = pooled.clone().requires_grad_(True)
+    hpre, gate = R.se_fc(pr, w1, b1, w2, b2, R.ACT_SILU)
+    dgate = torch.randn((N, C), generator=g)
+    gate.backward(dgate)
+    h2, g2 = K.se_fc_fwd(dev(pooled), dev(w1.detach()), dev(b1.detach()), dev(w2.detach()), dev(b2.detach()), R.ACT_SILU)
+    close(h2, hpre, 1e-4, "se hpre")
+    close(g2, gate, 1e-4, "se gate")
+    # the kernel takes d(loss)/d(gate) and applies sigmoid' itself
+    dp, dw1, db1, dw2, db2 = K.se_fc_bwd(dev(dgate), g2, h2, dev(pooled), dev(w1.detach()), dev(w2.detach()), R.ACT_SILU)
+    close(dp, pr.grad, 2e-4, "se dpooled")
+    close(dw1, w1.grad, 2e-4, "se dw1")
+    close(db1, b1.grad, 2e-4, "se db1")
+    close(dw2, w2.grad, 2e-4, "se dw2")
+    close(db2, b2.grad, 2e-4, "se db2")
+
+
+@pytest.mark.parametrize("rd", DT)
+@pytest.mark.parametrize("case", [(2, 32, 32, 32, 0), (2, 33, 31, 40, 1), (1, 224, 224, 32, 1)])
+def test_stem(case, rd):
+    K = _k()
+    N, H, W, Co, pad = case
+    Ho, Wo = -(-H // 2), -(-W // 2)
+    x = gen((N, H, W, 3), 61, torch.float32)
+    w = gen((Co, 3, 3, 3), 62, torch.float32, 0.3)
+    want = R.stem_conv_fwd(x, w, 2, pad, pad, Ho, Wo, rd)
+    y, parts, n = K.stem_conv_fwd(dev(x), dev(w), rd, 2, pad, pad, Ho, Wo)
+    close(y, want, tol(rd), "stem fwd")
+    close(sum_parts(parts, n, Co), R.stats_sums(y.float().cpu()), 1e-3, "stem stats")
+    dz = gen((N, Ho, Wo, Co), 63, rd)
+    yraw = gen((N, Ho, Wo, Co), 64, rd)
+    coef = rand_state(Co, 65)[:3].contiguous()
+    dy = R.rnd(coef[0] * dz.float() + coef[1] * yraw.float() + coef[2], rd)
+    want_dw = R.stem_conv_wgrad(x, dy, 3, 2, pad, pad, rd)
+    got = K.stem_conv_wgrad(dev(x), dev(dz), dev(yraw), dev(coef), 3, 2, pad, pad)
+    close(got, want_dw, 5e-3 if rd == torch.bfloat16 else 2e-4, "stem wgrad")
+
+
+@pytest.mark.parametrize("J", [2, 10, 1000])
+def test_head_loss(J):
+    K = _k()
+    N, Kd = 6, 1280
+    g = torch.Generator().manual_seed(71)
+    x = torch.randn((N, Kd), generator=g)
+    w = (torch.randn((J, Kd), generator=g) * Kd ** -0.5).requires_grad_(True)
+    b = (torch.randn(J, generator=g) * 0.1).requires_grad_(True)
+    xr = x.clone().requires_grad_(True)
+    logits = xr @ w.t() + b
+    tg = torch.randint(0, J, (N,), generator=g)
+    loss = R.ce_label_smooth(logits, tg, 0.1)
+    loss.backward()
+    lg = K.linear_fwd(dev(x), dev(w.detach()), dev(b.detach()))
+    close(lg, logits, 1e-4, "linear fwd")
+    l2, dlog = K.ce_loss(lg, dev(tg), 0.1, 1.0, True)
+    close(l2.reshape(1), loss.detach().reshape(1), 1e-5, "ce loss")
+    dx, dw, db = K.linear_bwd(dlog, dev(x), dev(w.detach()), True, True, True)
+    close(dx, xr.grad, 2e-4, "linear dx")
+    close(dw, w.grad, 2e-4, "linear dw")
+    close(db, b.grad, 2e-4, "linear db")
+    probs, preds = K.softmax_argmax(lg, True)
+    want_p = torch.softmax(logits.detach(), 1)
+    close(probs, want_p, 1e-5, "softmax")
+    assert torch.equal(preds.cpu(), want_p.argmax(1))
+    u = torch.rand((N, Kd), generator=g)
+    close(K.dropout(dev(x), dev(u), 0.2), torch.where(u >= 0.2, x / 0.8, torch.zeros_like(x)), 1e-6, "dropout")
+
+
+def test_adamw_matches_torch():
+    K = _k()
+    g = torch.Generator().manual_seed(81)
+    shapes = [(1280, 10), (10,), (32, 3, 3, 3), (70001,)]
+    params = [torch.randn(s, generator=g) for s in shapes]
+    ref = [p.clone().requires_grad_(True) for p in params]
+    opt = torch.optim.AdamW(ref, lr=3e-3, weight_decay=5e-2)
+    dparams = [p.cuda() for p in params]
+    ms = [torch.zeros_like(p) for p in dparams]
+    vs = [torch.zeros_like(p) for p in dparams]
+    for step in range(1, 4):
+        grads = [torch.randn(s, generator=g) for s in shapes]
+        for r, gr in zip(ref, grads):
+            r.grad = gr.clone()
+        opt.step()
+        dgrads = [gr.cuda() for gr in grads]
+        rows = []
+        for p, gr, m, v in zip(dparams, dgrads, ms, vs):
+            for off in range(0, p.numel(), 65536):
+                cnt = min(65536, p.numel() - off)
+                rows.append([p.data_ptr() + 4 * off, gr.data_ptr() + 4 * off, m.data_ptr() + 4 * off, v.data_ptr() + 4 * off, cnt])
+        table = torch.tensor(rows, dtype=torch.int64).cuda()
+        hp = torch.tensor([3e-3, 0.9, 0.999, 1e-8, 5e-2, 1 - 0.9 ** step, 1 - 0.999 ** step, 1.0]).cuda()
+        K.adamw_step(table, hp)
+        torch.cuda.synchronize()
+    for p, r in zip(dparams, ref):
+        close(p, r.detach(), 1e-5, "adamw")
