@@ -151,13 +151,14 @@ def test_pwconv_fwd(case, mode, rd):
     st = rand_state(Kd, 14)
     gate = torch.rand((N, Kd), generator=torch.Generator().manual_seed(15))
     coef3 = rand_state(Kd, 16)[:3].contiguous()
+    dst = dev(st)  # the Prologue struct holds raw pointers: keep the tensors alive
     if mode == 0:
         pro, A = None, a.float()
     elif mode == 1:
-        pro, A = K.pro_bn_act(dev(st), R.ACT_SILU), R.prologue(a.float().view(N, HW, Kd), 1, rd, R.ACT_SILU, st)
+        pro, A = K.pro_bn_act(dst, R.ACT_SILU), R.prologue(a.float().view(N, HW, Kd), 1, rd, R.ACT_SILU, st)
     elif mode == 2:
         dgate = dev(gate)
-        pro = K.pro_bn_act_gate(dev(st), R.ACT_SILU, dgate, HW)
+        pro = K.pro_bn_act_gate(dst, R.ACT_SILU, dgate, HW)
         A = R.prologue(a.float().view(N, HW, Kd), 2, rd, R.ACT_SILU, st, gate=gate)
     else:
         da2, dcoef = dev(a2), dev(coef3)
