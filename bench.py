@@ -1,0 +1,228 @@
+"""Headline benchmark: EfficientNet-B0 train images/sec @224x224 on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = the reference's hot loop body (trainers/efficientnet.py:290-309) on one
+synthetic batch already resident in HBM: bf16-autocast forward, label-smoothed CE,
+backward, [gradient all-reduce,] AdamW — every kernel from libdfd_hip.so.  The step is
+captured into one hipGraph when capture succeeds (launch: "hipgraph"), otherwise it runs
+eagerly (launch: "eager").  Rank 0 prints ONE JSON line (see README/DESIGN for fields):
+  roofline      — dominant kernel family of the step, measured live with HIP events on the
+                  stream the kernels run on, against the HBM (or MFMA) peak of the guide;
+  cpu_baseline  — the CPU oracle (same op sequence through ATen/oneDNN CPU kernels, f32,
+                  channels_last) timed on this host's cores on a bounded sample.
+"""
+
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+if str(ROOT) not in sys.path:
+    sys.path.insert(0, str(ROOT))
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16
+
+
+def parse() -> argparse.Namespace:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=256, help="per-GPU batch (BASELINE config: 256)")
+    ap.add_argument("--size", type=int, default=224)
+    ap.add_argument("--classes", type=int, default=2)
+    ap.add_argument("--variant", default="b0")
+    ap.add_argument("--flavour", default="timm")
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=16)
+    ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--profile-steps", type=int, default=2)
+    return ap.parse_args()
+
+
+def cpu_baseline(args) -> dict:
+    """Oracle train step on the host cores; bounded sample, ~10-30 s."""
+    from oracle.effnet_ref import EfficientNetRef, train_step_ref
+
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    torch.manual_seed(0)
+    model = EfficientNetRef(args.variant, args.flavour, args.classes).to(memory_format=torch.channels_last)
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-4, weight_decay=5e-2)
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(args.cpu_batch, 3, args.size, args.size, generator=g).contiguous(memory_format=torch.channels_last)
+    y = torch.randint(0, args.classes, (args.cpu_batch,), generator=g)
+    train_step_ref(model, opt, x, y)        # warm-up
+    times = []
+    for _ in range(args.cpu_steps):
+        t0 = time.perf_counter()
+        train_step_ref(model, opt, x, y)
+        times.append(time.perf_counter() - t0)
+    med = sorted(times)[len(times) // 2]
+    return {"value": round(args.cpu_batch / med, 2), "unit": "images/sec", "cores": cores, "kind": "port",
+            "sample": f"oracle EfficientNet-{args.variant} f32 channels_last train step (fwd+CE+bwd+AdamW), "
+                      f"batch {args.cpu_batch} @{args.size}px, median of {args.cpu_steps} steps after 1 warm-up"}
+
+
+def main() -> None:
+    args = parse()
+    from deepfakedetection_amd import kernels as K
+    from deepfakedetection_amd.dp import GradAllReducer, broadcast_module_state, init_distributed
+    from deepfakedetection_amd.efficientnet import HipEfficientNet
+    from deepfakedetection_amd.optim import HipAdamW, HipCrossEntropyLoss
+
+    rank, local_rank, world = init_distributed()
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback)"
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+
+    torch.manual_seed(1)
+    model = HipEfficientNet(args.variant, args.flavour, args.classes).to(device).train()
+    broadcast_module_state(model)
+    opt = HipAdamW(model.parameters(), lr=1e-4, weight_decay=5e-2, grad_scale=1.0 / world)
+    reducer = GradAllReducer(model.parameters(), arena=opt.arena) if world > 1 else None
+    crit = HipCrossEntropyLoss(label_smoothing=0.1)
+    g = torch.Generator().manual_seed(1 + rank)
+    x = torch.randn(args.batch, 3, args.size, args.size, generator=g).to(device).contiguous(memory_format=torch.channels_last)
+    y = torch.randint(0, args.classes, (args.batch,), generator=g).to(device)
+    loss_box: list[torch.Tensor] = [torch.zeros((), device=device)]
+
+    def step_body() -> None:
+        opt.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            loss = crit(model(x), y)
+        loss.backward()
+        if reducer is not None:
+            reducer.reduce()
+        opt.step()
+        loss_box[0] = loss.detach()
+
+    # eager warm-up: sizes the scratch buffers, builds the optimizer state / tables
+    for _ in range(3):
+        step_body()
+    torch.cuda.synchronize()
+
+    launch = "eager"
+    graph = None
+    if not args.no_graph:
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(2):
+                    step_body()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            opt.prepare_step()
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                step_body()
+            launch = "hipgraph"
+        except Exception as exc:  # noqa: BLE001 - any capture failure means: measure eagerly
+            if rank == 0:
+                import traceback
+
+                traceback.print_exc()
+                print(f"[bench] hipGraph capture failed ({type(exc).__name__}); running eagerly", file=sys.stderr)
+            graph = None
+            torch.cuda.synchronize()
+
+    def run_step() -> None:
+        if graph is not None:
+            opt.prepare_step()
+            graph.replay()
+        else:
+            step_body()
+
+    for _ in range(args.warmup):
+        run_step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        run_step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    final_loss = float(loss_box[0])
+
+    # ---- live per-kernel measurement (eager, HIP events on the compute stream)
+    roofline, breakdown = None, []
+    if rank == 0:
+        sink: list = []
+        step_body()
+        torch.cuda.synchronize()
+        K.set_profile_sink(sink)
+        for _ in range(args.profile_steps):
+            step_body()
+        torch.cuda.synchronize()
+        K.set_profile_sink(None)
+        agg: dict[str, list[float]] = {}
+        for name, nbytes, flops, e0, e1 in sink:
+            a = agg.setdefault(name, [0.0, 0.0, 0.0, 0])
+            a[0] += e0.elapsed_time(e1) * 1e-3
+            a[1] += nbytes
+            a[2] += flops
+            a[3] += 1
+        total_t = sum(a[0] for a in agg.values())
+        for name, (t, b, f, n) in sorted(agg.items(), key=lambda kv: -kv[1][0]):
+            breakdown.append({"kernel": name, "launches_per_step": n // args.profile_steps,
+                              "ms_per_step": round(t / args.profile_steps * 1e3, 4),
+                              "share": round(t / total_t, 4), "GBps": round(b / t / 1e9, 1),
+                              "TFLOPs": round(f / t / 1e12, 2)})
+        # dominant family by time; every family in this step is HBM-bound by arithmetic
+        # intensity (all 1x1 layers < 312 flop/B), so bound = "hbm"
+        top = breakdown[0]
+        t, b, f, n = agg[top["kernel"]]
+        roofline = {"kernel": top["kernel"], "bound": "hbm", "achieved": round(b / t / 1e9, 1), "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": round(b / t / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
+                    "avg_launch_us": round(t / n * 1e6, 2), "avg_launch_bytes": int(b / n),
+                    "share_of_step": top["share"], "mfma_tflops": round(f / t / 1e12, 2),
+                    "mfma_frac": round(f / t / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4)}
+
+    if rank == 0:
+        ms = elapsed / args.steps * 1e3
+        value = args.batch * world * args.steps / elapsed
+        line = {
+            "metric": "train images/sec @224^2 (EfficientNet-B0)", "value": round(value, 1), "unit": "images/sec",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"EfficientNet-{args.variant} ({args.flavour} flavour) {args.size}x{args.size} train step: "
+                                   f"bf16 fwd + label-smoothed CE + bwd + AdamW, random-init weights, {args.classes} classes",
+                       "per_gpu_batch": args.batch, "global_batch": args.batch * world, "parallelism": f"dp{world}",
+                       "launch": launch, "final_loss": round(final_loss, 4)},
+            "roofline": roofline,
+            "kernels": breakdown,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,156 @@
+"""Single-node data parallelism for the hot loop: one process per GPU, RCCL over xGMI.
+
+The reference has no multi-GPU path at all (no torch.distributed call site, SURVEY.md
+section 2a); BASELINE.json asks for ImageFolder minibatches sharded across the 8 GPUs
+of one node with gradient all-reduce.  Design for MI355X:
+
+  * samples are independent (no SyncBN in the reference, per-replica BN statistics), so
+    the ONLY exchange per optimizer step is a sum-all-reduce of the gradients:
+    EfficientNet-B0 (2 classes) = 4,010,110 f32 = 16 MB.
+  * xGMI is a point-to-point mesh (7 links/GPU), so few large messages beat many small
+    ones: gradients are packed into a handful of flat buckets (default 8 MiB) and each
+    bucket is one collective.  The mean is folded into AdamW's grad_scale (1/world), so
+    no extra division pass runs.
+  * after the all-reduce each parameter's .grad is re-pointed at its slice of the flat
+    bucket (views, no copy back).
+  * initial parameters and buffers are broadcast from rank 0; BN running statistics stay
+    per-replica during training (rank 0's are what a checkpoint records).
+
+Backends: "nccl" (= RCCL on ROCm) on GPUs, "gloo" in the CPU tests.
+"""
+
+from __future__ import annotations
+
+import math
+import os
+from collections.abc import Iterable, Iterator
+
+import torch
+import torch.distributed as dist
+
+
+def env_rank() -> tuple[int, int, int]:
+    """(rank, local_rank, world_size) from the torchrun environment; (0, 0, 1) when absent."""
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+
+
+def init_distributed(backend: str | None = None) -> tuple[int, int, int]:
+    rank, local_rank, world = env_rank()
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        kwargs = {}
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            kwargs["device_id"] = torch.device("cuda", local_rank)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kwargs)
+    return rank, local_rank, world
+
+
+def broadcast_module_state(module: torch.nn.Module, src: int = 0) -> None:
+    """Make every replica start from rank `src`'s parameters and buffers."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return
+    with torch.no_grad():
+        for t in list(module.parameters()) + list(module.buffers()):
+            dist.broadcast(t, src=src)
+
+
+class GradAllReducer:
+    """Bucketed gradient all-reduce (sum); pair with an optimizer whose grad_scale = 1/world."""
+
+    def __init__(self, params: Iterable[torch.nn.Parameter], bucket_bytes: int = 8 << 20, arena=None) -> None:
+        self.params = [p for p in params if p.requires_grad]
+        self.world = dist.get_world_size() if dist.is_initialized() else 1
+        self.arena = arena                      # a GradArena (arena.py): flat, copy-free path
+        self.bucket_elems = max(1, bucket_bytes // 4)
+        # reverse order: the last layers' gradients are ready first in backward
+        order = list(reversed(self.params))
+        self.buckets: list[list[torch.nn.Parameter]] = []
+        cur: list[torch.nn.Parameter] = []
+        size = 0
+        for p in order:
+            nbytes = p.numel() * 4
+            if cur and size + nbytes > bucket_bytes:
+                self.buckets.append(cur)
+                cur, size = [], 0
+            cur.append(p)
+            size += nbytes
+        if cur:
+            self.buckets.append(cur)
+
+    @property
+    def grad_scale(self) -> float:
+        return 1.0 / self.world
+
+    @torch.no_grad()
+    def reduce(self) -> None:
+        """Sum the gradients over ranks, in place of each parameter's .grad."""
+        if self.world == 1:
+            return
+        arena = self.arena
+        if arena is not None and arena.holds_all_grads():
+            # every gradient already sits in one flat buffer: reduce it in place, bucket by bucket
+            works = [dist.all_reduce(chunk, op=dist.ReduceOp.SUM, async_op=True)
+                     for chunk in arena.flat.split(self.bucket_elems)]
+            for w in works:
+                w.wait()
+            return
+        pending = []
+        for bucket in self.buckets:
+            live = [p for p in bucket if p.grad is not None]
+            if not live:
+                continue
+            flat = torch.cat([p.grad.reshape(-1).float() for p in live])
+            pending.append((dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True), flat, live))
+        for work, flat, live in pending:
+            work.wait()
+            at = 0
+            for p in live:
+                n = p.numel()
+                p.grad = flat[at:at + n].view_as(p)
+                at += n
+
+
+class ShardedSampler:
+    """Rank-strided shard of a seeded per-epoch permutation, padded so every rank sees the
+    same number of samples (the contract of torch's DistributedSampler)."""
+
+    def __init__(self, length: int, rank: int, world: int, shuffle: bool = True, seed: int = 0, drop_last: bool = False) -> None:
+        self.length, self.rank, self.world, self.shuffle, self.seed, self.drop_last = length, rank, world, shuffle, seed, drop_last
+        self.epoch = 0
+        self.per_rank = length // world if drop_last else math.ceil(length / world)
+
+    def set_epoch(self, epoch: int) -> None:
+        self.epoch = epoch
+
+    def __len__(self) -> int:
+        return self.per_rank
+
+    def __iter__(self) -> Iterator[int]:
+        if self.shuffle:
+            g = torch.Generator().manual_seed(self.seed + self.epoch)
+            order = torch.randperm(self.length, generator=g).tolist()
+        else:
+            order = list(range(self.length))
+        total = self.per_rank * self.world
+        if self.drop_last:
+            order = order[:total]
+        elif len(order) < total:
+            order += order[: total - len(order)]
+        return iter(order[self.rank:total:self.world])
+
+
+def all_reduce_counts(*values: float, device: torch.device | str = "cpu") -> list[float]:
+    """Sum scalars (correct / total / loss sums of `evaluate`) over ranks."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return [float(v) for v in values]
+    t = torch.tensor(values, dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t.tolist()
+
+
+__all__ = ["GradAllReducer", "ShardedSampler", "all_reduce_counts", "broadcast_module_state", "env_rank", "init_distributed"]

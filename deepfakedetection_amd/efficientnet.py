@@ -1,0 +1,228 @@
+"""HIP-backed EfficientNet modules: drop-in for the nn.Modules the reference builds.
+
+`HipEfficientNet(variant, flavour, num_classes)` exposes the same surface the reference
+touches on its third-party models:
+  * `forward(float[N,3,H,W]) -> float[N,num_classes]` raw logits, any memory format;
+  * `.to()`, `.train()/.eval()`, `.named_parameters()` with the third-party names
+    (`_fc` / `classifier` substrings drive the trainers' freeze masks,
+    trainers/efficientnet.py:433-437), `.state_dict()/.load_state_dict()` with the
+    third-party KEYS so released weights load (orchestrator.py:370-375);
+  * lukemelas flavour: attributes `_fc`, `_fc.in_features`, `_conv_head`
+    (trainers/efficientnet.py:406-407, web_ui.py:111); `.modules()` yields nn.Conv2d.
+The sub-modules are real nn.Conv2d / nn.BatchNorm2d / nn.Linear objects used as
+parameter containers; the arithmetic runs in the fused functions of functions.py on the
+kernels of libdfd_hip.so.  There is no ATen fallback: a CPU input raises.
+
+Compute dtype: bf16 activations when called under torch autocast (the reference's
+AMP region, trainers/efficientnet.py:296), f32 otherwise (evaluate / inference run
+without autocast: trainers/efficientnet.py:249-254, orchestrator.py:587-590).
+"""
+
+from __future__ import annotations
+
+import math
+import warnings
+
+import torch
+from torch import nn
+
+from .arch import BlockPlan, NetPlan, efficientnet_plan
+from .functions import BNRef, HeadCtx, HeadFunction, MBConvCtx, MBConvFunction, StemCtx, StemFunction
+
+_LM_NAMES = dict(expand="_expand_conv", expand_bn="_bn0", dw="_depthwise_conv", dw_bn="_bn1",
+                 se_reduce="_se_reduce", se_expand="_se_expand", project="_project_conv", project_bn="_bn2")
+_TIMM_IR_NAMES = dict(expand="conv_pw", expand_bn="bn1", dw="conv_dw", dw_bn="bn2",
+                      se_reduce="se.conv_reduce", se_expand="se.conv_expand", project="conv_pwl", project_bn="bn3")
+_TIMM_DS_NAMES = dict(dw="conv_dw", dw_bn="bn1", se_reduce="se.conv_reduce", se_expand="se.conv_expand",
+                      project="conv_pw", project_bn="bn2")
+
+
+def _bnref(bn: nn.BatchNorm2d) -> BNRef:
+    return BNRef(bn.running_mean, bn.running_var, bn.num_batches_tracked, bn.momentum, bn.eps)
+
+
+def compute_dtype(device_type: str = "cuda") -> torch.dtype:
+    """bf16 inside an autocast region, f32 outside."""
+    try:
+        enabled = torch.is_autocast_enabled(device_type)
+    except TypeError:  # older signature
+        enabled = torch.is_autocast_enabled()
+    if not enabled:
+        return torch.float32
+    amp = torch.get_autocast_dtype(device_type) if hasattr(torch, "get_autocast_dtype") else torch.get_autocast_gpu_dtype()
+    if amp != torch.bfloat16:
+        warnings.warn("dfd HIP engine computes autocast regions in bf16 (fp16 autocast requested)", stacklevel=3)
+    return torch.bfloat16
+
+
+class _SEParams(nn.Module):
+    """Parameter holder named like timm's SqueezeExcite (se.conv_reduce / se.conv_expand)."""
+
+    def __init__(self, channels: int, reduced: int) -> None:
+        super().__init__()
+        self.conv_reduce = nn.Conv2d(channels, reduced, 1, bias=True)
+        self.conv_expand = nn.Conv2d(reduced, channels, 1, bias=True)
+
+
+class HipMBConv(nn.Module):
+    """One MBConv / depthwise-separable block; parameters named per flavour."""
+
+    def __init__(self, plan: BlockPlan, net: NetPlan) -> None:
+        super().__init__()
+        self.plan = plan
+        lm = net.flavour == "lukemelas"
+        self._names = _LM_NAMES if lm else (_TIMM_IR_NAMES if plan.expand else _TIMM_DS_NAMES)
+        names = self._names
+
+        def bn(c: int) -> nn.BatchNorm2d:
+            return nn.BatchNorm2d(c, eps=net.bn_eps, momentum=net.bn_momentum)
+
+        if plan.expand:
+            setattr(self, names["expand"], nn.Conv2d(plan.cin, plan.cmid, 1, bias=False))
+            setattr(self, names["expand_bn"], bn(plan.cmid))
+        setattr(self, names["dw"], nn.Conv2d(plan.cmid, plan.cmid, plan.dw.kernel, stride=plan.dw.stride,
+                                              groups=plan.cmid, bias=False))
+        setattr(self, names["dw_bn"], bn(plan.cmid))
+        if lm:
+            self._se_reduce = nn.Conv2d(plan.cmid, plan.se_width, 1, bias=True)
+            self._se_expand = nn.Conv2d(plan.se_width, plan.cmid, 1, bias=True)
+        else:
+            self.se = _SEParams(plan.cmid, plan.se_width)
+        setattr(self, names["project"], nn.Conv2d(plan.cmid, plan.cout, 1, bias=False))
+        setattr(self, names["project_bn"], bn(plan.cout))
+
+    def part(self, role: str) -> nn.Module:
+        mod: nn.Module = self
+        for piece in self._names[role].split("."):
+            mod = getattr(mod, piece)
+        return mod
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:  # x: NHWC
+        p = self.plan
+        row_scale = None
+        if self.training and p.skip and p.drop_connect > 0:
+            keep = 1.0 - p.drop_connect
+            row_scale = torch.floor(keep + torch.rand(x.shape[0], device=x.device, dtype=torch.float32)) / keep
+        return self.run(x, row_scale)
+
+    def run(self, x: torch.Tensor, row_scale: torch.Tensor | None) -> torch.Tensor:
+        p = self.plan
+        dw, dw_bn = self.part("dw"), self.part("dw_bn")
+        ser, see = self.part("se_reduce"), self.part("se_expand")
+        proj, proj_bn = self.part("project"), self.part("project_bn")
+        if p.expand:
+            exp, exp_bn = self.part("expand"), self.part("expand_bn")
+            w_exp, g_exp, b_exp, ref_exp = exp.weight, exp_bn.weight, exp_bn.bias, _bnref(exp_bn)
+        else:
+            w_exp = g_exp = b_exp = ref_exp = None
+        cfg = MBConvCtx(p.expand, p.dw, p.skip, ref_exp, _bnref(dw_bn), _bnref(proj_bn), self.training)
+        return MBConvFunction.apply(x, w_exp, g_exp, b_exp, dw.weight, dw_bn.weight, dw_bn.bias, ser.weight, ser.bias,
+                                    see.weight, see.bias, proj.weight, proj_bn.weight, proj_bn.bias, row_scale, cfg)
+
+
+class HipEfficientNet(nn.Module):
+    """EfficientNet-{b0..b4} whose forward/backward run on the MI355X kernels."""
+
+    def __init__(self, variant: str = "b0", flavour: str = "timm", num_classes: int = 1000,
+                 drop_rate: float | None = None) -> None:
+        super().__init__()
+        plan = efficientnet_plan(variant, flavour)
+        self.plan = plan
+        self.flavour = flavour
+        self.drop_rate = plan.dropout if drop_rate is None else drop_rate
+        last = plan.blocks[-1].cout
+
+        def bn(c: int) -> nn.BatchNorm2d:
+            return nn.BatchNorm2d(c, eps=plan.bn_eps, momentum=plan.bn_momentum)
+
+        stem = nn.Conv2d(3, plan.stem_out, 3, stride=2, bias=False)
+        head = nn.Conv2d(last, plan.head_out, 1, bias=False)
+        blocks = [HipMBConv(b, plan) for b in plan.blocks]
+        if flavour == "lukemelas":
+            self._conv_stem, self._bn0 = stem, bn(plan.stem_out)
+            self._blocks = nn.ModuleList(blocks)
+            self._conv_head, self._bn1 = head, bn(plan.head_out)
+            self._avg_pooling = nn.AdaptiveAvgPool2d(1)
+            self._dropout = nn.Dropout(self.drop_rate)
+            self._fc = nn.Linear(plan.head_out, num_classes)
+        else:
+            self.conv_stem, self.bn1 = stem, bn(plan.stem_out)
+            stages, at = [], 0
+            for count in plan.stage_sizes:
+                stages.append(nn.Sequential(*blocks[at:at + count]))
+                at += count
+            self.blocks = nn.Sequential(*stages)
+            self.conv_head, self.bn2 = head, bn(plan.head_out)
+            self.global_pool = nn.AdaptiveAvgPool2d(1)
+            self.classifier = nn.Linear(plan.head_out, num_classes)
+            self._init_timm()
+        self.num_features = plan.head_out
+
+    # -- timm's efficientnet_init_weights: fan-out normal convs, unit BN, uniform classifier
+    def _init_timm(self) -> None:
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                fan_out = m.kernel_size[0] * m.kernel_size[1] * m.out_channels // m.groups
+                nn.init.normal_(m.weight, 0.0, math.sqrt(2.0 / fan_out))
+                if m.bias is not None:
+                    nn.init.zeros_(m.bias)
+            elif isinstance(m, nn.BatchNorm2d):
+                nn.init.ones_(m.weight)
+                nn.init.zeros_(m.bias)
+            elif isinstance(m, nn.Linear):
+                bound = 1.0 / math.sqrt(m.weight.shape[0])
+                nn.init.uniform_(m.weight, -bound, bound)
+                nn.init.zeros_(m.bias)
+
+    # -- named parts, resolved at call time (the reference swaps `_fc` after construction)
+    def _parts(self):
+        if self.flavour == "lukemelas":
+            return self._conv_stem, self._bn0, list(self._blocks), self._conv_head, self._bn1, self._fc
+        flat = [b for stage in self.blocks for b in stage]
+        return self.conv_stem, self.bn1, flat, self.conv_head, self.bn2, self.classifier
+
+    def block_list(self) -> list[HipMBConv]:
+        return self._parts()[2]
+
+    def forward_features_nhwc(self, x: torch.Tensor, drop_masks=None) -> torch.Tensor:
+        stem, stem_bn, blocks, _, _, _ = self._parts()
+        if not x.is_cuda:
+            raise RuntimeError("HipEfficientNet runs on a HIP device only (no CPU fallback); move the input with .to('cuda')")
+        dt = compute_dtype()
+        xh = x.detach().float().contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1)
+        h = StemFunction.apply(xh, stem.weight, stem_bn.weight, stem_bn.bias,
+                               StemCtx(self.plan.stem, _bnref(stem_bn), dt, self.training))
+        for i, blk in enumerate(blocks):
+            h = blk(h) if drop_masks is None else blk.run(h, drop_masks[i])
+        return h
+
+    def forward(self, x: torch.Tensor, drop_masks=None, dropout_u: torch.Tensor | None = None) -> torch.Tensor:
+        """drop_masks / dropout_u let a test inject the stochastic-depth masks (already
+        1/keep scaled, one [N] tensor or None per block) and the dropout uniforms."""
+        _, _, _, head, head_bn, fc = self._parts()
+        h = self.forward_features_nhwc(x, drop_masks)
+        u = dropout_u
+        if u is None and self.training and self.drop_rate > 0 and drop_masks is None:
+            u = torch.rand((h.shape[0], head.out_channels), device=h.device, dtype=torch.float32)
+        cfg = HeadCtx(_bnref(head_bn), self.drop_rate, self.training)
+        return HeadFunction.apply(h, head.weight, head_bn.weight, head_bn.bias, fc.weight, fc.bias, u, cfg)
+
+
+def build_efficientnet(name: str, num_classes: int) -> HipEfficientNet:
+    """'efficientnet_b3' / 'efficientnet-b3' -> lukemelas flavour (the reference's model);
+    'efficientnet_b0' and friends with suffix '.timm' or variant b0 -> timm flavour (BASELINE)."""
+    key = name.lower().replace("-", "_")
+    flavour = None
+    if key.endswith(".timm"):
+        key, flavour = key[:-5], "timm"
+    elif key.endswith(".lukemelas"):
+        key, flavour = key[:-10], "lukemelas"
+    if not key.startswith("efficientnet_b"):
+        raise KeyError(f"not an EfficientNet name: {name}")
+    variant = key[len("efficientnet_"):]
+    if flavour is None:
+        flavour = "timm" if variant == "b0" else "lukemelas"
+    return HipEfficientNet(variant, flavour, num_classes)
+
+
+__all__ = ["HipEfficientNet", "HipMBConv", "build_efficientnet", "compute_dtype"]

@@ -1,0 +1,303 @@
+"""Fused autograd functions of the HIP engine: stem, MBConv block, classifier head, loss.
+
+One torch.autograd.Function per network stage.  Inside a stage the tensors that an
+unfused framework would write to HBM after every BatchNorm / SiLU / SE multiply never
+exist: each conv kernel writes its RAW output plus per-channel partial sums, a tiny
+finalize kernel turns the sums into (scale, shift, mean, rstd), and the NEXT kernel
+applies normalisation + activation (+ SE gate) while it loads its operand.  Backward
+re-derives activations from the saved raw tensors the same way and uses the identity
+    d(conv out) = a[c]*dz + b[c]*y + c[c]
+for training-mode BatchNorm, so BN-backward is also folded into the consumers.
+
+Stage arithmetic mirrors efficientnet_pytorch 0.7.1 `MBConvBlock.forward` /
+timm 1.0.20 `InvertedResidual.forward` (reference call sites:
+trainers/efficientnet.py:297,302; orchestration/orchestrator.py:529,590).
+"""
+
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+import torch
+
+from . import kernels as K
+from ._lib import ACT_NONE, ACT_SILU
+from .arch import ConvGeom
+from .arena import grad_dest
+
+
+@dataclass
+class BNRef:
+    """A BatchNorm2d's buffers + hyper-parameters (its weight/bias travel as Function inputs)."""
+
+    running_mean: torch.Tensor
+    running_var: torch.Tensor
+    num_batches_tracked: torch.Tensor | None
+    momentum: float
+    eps: float
+
+    def params(self, weight: torch.Tensor, bias: torch.Tensor) -> K.BNParams:
+        return K.BNParams(weight, bias, self.running_mean, self.running_var, self.momentum, self.eps)
+
+
+def _bn_state(parts, nparts, count: int, bn: BNRef, weight, bias, training: bool) -> torch.Tensor:
+    if training:
+        if bn.num_batches_tracked is not None:
+            bn.num_batches_tracked.add_(1)
+        return K.bn_finalize(parts, nparts, count, bn.params(weight, bias))
+    return K.bn_eval_coeffs(bn.params(weight, bias))
+
+
+def _identity_state(C: int, device) -> torch.Tensor:
+    st = torch.zeros((4, C), dtype=torch.float32, device=device)
+    st[0].fill_(1.0)
+    st[3].fill_(1.0)
+    return st
+
+
+def _c(t: torch.Tensor) -> torch.Tensor:
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _ptrs(*tensors) -> tuple[int, ...]:
+    """Addresses of a Function's tensor inputs: keys into the gradient arena."""
+    return tuple(t.data_ptr() if isinstance(t, torch.Tensor) else 0 for t in tensors)
+
+
+def _dest(ctx, index: int, shape):
+    """Arena slot for input `index` if that input wants a gradient and owns a free slot."""
+    if not ctx.needs_input_grad[index] or not ctx.pptr[index]:
+        return None
+    return grad_dest(ctx.pptr[index], shape)
+
+
+# =========================================================================== stem
+@dataclass
+class StemCtx:
+    geom: ConvGeom
+    bn: BNRef
+    dtype: torch.dtype
+    training: bool
+
+
+class StemFunction(torch.autograd.Function):
+    """conv k3 s2 (3 -> C) + BN + SiLU.  x: [N,H,W,3] f32."""
+
+    @staticmethod
+    def forward(ctx, x, weight, gamma, beta, cfg: StemCtx):
+        g = cfg.geom
+        N, H, W, _ = x.shape
+        Ho, Wo = g.out_size(H), g.out_size(W)
+        y, parts, n = K.stem_conv_fwd(x, weight, cfg.dtype, g.stride, g.pad_lead, g.pad_lead, Ho, Wo, stats=cfg.training)
+        st = _bn_state(parts, n, N * Ho * Wo, cfg.bn, gamma, beta, cfg.training)
+        out = K.bn_act_apply(y, st, ACT_SILU)
+        ctx.cfg = cfg
+        ctx.pptr = _ptrs(x, weight, gamma, beta)
+        ctx.save_for_backward(x, y, st, gamma)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        cfg: StemCtx = ctx.cfg
+        x, y, st, gamma = ctx.saved_tensors
+        geom = cfg.geom
+        N, Ho, Wo, _ = y.shape
+        dz, parts, n = K.act_bn_bwd(_c(g), y, None, None, st, ACT_SILU)
+        want_bn = ctx.needs_input_grad[2] or ctx.needs_input_grad[3]
+        C = gamma.numel()
+        coef, dgamma, dbeta = K.bn_bwd_finalize(parts, n, N * Ho * Wo, gamma, st, cfg.training, want_bn,
+                                                _dest(ctx, 2, (C,)), _dest(ctx, 3, (C,)))
+        dw = None
+        if ctx.needs_input_grad[1]:
+            dw = K.stem_conv_wgrad(x, dz, y, coef, geom.kernel, geom.stride, geom.pad_lead, geom.pad_lead,
+                                   _dest(ctx, 1, (C, 3, geom.kernel, geom.kernel)))
+        return None, dw, dgamma, dbeta, None
+
+
+# =========================================================================== MBConv
+@dataclass
+class MBConvCtx:
+    expand: bool
+    dw: ConvGeom
+    skip: bool
+    bn_expand: BNRef | None
+    bn_dw: BNRef
+    bn_project: BNRef
+    training: bool
+
+
+class MBConvFunction(torch.autograd.Function):
+    """[1x1 expand + BN + SiLU] -> dw kxk + BN + SiLU -> SE -> 1x1 project + BN [-> *mask + x].
+
+    Tensor inputs (None where a block has no expand conv):
+      x, w_exp, g_exp, b_exp, w_dw, g_dw, b_dw, se_w1, se_b1, se_w2, se_b2, w_proj, g_proj, b_proj, row_scale
+    """
+
+    @staticmethod
+    def forward(ctx, x, w_exp, g_exp, b_exp, w_dw, g_dw, b_dw, se_w1, se_b1, se_w2, se_b2, w_proj, g_proj, b_proj,
+                row_scale, cfg: MBConvCtx):
+        tr = cfg.training
+        N, H, W, Cin = x.shape
+        dt = x.dtype
+        geom = cfg.dw
+        Ho, Wo = geom.out_size(H), geom.out_size(W)
+        need_bwd = any(ctx.needs_input_grad)   # grad mode is off inside forward(); this is the autograd view
+        if cfg.expand:
+            wexp_nk, wexp_kn = K.prep_weights(w_exp, dt, True, need_bwd)
+            y1, parts, n = K.pwconv(x, None, wexp_nk, None, stats=tr)
+            st1 = _bn_state(parts, n, N * H * W, cfg.bn_expand, g_exp, b_exp, tr)
+            y2, parts, n = K.dwconv_fwd(y1, st1, ACT_SILU, w_dw, geom.kernel, geom.stride, geom.pad_lead, geom.pad_lead,
+                                        Ho, Wo, stats=tr)
+        else:
+            wexp_kn, y1, st1 = None, None, None
+            y2, parts, n = K.dwconv_fwd(x, None, ACT_NONE, w_dw, geom.kernel, geom.stride, geom.pad_lead, geom.pad_lead,
+                                        Ho, Wo, stats=tr)
+        st2 = _bn_state(parts, n, N * Ho * Wo, cfg.bn_dw, g_dw, b_dw, tr)
+        pooled = K.pool_act(y2, st2, ACT_SILU)
+        w1, w2 = se_w1.reshape(se_w1.shape[0], -1), se_w2.reshape(se_w2.shape[0], -1)
+        hpre, gate = K.se_fc_fwd(pooled, w1, se_b1, w2, se_b2, ACT_SILU)
+        wproj_nk, wproj_kn = K.prep_weights(w_proj, dt, True, need_bwd)
+        pro = K.pro_bn_act_gate(st2, ACT_SILU, gate, Ho * Wo)
+        y3, parts, n = K.pwconv(y2, pro, wproj_nk, None, stats=tr)
+        st3 = _bn_state(parts, n, N * Ho * Wo, cfg.bn_project, g_proj, b_proj, tr)
+        out = K.bn_act_apply(y3, st3, ACT_NONE, x if cfg.skip else None, row_scale if cfg.skip else None)
+        ctx.cfg = cfg
+        ctx.pptr = _ptrs(x, w_exp, g_exp, b_exp, w_dw, g_dw, b_dw, se_w1, se_b1, se_w2, se_b2, w_proj, g_proj, b_proj)
+        ctx.in_shape = (N, H, W, Cin)
+        ctx.has_rs = cfg.skip and row_scale is not None
+        ctx.save_for_backward(x, y1, y2, y3, st1, st2, st3, pooled, hpre, gate, wexp_kn, wproj_kn, w_dw, w1, w2,
+                              g_exp, g_dw, g_proj, row_scale if ctx.has_rs else None)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        cfg: MBConvCtx = ctx.cfg
+        (x, y1, y2, y3, st1, st2, st3, pooled, hpre, gate, wexp_kn, wproj_kn, w_dw, w1, w2,
+         g_exp, g_dw, g_proj, row_scale) = ctx.saved_tensors
+        need = ctx.needs_input_grad
+        tr = cfg.training
+        geom = cfg.dw
+        N, H, W, Cin = ctx.in_shape
+        _, Ho, Wo, Cmid = y2.shape
+        g = _c(g)
+        gb = K.scale_rows(g, row_scale) if ctx.has_rs else g
+        # ---- project BN backward, folded into the two GEMMs that consume dy3
+        parts, n = K.bn_bwd_reduce(gb, y3, st3, None)
+        Cout, R = y3.shape[3], w1.shape[0]
+        coef3, dg_proj, db_proj = K.bn_bwd_finalize(parts, n, N * Ho * Wo, g_proj, st3, tr, need[12] or need[13],
+                                                    _dest(ctx, 12, (Cout,)), _dest(ctx, 13, (Cout,)))
+        pro_dy3 = K.pro_affine2(y3, coef3)
+        D, _, _ = K.pwconv(gb, pro_dy3, wproj_kn, None, stats=False)               # d(act*gate) [.., Cmid]
+        dw_proj = None
+        if need[11]:
+            pro_q = K.pro_bn_act_gate(st2, ACT_SILU, gate, Ho * Wo)
+            dw_proj = K.pwconv_wgrad(gb, pro_dy3, y2, pro_q, _dest(ctx, 11, (Cout, Cmid))).view(Cout, Cmid, 1, 1)
+        # ---- squeeze-excite backward
+        dgate = K.pool_bwd_reduce(D, y2, st2, ACT_SILU)
+        want_se = need[7] or need[8] or need[9] or need[10]
+        se_outs = (_dest(ctx, 7, (R, Cmid)), _dest(ctx, 8, (R,)), _dest(ctx, 9, (Cmid, R)), _dest(ctx, 10, (Cmid,)))
+        dpooled, dw1, db1, dw2, db2 = K.se_fc_bwd(dgate, gate, hpre, pooled, w1, w2, ACT_SILU, want_se, se_outs)
+        if dw1 is not None:
+            dw1, dw2 = dw1.view(dw1.shape[0], -1, 1, 1), dw2.view(dw2.shape[0], -1, 1, 1)
+        # ---- SiLU' and depthwise BN backward
+        dz2, parts, n = K.act_bn_bwd(D, y2, gate, dpooled, st2, ACT_SILU)
+        coef2, dg_dw, db_dw = K.bn_bwd_finalize(parts, n, N * Ho * Wo, g_dw, st2, tr, need[5] or need[6],
+                                                _dest(ctx, 5, (Cmid,)), _dest(ctx, 6, (Cmid,)))
+        kk = geom.kernel
+        dw_dw = dx = dw_exp = dg_exp = db_exp = None
+        if cfg.expand:
+            dz1, parts, n = K.dwconv_bwd_data(dz2, y2, coef2, w_dw, y1, st1, ACT_SILU, y1.shape, geom.kernel,
+                                              geom.stride, geom.pad_lead, geom.pad_lead)
+            coef1, dg_exp, db_exp = K.bn_bwd_finalize(parts, n, N * H * W, g_exp, st1, tr, need[2] or need[3],
+                                                      _dest(ctx, 2, (Cmid,)), _dest(ctx, 3, (Cmid,)))
+            if need[4]:
+                dw_dw = K.dwconv_bwd_weight(dz2, y2, coef2, y1, st1, ACT_SILU, geom.kernel, geom.stride,
+                                            geom.pad_lead, geom.pad_lead, _dest(ctx, 4, (Cmid, 1, kk, kk)))
+            pro_dy1 = K.pro_affine2(y1, coef1)
+            if need[0]:
+                dx, _, _ = K.pwconv(dz1, pro_dy1, wexp_kn, g if cfg.skip else None, stats=False)
+            if need[1]:
+                dw_exp = K.pwconv_wgrad(dz1, pro_dy1, x, None, _dest(ctx, 1, (Cmid, Cin))).view(Cmid, Cin, 1, 1)
+        else:
+            if need[4]:
+                dw_dw = K.dwconv_bwd_weight(dz2, y2, coef2, x, None, ACT_NONE, geom.kernel, geom.stride,
+                                            geom.pad_lead, geom.pad_lead, _dest(ctx, 4, (Cmid, 1, kk, kk)))
+            if need[0]:
+                dx, _, _ = K.dwconv_bwd_data(dz2, y2, coef2, w_dw, None, None, ACT_NONE, ctx.in_shape, geom.kernel,
+                                             geom.stride, geom.pad_lead, geom.pad_lead)
+                if cfg.skip:
+                    dx = K.bn_act_apply(dx, _identity_state(Cin, dx.device), ACT_NONE, g, None)
+        return (dx, dw_exp, dg_exp, db_exp, dw_dw, dg_dw, db_dw, dw1, db1, dw2, db2, dw_proj, dg_proj, db_proj,
+                None, None)
+
+
+# =========================================================================== head
+@dataclass
+class HeadCtx:
+    bn: BNRef
+    dropout: float
+    training: bool
+
+
+class HeadFunction(torch.autograd.Function):
+    """1x1 conv + BN + SiLU -> global average pool -> dropout -> Linear.  Returns f32 logits."""
+
+    @staticmethod
+    def forward(ctx, x, w_head, gamma, beta, w_fc, b_fc, drop_u, cfg: HeadCtx):
+        N, H, W, Cin = x.shape
+        need_bwd = any(ctx.needs_input_grad)
+        w_nk, w_kn = K.prep_weights(w_head, x.dtype, True, need_bwd)
+        y, parts, n = K.pwconv(x, None, w_nk, None, stats=cfg.training)
+        st = _bn_state(parts, n, N * H * W, cfg.bn, gamma, beta, cfg.training)
+        pooled = K.pool_act(y, st, ACT_SILU)
+        feat = K.dropout(pooled, drop_u, cfg.dropout) if drop_u is not None else pooled
+        logits = K.linear_fwd(feat, w_fc, b_fc)
+        ctx.cfg = cfg
+        ctx.pptr = _ptrs(x, w_head, gamma, beta, w_fc, b_fc)
+        ctx.has_bias = b_fc is not None
+        ctx.save_for_backward(x, y, st, feat, w_kn, w_fc, gamma, drop_u)
+        return logits
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        cfg: HeadCtx = ctx.cfg
+        x, y, st, feat, w_kn, w_fc, gamma, drop_u = ctx.saved_tensors
+        need = ctx.needs_input_grad
+        N, H, W, Cin = x.shape
+        Chead = y.shape[3]
+        backbone = need[0] or need[1] or need[2] or need[3]
+        J = w_fc.shape[0]
+        dfeat, dw_fc, db_fc = K.linear_bwd(_c(dlogits.float()), feat, w_fc, backbone, need[4], ctx.has_bias and need[5],
+                                           _dest(ctx, 4, (J, Chead)), _dest(ctx, 5, (J,)) if ctx.has_bias else None)
+        dx = dw_head = dgamma = dbeta = None
+        if backbone:
+            dpooled = K.dropout(dfeat, drop_u, cfg.dropout) if drop_u is not None else dfeat
+            dz, parts, n = K.act_bn_bwd(None, y, None, dpooled, st, ACT_SILU)
+            coef, dgamma, dbeta = K.bn_bwd_finalize(parts, n, N * H * W, gamma, st, cfg.training, need[2] or need[3],
+                                                    _dest(ctx, 2, (Chead,)), _dest(ctx, 3, (Chead,)))
+            pro = K.pro_affine2(y, coef)
+            if need[0]:
+                dx, _, _ = K.pwconv(dz, pro, w_kn, None, stats=False)
+            if need[1]:
+                dw_head = K.pwconv_wgrad(dz, pro, x, None, _dest(ctx, 1, (Chead, Cin))).view(Chead, Cin, 1, 1)
+        return dx, dw_head, dgamma, dbeta, dw_fc, db_fc, None, None
+
+
+# =========================================================================== loss
+class CrossEntropyFunction(torch.autograd.Function):
+    """Mean label-smoothed cross entropy of f32 logits (trainers/efficientnet.py:412)."""
+
+    @staticmethod
+    def forward(ctx, logits, targets, label_smoothing: float):
+        loss, dlogits = K.ce_loss(_c(logits), targets, label_smoothing, 1.0, ctx.needs_input_grad[0])
+        ctx.save_for_backward(dlogits)
+        return loss
+
+    @staticmethod
+    def backward(ctx, gloss):
+        (dlogits,) = ctx.saved_tensors
+        return dlogits * gloss, None, None
+
+
+__all__ = ["BNRef", "CrossEntropyFunction", "HeadCtx", "HeadFunction", "MBConvCtx", "MBConvFunction", "StemCtx",
+           "StemFunction"]

@@ -62,6 +62,15 @@ def scratch(device: torch.device, name: str, nbytes: int) -> torch.Tensor:
     return buf
 
 
+def _dst(out: torch.Tensor | None, shape, device) -> torch.Tensor:
+    """A caller-provided destination (gradient-arena slot) or a fresh f32 tensor."""
+    if out is None:
+        return torch.empty(shape, dtype=torch.float32, device=device)
+    if tuple(out.shape) != tuple(shape) or out.dtype != torch.float32 or not out.is_contiguous():
+        raise ValueError(f"bad gradient destination {tuple(out.shape)} for {tuple(shape)}")
+    return out
+
+
 def partials_buf(device: torch.device, C: int) -> torch.Tensor:
     return scratch(device, "partials", MAX_PARTIALS * 2 * C * 4)
 
@@ -98,11 +107,13 @@ def bn_eval_coeffs(bn: BNParams) -> torch.Tensor:
 
 
 def bn_bwd_finalize(partials: torch.Tensor, nparts: int, count: int, gamma: torch.Tensor, state: torch.Tensor,
-                    train: bool, want_param_grads: bool = True):
+                    train: bool, want_param_grads: bool = True, out_dgamma: torch.Tensor | None = None,
+                    out_dbeta: torch.Tensor | None = None):
+    """out_*: optional destinations (gradient-arena slots) written instead of fresh tensors."""
     C = gamma.numel()
     coef = torch.empty((3, C), dtype=torch.float32, device=gamma.device)
-    dgamma = torch.empty(C, dtype=torch.float32, device=gamma.device) if want_param_grads else None
-    dbeta = torch.empty(C, dtype=torch.float32, device=gamma.device) if want_param_grads else None
+    dgamma = _dst(out_dgamma, (C,), gamma.device) if want_param_grads else None
+    dbeta = _dst(out_dbeta, (C,), gamma.device) if want_param_grads else None
     check(_L().dfd_bn_bwd_finalize(_p(partials), nparts, C, float(count), _p(gamma), _p(state), int(train),
                                    _p(dgamma), _p(dbeta), 0, _p(coef), _stream()), "dfd_bn_bwd_finalize")
     return coef, dgamma, dbeta
@@ -176,17 +187,17 @@ def se_fc_fwd(pooled: torch.Tensor, w1, b1, w2, b2, act: int):
     return hpre, gate
 
 
-def se_fc_bwd(dgate, gate, hpre, pooled, w1, w2, act: int, want_param_grads: bool = True):
+def se_fc_bwd(dgate, gate, hpre, pooled, w1, w2, act: int, want_param_grads: bool = True, outs=(None, None, None, None)):
     N, C = pooled.shape
     R = w1.shape[0]
     dev = pooled.device
     dpooled = torch.empty((N, C), dtype=torch.float32, device=dev)
     ws = scratch(dev, "se_ws", (N * C + 2 * N * R) * 4)
     if want_param_grads:
-        dw1 = torch.empty((R, C), dtype=torch.float32, device=dev)
-        db1 = torch.empty(R, dtype=torch.float32, device=dev)
-        dw2 = torch.empty((C, R), dtype=torch.float32, device=dev)
-        db2 = torch.empty(C, dtype=torch.float32, device=dev)
+        dw1 = _dst(outs[0], (R, C), dev)
+        db1 = _dst(outs[1], (R,), dev)
+        dw2 = _dst(outs[2], (C, R), dev)
+        db2 = _dst(outs[3], (C,), dev)
     else:
         dw1 = db1 = dw2 = db2 = None
     check(_L().dfd_se_fc_bwd(_p(dgate), _p(gate), _p(hpre), _p(pooled), _p(w1), _p(w2), N, C, R, act, _p(dpooled),
@@ -231,13 +242,14 @@ def dwconv_bwd_data(dz: torch.Tensor, y: torch.Tensor | None, coef: torch.Tensor
 
 
 def dwconv_bwd_weight(dz: torch.Tensor, y: torch.Tensor | None, coef: torch.Tensor | None, xin: torch.Tensor,
-                      in_state: torch.Tensor | None, in_act: int, k: int, stride: int, pad_top: int, pad_left: int) -> torch.Tensor:
+                      in_state: torch.Tensor | None, in_act: int, k: int, stride: int, pad_top: int, pad_left: int,
+                      out: torch.Tensor | None = None) -> torch.Tensor:
     N, H, W, C = xin.shape
     Ho, Wo = dz.shape[1], dz.shape[2]
     shp = _dw_shape(xin.shape, Ho, Wo, k, stride, pad_top, pad_left)
     nbytes = _L().dfd_dwconv_bwd_weight_ws(ctypes.byref(shp))
     ws = scratch(dz.device, "wgrad_ws", nbytes)
-    dw = torch.empty((C, 1, k, k), dtype=torch.float32, device=dz.device)
+    dw = _dst(out, (C, 1, k, k), dz.device)
     check(_L().dfd_dwconv_bwd_weight(_dt(dz), _p(dz), _p(y), _p(coef), _p(xin), _p(in_state), in_act, _p(dw),
                                      ctypes.byref(shp), 0, _p(ws), ws.numel() * 4, _stream()), "dfd_dwconv_bwd_weight")
     return dw
@@ -245,7 +257,10 @@ def dwconv_bwd_weight(dz: torch.Tensor, y: torch.Tensor | None, coef: torch.Tens
 
 # ------------------------------------------------------------------ pointwise
 def _pro(mode: int = PRO_NONE, act: int = ACT_NONE, HW: int = 1, a2=None, coef=None, gate=None) -> Prologue:
-    return Prologue(mode, act, HW, 0, _p(a2), _p(coef), _p(gate))
+    pr = Prologue(mode, act, HW, 0, _p(a2), _p(coef), _p(gate))
+    pr._keep = (a2, coef, gate)       # the struct holds raw pointers: keep the tensors alive with it
+    pr._nbytes = sum(t.numel() * t.element_size() for t in pr._keep if t is not None)
+    return pr
 
 
 def pro_bn_act(state: torch.Tensor, act: int) -> Prologue:
@@ -285,13 +300,14 @@ def pwconv(a: torch.Tensor, pro: Prologue | None, w_nk: torch.Tensor, residual: 
     return out, parts, n.value
 
 
-def pwconv_wgrad(p: torch.Tensor, pro_p: Prologue | None, q: torch.Tensor, pro_q: Prologue | None) -> torch.Tensor:
+def pwconv_wgrad(p: torch.Tensor, pro_p: Prologue | None, q: torch.Tensor, pro_q: Prologue | None,
+                 out: torch.Tensor | None = None) -> torch.Tensor:
     """dw[Ni, Nj] = sum_m P(p)[m, i] * Q(q)[m, j]."""
     Ni, Nj = p.shape[-1], q.shape[-1]
     M = p.numel() // Ni
     nbytes = _L().dfd_pwconv_wgrad_ws(M, Ni, Nj)
     ws = scratch(p.device, "wgrad_ws", nbytes)
-    dw = torch.empty((Ni, Nj), dtype=torch.float32, device=p.device)
+    dw = _dst(None if out is None else out.view(Ni, Nj), (Ni, Nj), p.device)
     check(_L().dfd_pwconv_wgrad(_dt(p), _p(p), ctypes.byref(pro_p) if pro_p is not None else None, Ni, _p(q),
                                 ctypes.byref(pro_q) if pro_q is not None else None, Nj, M, _p(dw), 0, _p(ws),
                                 ws.numel() * 4, _stream()), "dfd_pwconv_wgrad", f"M={M} Ni={Ni} Nj={Nj}")
@@ -321,12 +337,12 @@ def stem_conv_fwd(x: torch.Tensor, w: torch.Tensor, out_dtype: torch.dtype, stri
 
 
 def stem_conv_wgrad(x: torch.Tensor, dz: torch.Tensor, y: torch.Tensor | None, coef: torch.Tensor | None, k: int,
-                    stride: int, pad_top: int, pad_left: int) -> torch.Tensor:
+                    stride: int, pad_top: int, pad_left: int, out: torch.Tensor | None = None) -> torch.Tensor:
     Cout, Ho, Wo = dz.shape[3], dz.shape[1], dz.shape[2]
     shp = _stem_shape(x.shape, Cout, Ho, Wo, k, stride, pad_top, pad_left)
     nbytes = _L().dfd_stem_conv_wgrad_ws(ctypes.byref(shp))
     ws = scratch(dz.device, "wgrad_ws", nbytes)
-    dw = torch.empty((Cout, 3, k, k), dtype=torch.float32, device=dz.device)
+    dw = _dst(out, (Cout, 3, k, k), dz.device)
     check(_L().dfd_stem_conv_wgrad(_dt(dz), _p(x), _p(dz), _p(y), _p(coef), _p(dw), ctypes.byref(shp), 0, _p(ws),
                                    ws.numel() * 4, _stream()), "dfd_stem_conv_wgrad")
     return dw
@@ -347,13 +363,14 @@ def linear_fwd(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor | None) -> torc
     return out
 
 
-def linear_bwd(dout: torch.Tensor, x: torch.Tensor, w: torch.Tensor, need_dx: bool, need_dw: bool, has_bias: bool):
+def linear_bwd(dout: torch.Tensor, x: torch.Tensor, w: torch.Tensor, need_dx: bool, need_dw: bool, has_bias: bool,
+               out_dw: torch.Tensor | None = None, out_db: torch.Tensor | None = None):
     N, K = x.shape
     J = w.shape[0]
     dev = x.device
     dx = torch.empty((N, K), dtype=torch.float32, device=dev) if need_dx else None
-    dw = torch.empty((J, K), dtype=torch.float32, device=dev) if need_dw else None
-    db = torch.empty(J, dtype=torch.float32, device=dev) if (need_dw and has_bias) else None
+    dw = _dst(out_dw, (J, K), dev) if need_dw else None
+    db = _dst(out_db, (J,), dev) if (need_dw and has_bias) else None
     check(_L().dfd_linear_bwd(_p(dout), _p(x), _p(w), _p(dx), _p(dw), _p(db), N, K, J, 0, _stream()), "dfd_linear_bwd")
     return dx, dw, db
 
@@ -381,5 +398,65 @@ def softmax_argmax(logits: torch.Tensor, want_probs: bool = True):
 def adamw_step(table: torch.Tensor, hp: torch.Tensor) -> None:
     check(_L().dfd_adamw_step(_p(table), table.shape[0], _p(hp), _stream()), "dfd_adamw_step")
 
+
+# ------------------------------------------------------------------ measurement hook
+# bench.py installs a list here; each front-end call then appends
+# (name, algorithmic_bytes, flops, start_event, end_event).  Algorithmic bytes = every
+# tensor the call must read or write once (activations, weights, coefficients), i.e.
+# the DESIGN.md per-kernel figure, not counter traffic.
+_profile_sink: list | None = None
+_TIMED = ("bn_act_apply", "bn_bwd_reduce", "act_bn_bwd", "pool_act", "pool_bwd_reduce", "scale_rows", "dwconv_fwd",
+          "dwconv_bwd_data", "dwconv_bwd_weight", "pwconv", "pwconv_wgrad", "stem_conv_fwd", "stem_conv_wgrad",
+          "se_fc_fwd", "se_fc_bwd", "linear_fwd", "linear_bwd", "ce_loss", "adamw_step", "prep_weights", "bn_finalize",
+          "bn_bwd_finalize", "dropout")
+
+
+def set_profile_sink(sink: list | None) -> None:
+    global _profile_sink
+    _profile_sink = sink
+
+
+def _tensor_bytes(obj) -> int:
+    if isinstance(obj, torch.Tensor):
+        if obj.dim() <= 1 and obj.numel() >= MAX_PARTIALS:      # scratch / partial slabs
+            return 0
+        return obj.numel() * obj.element_size()
+    if isinstance(obj, Prologue):
+        return getattr(obj, "_nbytes", 0)
+    if isinstance(obj, (tuple, list)):
+        return sum(_tensor_bytes(o) for o in obj)
+    return 0
+
+
+def _flops(name: str, args) -> float:
+    if name == "pwconv":
+        a, w = args[0], args[2]
+        return 2.0 * (a.numel() // a.shape[-1]) * a.shape[-1] * w.shape[0]
+    if name == "pwconv_wgrad":
+        p, q = args[0], args[2]
+        return 2.0 * (p.numel() // p.shape[-1]) * p.shape[-1] * q.shape[-1]
+    return 0.0
+
+
+def _timed(name: str, fn):
+    def inner(*args, **kwargs):
+        sink = _profile_sink
+        if sink is None:
+            return fn(*args, **kwargs)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = fn(*args, **kwargs)
+        e1.record()
+        sink.append((name, _tensor_bytes(args) + _tensor_bytes(list(kwargs.values())) + _tensor_bytes(out),
+                     _flops(name, args), e0, e1))
+        return out
+
+    inner.__name__ = name
+    inner.__doc__ = fn.__doc__
+    return inner
+
+
+for _name in _TIMED:
+    globals()[_name] = _timed(_name, globals()[_name])
 
 __all__ = [name for name in dir() if not name.startswith("_")]

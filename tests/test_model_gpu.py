@@ -1,0 +1,242 @@
+"""Network-level parity on the MI355X: HipEfficientNet against the CPU oracle.
+
+The bar (BASELINE.json north_star): logits within 1e-3 relative in f32 and bit-exact
+arg-max class indices on a seeded batch; gradients / optimizer step compared tensor by
+tensor; bf16 (autocast) compared against the f32 oracle with bf16-appropriate tolerance,
+written at each assert.  Weights travel through state_dict(), so the third-party key
+compatibility is exercised as well.
+"""
+
+from __future__ import annotations
+
+import pytest
+import torch
+
+from oracle.effnet_ref import EfficientNetRef
+
+pytestmark = pytest.mark.gpu
+
+
+def _hip():
+    from deepfakedetection_amd.efficientnet import HipEfficientNet
+    from deepfakedetection_amd.optim import HipAdamW, HipCrossEntropyLoss
+
+    return HipEfficientNet, HipAdamW, HipCrossEntropyLoss
+
+
+def rel_err(got: torch.Tensor, want: torch.Tensor) -> float:
+    got, want = got.detach().float().cpu(), want.detach().float().cpu()
+    return float((got - want).abs().max()) / max(float(want.abs().max()), 1e-12)
+
+
+def make_pair(variant, flavour, classes, seed=5):
+    HipEfficientNet, _, _ = _hip()
+    torch.manual_seed(seed)
+    ref = EfficientNetRef(variant, flavour, classes)
+    hip = HipEfficientNet(variant, flavour, classes)
+    missing = hip.load_state_dict(ref.state_dict(), strict=True)
+    assert not missing.missing_keys and not missing.unexpected_keys
+    return ref, hip.cuda()
+
+
+def warm_running_stats(ref, size, steps=3):
+    ref.train()
+    g = torch.Generator().manual_seed(99)
+    with torch.no_grad():
+        for _ in range(steps):
+            ref(torch.randn(8, 3, size, size, generator=g))
+
+
+@pytest.mark.parametrize("variant,flavour,size", [("b0", "timm", 224), ("b3", "lukemelas", 224), ("b3", "lukemelas", 160)])
+def test_eval_logits_f32(variant, flavour, size):
+    torch.manual_seed(1)
+    HipEfficientNet, _, _ = _hip()
+    ref = EfficientNetRef(variant, flavour, 2)
+    warm_running_stats(ref, size)
+    ref.eval()
+    hip = HipEfficientNet(variant, flavour, 2)
+    hip.load_state_dict(ref.state_dict())
+    hip = hip.cuda().eval()
+    x = torch.randn(8, 3, size, size, generator=torch.Generator().manual_seed(1))
+    with torch.no_grad():
+        want = ref(x)
+    with torch.inference_mode():
+        got_cl = hip(x.cuda().to(memory_format=torch.channels_last))     # training-style input
+        got_nchw = hip(x.cuda())                                          # inference-style input (orchestrator.py:588)
+    assert rel_err(got_cl, want) <= 1e-3, rel_err(got_cl, want)            # north_star: logits within 1e-3 rel f32
+    assert torch.equal(got_cl.cpu(), got_nchw.cpu())
+    assert torch.equal(got_cl.argmax(1).cpu(), want.argmax(1))            # bit-exact class indices
+
+
+@pytest.mark.parametrize("variant,flavour,size", [("b0", "timm", 96), ("b3", "lukemelas", 64)])
+def test_train_step_f32(variant, flavour, size):
+    _, HipAdamW, HipCrossEntropyLoss = _hip()
+    ref, hip = make_pair(variant, flavour, 2)
+    ref.train(); hip.train()
+    N = 8
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(N, 3, size, size, generator=g)
+    y = torch.randint(0, 2, (N,), generator=g)
+    blocks = ref.block_list()
+    masks = []
+    for i, b in enumerate(blocks):
+        c = b.c
+        if c.stride == 1 and c.cin == c.cout and c.drop_connect > 0:
+            keep = 1 - c.drop_connect
+            masks.append(torch.floor(keep + torch.rand(N, generator=g)) / keep)
+        else:
+            masks.append(None)
+    feat = ref._fc.in_features if flavour == "lukemelas" else ref.classifier.in_features
+    u = torch.rand((N, feat), generator=g)
+    p = ref.dropout
+    ref_logits = ref(x, [None if m is None else m.view(N, 1, 1, 1) for m in masks], (u >= p).float() / (1 - p))
+    ref_loss = torch.nn.functional.cross_entropy(ref_logits, y, label_smoothing=0.1)
+    ref_loss.backward()
+    crit = HipCrossEntropyLoss(0.1)
+    logits = hip(x.cuda().to(memory_format=torch.channels_last), [None if m is None else m.cuda() for m in masks], u.cuda())
+    loss = crit(logits, y.cuda())
+    loss.backward()
+    assert rel_err(logits, ref_logits) <= 1e-3
+    assert abs(float(loss) - float(ref_loss)) <= 1e-4 * max(1.0, abs(float(ref_loss)))
+    ref_params = dict(ref.named_parameters())
+    bad = []
+    # a BN bias that feeds (through a 1x1 conv) another training-mode BN has an exactly-zero
+    # gradient; both sides then hold rounding noise (~1e-8), so errors are floored at 1e-5 of
+    # the largest gradient in the network
+    floor = 1e-5 * max(float(p.grad.abs().max()) for p in ref.parameters())
+    for name, prm in hip.named_parameters():
+        assert prm.grad is not None, name
+        want = ref_params[name].grad
+        err = float((prm.grad.float().cpu() - want).abs().max())
+        if err > 5e-3 * float(want.abs().max()) + floor:
+            bad.append((name, err, float(want.abs().max())))
+    # f32 vs f32, different summation orders through ~80 layers of BN backward
+    assert not bad, (len(bad), bad[-12:])
+    ref_bufs = dict(ref.named_buffers())
+    for name, buf in hip.named_buffers():
+        if buf.dtype.is_floating_point:
+            # running means of exactly-zero-mean channels are rounding noise (~1e-10): absolute floor
+            err = float((buf.float().cpu() - ref_bufs[name]).abs().max())
+            assert err <= 1e-4 * float(ref_bufs[name].abs().max()) + 1e-6, (name, err)
+        else:
+            assert int(buf) == int(ref_bufs[name]), name
+    # optimizer step (trainers/efficientnet.py:487-491 hyper-parameters).  The first AdamW step
+    # is lr*g/(|g|+eps): it amplifies the relative error of near-zero gradients, so exactness
+    # of the update rule is tested on identical gradients in test_ops_gpu.py::test_adamw_matches_torch
+    # and here only where the gradient carries signal.
+    opt_ref = torch.optim.AdamW(ref.parameters(), lr=1e-4, weight_decay=5e-2)
+    opt_hip = HipAdamW(hip.parameters(), lr=1e-4, weight_decay=5e-2, use_arena=False)
+    before = {n: p.detach().clone().cpu() for n, p in hip.named_parameters()}
+    opt_ref.step(); opt_hip.step()
+    for name, prm in hip.named_parameters():
+        gref = ref_params[name].grad
+        mask = gref.abs() > 1e-3 * float(gref.abs().max()) + floor
+        got_upd = (prm.detach().cpu() - before[name])[mask]
+        want_upd = (ref_params[name].detach() - before[name])[mask]
+        if mask.any():
+            assert float((got_upd - want_upd).abs().max()) <= 2e-2 * 1e-4, name     # 2 % of lr
+    sd = opt_hip.state_dict()
+    assert set(sd["state"][0]) == {"step", "exp_avg", "exp_avg_sq"}
+
+
+def test_arena_gradients_are_adopted_in_place():
+    """Backward kernels write into the gradient arena and autograd adopts those views as
+    .grad (no copies): fixed addresses for the fused AdamW table and the DP all-reduce."""
+    _, HipAdamW, HipCrossEntropyLoss = _hip()
+    _, hip = make_pair("b0", "timm", 2)
+    hip.train()
+    opt = HipAdamW(hip.parameters(), lr=1e-4, weight_decay=5e-2)
+    x = torch.randn(4, 3, 64, 64, generator=torch.Generator().manual_seed(8)).cuda()
+    y = torch.zeros(4, dtype=torch.int64).cuda()
+    grads = []
+    for _ in range(2):
+        opt.zero_grad(set_to_none=True)
+        HipCrossEntropyLoss(0.1)(hip(x, [None] * len(hip.block_list()), None), y).backward()
+        assert opt.arena.holds_all_grads()
+        grads.append(opt.arena.flat.clone())
+        opt.step()
+    assert torch.isfinite(grads[0]).all() and float(grads[0].abs().max()) > 0
+    # gradient accumulation: a second backward without zero_grad must ADD, not overwrite
+    opt.zero_grad(set_to_none=True)
+    HipCrossEntropyLoss(0.1)(hip(x, [None] * len(hip.block_list()), None), y).backward()
+    once = opt.arena.flat.clone()
+    hip.eval()   # freeze BN statistics so both passes see the same function
+    hip.train()
+    HipCrossEntropyLoss(0.1)(hip(x, [None] * len(hip.block_list()), None), y).backward()
+    twice = opt.arena.flat
+    assert rel_err(twice, 2 * once) <= 1e-5
+
+
+def test_bf16_autocast_train_close_to_f32_oracle():
+    _, _, HipCrossEntropyLoss = _hip()
+    ref, hip = make_pair("b0", "timm", 2)
+    ref.train(); hip.train()
+    N, size = 16, 128
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(N, 3, size, size, generator=g)
+    y = torch.randint(0, 2, (N,), generator=g)
+    ref_logits = ref(x)
+    torch.nn.functional.cross_entropy(ref_logits, y, label_smoothing=0.1).backward()
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        logits = hip(x.cuda().to(memory_format=torch.channels_last), [None] * len(hip.block_list()), None)
+        loss = HipCrossEntropyLoss(0.1)(logits, y.cuda())
+    loss.backward()
+    assert logits.dtype == torch.float32
+    # bf16 activations (8 significant bits) through 80+ layers: logits within 8 % of their range
+    assert rel_err(logits, ref_logits) <= 8e-2, rel_err(logits, ref_logits)
+    ref_params = dict(ref.named_parameters())
+    # direction of the whole gradient, and of every tensor that carries real signal
+    # (exactly-zero BN-bias gradients hold only rounding noise: skipped by norm)
+    ga = torch.cat([p.grad.float().cpu().flatten() for _, p in hip.named_parameters()])
+    gb = torch.cat([ref_params[n].grad.flatten() for n, _ in hip.named_parameters()])
+    cos_all = float(torch.dot(ga, gb) / (ga.norm() * gb.norm()))
+    assert cos_all >= 0.98, cos_all
+    low = []
+    for name, prm in hip.named_parameters():
+        a, b = prm.grad.float().cpu().flatten(), ref_params[name].grad.flatten()
+        if b.norm() > 1e-4 * gb.norm():
+            c = float(torch.dot(a, b) / (a.norm() * b.norm() + 1e-30))
+            if c < 0.9:
+                low.append((name, round(c, 3)))
+    assert not low, low
+
+
+def test_head_only_warmup_matches_oracle():
+    """Warm-up phase of the reference: only `_fc` trains (trainers/efficientnet.py:433-437)."""
+    ref, hip = make_pair("b3", "lukemelas", 2)
+    ref.train(); hip.train()
+    for model in (ref, hip):
+        for name, prm in model.named_parameters():
+            prm.requires_grad = "_fc" in name
+    x = torch.randn(4, 3, 64, 64, generator=torch.Generator().manual_seed(4))
+    nb = len(hip.block_list())
+    ref(x, None, None).sum().backward()
+    hip(x.cuda(), [None] * nb, None).sum().backward()
+    assert hip._conv_head.weight.grad is None and hip._blocks[0]._depthwise_conv.weight.grad is None
+    assert rel_err(hip._fc.weight.grad, ref._fc.weight.grad) <= 1e-3
+    assert rel_err(hip._fc.bias.grad, ref._fc.bias.grad) <= 1e-3
+
+
+def test_cpu_input_raises():
+    HipEfficientNet, _, _ = _hip()
+    model = HipEfficientNet("b0", "timm", 2).cuda()
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        model(torch.randn(1, 3, 32, 32))
+
+
+def test_reproducible_bitwise():
+    """Reductions use fixed-order partial slabs, never float atomics: same inputs, same bits."""
+    _, _, HipCrossEntropyLoss = _hip()
+    _, hip = make_pair("b0", "timm", 2)
+    hip.train()
+    x = torch.randn(8, 3, 96, 96, generator=torch.Generator().manual_seed(6)).cuda()
+    y = torch.zeros(8, dtype=torch.int64).cuda()
+    outs = []
+    for _ in range(2):
+        hip.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            logits = hip(x, [None] * len(hip.block_list()), None)
+            HipCrossEntropyLoss(0.1)(logits, y).backward()
+        outs.append((logits.detach().clone(), hip.conv_stem.weight.grad.clone()))
+    assert torch.equal(outs[0][0], outs[1][0])
+    assert torch.equal(outs[0][1], outs[1][1])

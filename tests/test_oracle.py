@@ -1,0 +1,127 @@
+"""Pins the CPU oracle (oracle/effnet_ref.py) — runs without a GPU.
+
+The reference's own tests hold no numeric fixture for this path
+(tests/test_repo_smoke.py of the reference only byte-compiles the tree), and the
+packages that carry the arithmetic are not installable here, so the oracle is pinned by:
+  1. published parameter counts (known answers),
+  2. the third-party state-dict key sets (both naming schemes),
+  3. an independent implementation of the same published architecture that IS
+     installed: transformers.EfficientNetForImageClassification (TF-SAME lineage,
+     BN eps 1e-3) — logits must agree after copying the weights across,
+  4. committed golden logits (tests/golden/effnet_logits.json, written by
+     tests/golden/make_golden.py from this oracle) so later edits cannot drift silently.
+"""
+
+from __future__ import annotations
+
+import json
+from pathlib import Path
+
+import pytest
+import torch
+
+from oracle.effnet_ref import EfficientNetRef, build_cfg, round_filters
+
+GOLDEN = Path(__file__).parent / "golden"
+
+
+@pytest.mark.parametrize("variant,flavour,classes,want", [
+    ("b0", "timm", 1000, 5_288_548),
+    ("b0", "lukemelas", 1000, 5_288_548),
+    ("b0", "timm", 2, 4_010_110),
+    ("b0", "timm", 10, 4_020_358),
+    ("b3", "lukemelas", 1000, 12_233_232),
+])
+def test_parameter_count_known_answers(variant, flavour, classes, want):
+    model = EfficientNetRef(variant, flavour, classes)
+    assert sum(p.numel() for p in model.parameters()) == want
+
+
+def test_b3_structure_matches_published_digest():
+    stem, stem_pad, blocks, head, dropout = build_cfg("b3", "lukemelas")
+    assert (stem, head, dropout, len(blocks)) == (40, 1536, 0.3, 26)
+    outs = sorted({b.cout for b in blocks})
+    assert outs == [24, 32, 48, 96, 136, 232, 384]
+    reps = [sum(1 for b in blocks if b.stage == s) for s in range(7)]
+    assert reps == [2, 3, 3, 5, 5, 6, 2]
+    # static SAME padding from the nominal 300 px: 300->150 and 150->75 pad (0,1); the k5 s2
+    # layer at 75 px pads (2,2) — NOT what TF-SAME would give for a 224 px input
+    assert stem_pad == (0, 1)
+    s2 = [b for b in blocks if b.stride == 2]
+    assert [b.pad_dw[:2] for b in s2] == [(0, 1), (2, 2), (0, 1), (2, 2)]
+    assert round_filters(32, 1.2) == 40
+
+
+def test_se_widths_timm_b0():
+    _, _, blocks, _, _ = build_cfg("b0", "timm")
+    assert [b.se_ch for b in blocks] == [8, 4, 6, 6, 10, 10, 20, 20, 20, 28, 28, 28, 48, 48, 48, 48]
+
+
+def test_state_dict_keys_follow_third_party_names():
+    lm = set(EfficientNetRef("b3", "lukemelas", 2).state_dict())
+    for key in ("_conv_stem.weight", "_bn0.running_mean", "_blocks.0._depthwise_conv.weight", "_blocks.0._se_reduce.bias",
+                "_blocks.2._expand_conv.weight", "_blocks.25._project_conv.weight", "_blocks.25._bn2.num_batches_tracked",
+                "_conv_head.weight", "_bn1.weight", "_fc.weight", "_fc.bias"):
+        assert key in lm, key
+    assert "_blocks.0._expand_conv.weight" not in lm          # expand_ratio 1 has no expand conv
+    tm = set(EfficientNetRef("b0", "timm", 2).state_dict())
+    for key in ("conv_stem.weight", "bn1.weight", "blocks.0.0.conv_dw.weight", "blocks.0.0.se.conv_reduce.bias",
+                "blocks.0.0.conv_pw.weight", "blocks.1.0.conv_pw.weight", "blocks.1.0.conv_pwl.weight", "blocks.1.0.bn3.bias",
+                "blocks.6.0.se.conv_expand.weight", "conv_head.weight", "bn2.running_var", "classifier.bias"):
+        assert key in tm, key
+
+
+def test_logits_match_independent_hf_implementation():
+    """Topology, padding, SE width and BN-eps cross-check on an installed, independent
+    implementation of the same architecture (not the reference's dependency)."""
+    transformers = pytest.importorskip("transformers")
+    cfg = transformers.EfficientNetConfig(width_coefficient=1.0, depth_coefficient=1.0, image_size=224, hidden_dim=1280,
+                                          dropout_rate=0.2, num_labels=10)
+    hf = transformers.EfficientNetForImageClassification(cfg).eval()
+    torch.manual_seed(7)
+    ours = EfficientNetRef("b0", "lukemelas", 10).eval()
+    # non-trivial BN statistics so eps / running stats matter
+    with torch.no_grad():
+        for m in ours.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.running_mean.normal_(0, 0.1)
+                m.running_var.uniform_(0.5, 1.5)
+                m.weight.uniform_(0.5, 1.5)
+                m.bias.normal_(0, 0.1)
+    src, dst = ours.state_dict(), hf.state_dict()
+    assert len(src) == len(dst)
+    mapped = {}
+    for (ks, vs), (kd, vd) in zip(src.items(), dst.items()):
+        assert vs.shape == vd.shape, (ks, kd, vs.shape, vd.shape)
+        mapped[kd] = vs
+    hf.load_state_dict(mapped)
+    x = torch.randn(2, 3, 224, 224, generator=torch.Generator().manual_seed(1))
+    with torch.no_grad():
+        a, b = ours(x), hf(pixel_values=x).logits
+    assert torch.allclose(a, b, rtol=1e-4, atol=1e-5), float((a - b).abs().max())
+
+
+def test_golden_logits_fixture():
+    path = GOLDEN / "effnet_logits.json"
+    data = json.loads(path.read_text())
+    for case in data["cases"]:
+        torch.manual_seed(case["seed"])
+        model = EfficientNetRef(case["variant"], case["flavour"], case["classes"]).eval()
+        g = torch.Generator().manual_seed(case["input_seed"])
+        x = torch.randn(case["batch"], 3, case["size"], case["size"], generator=g)
+        with torch.no_grad():
+            got = model(x)
+        want = torch.tensor(case["logits"])
+        assert torch.allclose(got, want, rtol=1e-4, atol=1e-5), (case["variant"], case["flavour"])
+
+
+def test_train_mode_updates_running_stats_and_grads_flow():
+    torch.manual_seed(3)
+    model = EfficientNetRef("b0", "timm", 2).train()
+    x = torch.randn(4, 3, 64, 64)
+    before = model.bn1.running_mean.clone()
+    out = model(x)
+    out.sum().backward()
+    assert not torch.equal(before, model.bn1.running_mean)
+    assert int(model.bn1.num_batches_tracked) == 1
+    assert all(p.grad is not None for p in model.parameters())
