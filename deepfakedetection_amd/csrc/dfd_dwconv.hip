@@ -107,7 +107,7 @@ __device__ __forceinline__ void stage_weights(float* __restrict__ wl, const floa
 // forward
 // ---------------------------------------------------------------------------
 template <typename T, int K, int S, int ACT, bool PRO, bool STATS>
-__global__ void __launch_bounds__(DFD_THREADS)
+__global__ void __launch_bounds__(DFD_THREADS, 4)
 k_dw_fwd(const T* __restrict__ x, const float* __restrict__ bnstate, const float* __restrict__ w, T* __restrict__ y,
          DwGeom g, float* __restrict__ partials, int tile_bytes) {
     constexpr int V = Vec<T>::N;
@@ -153,7 +153,7 @@ k_dw_fwd(const T* __restrict__ x, const float* __restrict__ bnstate, const float
         for (int i = 0; i < DW_NP; ++i)
 #pragma unroll
             for (int j = 0; j < V; ++j) acc[i][j] = 0.f;
-#pragma unroll
+#pragma unroll 1
         for (int kh = 0; kh < K; ++kh) {
 #pragma unroll
             for (int kw = 0; kw < K; ++kw) {
@@ -207,7 +207,7 @@ k_dw_fwd(const T* __restrict__ x, const float* __restrict__ bnstate, const float
 // dy region that can reach them.  g.IH/IW = staged dy extent, CH/CW = H/W.
 // ---------------------------------------------------------------------------
 template <typename T, int K, int S, int ACT, bool COEF, bool EPI>
-__global__ void __launch_bounds__(DFD_THREADS)
+__global__ void __launch_bounds__(DFD_THREADS, 4)
 k_dw_bwd_data(const T* __restrict__ dz, const T* __restrict__ yraw, const float* __restrict__ coef,
               const float* __restrict__ w, const T* __restrict__ xin, const float* __restrict__ in_bnstate,
               T* __restrict__ dzin, DwGeom g, float* __restrict__ partials, int tile_bytes) {
@@ -258,7 +258,7 @@ k_dw_bwd_data(const T* __restrict__ dz, const T* __restrict__ yraw, const float*
         stage_tile<T, DFD_ACT_NONE, COEF ? 2 : 0>(tile, dz, yraw, ka, kb, kc, (long)n * g.Ho * g.Wo * g.C, g.Ho, g.Wo, g.C,
                                                   c0, cvalid, sy0, sx0, g.IH, g.IW, g.iw_magic, g.cvb_log2);
         __syncthreads();
-#pragma unroll
+#pragma unroll 1
         for (int i = 0; i < DW_NP; ++i) {
             const int h = h0 + hyl[i], wq = w0 + hxl[i];
             if (!(cvalid && hyl[i] < g.TH && h < g.H && wq < g.W)) continue;

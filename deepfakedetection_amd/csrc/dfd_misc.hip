@@ -88,52 +88,49 @@ k_se_fc_bwd_a(const float* __restrict__ dgate, const float* __restrict__ gate, c
     }
 }
 
-// weight gradients: thread (c, rl) owns r = rl, rl+4, ... ; sums over images in order
-#define SE_RPT 32
+// weight gradients: grid (C/64, R); thread (c, nl) sums every 4th image, the four image
+// lanes are combined through LDS in a fixed order.
 __global__ void __launch_bounds__(DFD_THREADS)
 k_se_fc_bwd_w(const float* __restrict__ pooled, const float* __restrict__ ws, int N, int C, int R,
               float* __restrict__ dw1, float* __restrict__ db1, float* __restrict__ dw2, float* __restrict__ db2,
               int accumulate) {
+    __shared__ float red[3][4][64];
     const float* ws_g = ws;
     const float* ws_dh = ws + (long)N * C;
     const float* ws_h = ws_dh + (long)N * R;
-    const int t = threadIdx.x, cl = t & 63, rl = t >> 6;
-    const int c = blockIdx.x * 64 + cl;
-    float a1[SE_RPT], a2[SE_RPT];
-#pragma unroll
-    for (int i = 0; i < SE_RPT; ++i) { a1[i] = 0.f; a2[i] = 0.f; }
-    float sb2 = 0.f;
+    const int t = threadIdx.x, cl = t & 63, nl = t >> 6;
+    const int c = blockIdx.x * 64 + cl, r = blockIdx.y;
+    float a1 = 0.f, a2 = 0.f, sb2 = 0.f;
     if (c < C) {
-        for (int n = 0; n < N; ++n) {
+        for (int n = nl; n < N; n += 4) {
             const float g = ws_g[(long)n * C + c], pc = pooled[(long)n * C + c];
+            a2 = fmaf(g, ws_h[(long)n * R + r], a2);
+            a1 = fmaf(ws_dh[(long)n * R + r], pc, a1);
             sb2 += g;
-#pragma unroll
-            for (int i = 0; i < SE_RPT; ++i) {
-                const int r = rl + 4 * i;
-                if (r < R) {
-                    a2[i] = fmaf(g, ws_h[(long)n * R + r], a2[i]);
-                    a1[i] = fmaf(ws_dh[(long)n * R + r], pc, a1[i]);
-                }
-            }
         }
-#pragma unroll
-        for (int i = 0; i < SE_RPT; ++i) {
-            const int r = rl + 4 * i;
-            if (r < R) {
-                float* p2 = dw2 + (long)c * R + r;
-                float* p1 = dw1 + (long)r * C + c;
-                *p2 = (accumulate ? *p2 : 0.f) + a2[i];
-                *p1 = (accumulate ? *p1 : 0.f) + a1[i];
-            }
+    }
+    red[0][nl][cl] = a1; red[1][nl][cl] = a2; red[2][nl][cl] = sb2;
+    __syncthreads();
+    if (nl == 0 && c < C) {
+        a1 = red[0][0][cl] + red[0][1][cl] + red[0][2][cl] + red[0][3][cl];
+        a2 = red[1][0][cl] + red[1][1][cl] + red[1][2][cl] + red[1][3][cl];
+        float* p2 = dw2 + (long)c * R + r;
+        float* p1 = dw1 + (long)r * C + c;
+        *p2 = (accumulate ? *p2 : 0.f) + a2;
+        *p1 = (accumulate ? *p1 : 0.f) + a1;
+        if (r == 0 && db2) {
+            sb2 = red[2][0][cl] + red[2][1][cl] + red[2][2][cl] + red[2][3][cl];
+            db2[c] = (accumulate ? db2[c] : 0.f) + sb2;
         }
-        if (rl == 0 && db2) db2[c] = (accumulate ? db2[c] : 0.f) + sb2;
     }
     if (blockIdx.x == 0 && db1) {
-        for (int r = t; r < R; r += DFD_THREADS) {
-            float s = 0.f;
-            for (int n = 0; n < N; ++n) s += ws_dh[(long)n * R + r];
-            db1[r] = (accumulate ? db1[r] : 0.f) + s;
-        }
+        __syncthreads();
+        float s = 0.f;
+        for (int n = t; n < N; n += DFD_THREADS) s += ws_dh[(long)n * R + r];
+        s = wave_sum(s);
+        if ((t & 63) == 0) red[0][t >> 6][0] = s;
+        __syncthreads();
+        if (t == 0) db1[r] = (accumulate ? db1[r] : 0.f) + red[0][0][0] + red[0][1][0] + red[0][2][0] + red[0][3][0];
     }
 }
 
@@ -153,15 +150,15 @@ extern "C" int dfd_se_fc_bwd(const float* dgate, const float* gate, const float*
                              float* dw1, float* db1, float* dw2, float* db2, int accumulate, float* ws,
                              dfd_stream stream) {
     if (!dgate || !gate || !hpre || !pooled || !w1 || !w2 || !dpooled || !ws || N < 1 || C < 1 || R < 1) return DFD_EINVAL;
-    if (C > SE_MAX_C || R > SE_MAX_R || R > 4 * SE_RPT) return DFD_EUNSUPPORTED;
+    if (C > SE_MAX_C || R > SE_MAX_R) return DFD_EUNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     DISPATCH_ACT(act, {
         hipLaunchKernelGGL((k_se_fc_bwd_a<ACT>), dim3(N), dim3(DFD_THREADS), 0, st, dgate, gate, hpre, w1, w2, N, C, R, dpooled, ws);
     });
     if (hipGetLastError() != hipSuccess) return DFD_ELAUNCH;
     if (dw1 && dw2) {
-        hipLaunchKernelGGL(k_se_fc_bwd_w, dim3((C + 63) / 64), dim3(DFD_THREADS), 0, st, pooled, ws, N, C, R, dw1, db1, dw2,
-                           db2, accumulate);
+        hipLaunchKernelGGL(k_se_fc_bwd_w, dim3((C + 63) / 64, R), dim3(DFD_THREADS), 0, st, pooled, ws, N, C, R, dw1, db1,
+                           dw2, db2, accumulate);
     }
     return DFD_CHECK_LAUNCH();
 }

@@ -214,23 +214,38 @@ k_pool(const T* __restrict__ D, const T* __restrict__ y, const float* __restrict
 }
 
 // ------------------------------------------------------------------ finalize kernels
-// one thread per channel, partial rows summed in a fixed order, in double.
-__global__ void k_bn_finalize(const float* __restrict__ partials, int nparts, int C, double count,
-                              const float* __restrict__ gamma, const float* __restrict__ beta,
-                              float* __restrict__ rmean, float* __restrict__ rvar, float momentum, float eps,
-                              float* __restrict__ bnstate) {
-    // 4 lanes cooperate on one channel: lane q sums partial rows q, q+4, ...
-    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
-    const int c = gid >> 2, q = gid & 3;
-    double s = 0.0, ss = 0.0;
+// workgroup = 8 channels x 32 partial-row lanes; each lane sums every 32nd partial row in
+// f32, the 32 lane sums are combined in a fixed order in double.
+#define FIN_CH 8
+#define FIN_LANES 32
+__device__ __forceinline__ void fin_reduce(const float* __restrict__ partials, int nparts, int C, int c, int q,
+                                           double* sm, double& s0, double& s1) {
+    float a0 = 0.f, a1 = 0.f;
     if (c < C) {
-        for (int p = q; p < nparts; p += 4) {
-            s += (double)partials[(long)p * 2 * C + c];
-            ss += (double)partials[(long)p * 2 * C + C + c];
+        for (int p = q; p < nparts; p += FIN_LANES) {
+            a0 += partials[(long)p * 2 * C + c];
+            a1 += partials[(long)p * 2 * C + C + c];
         }
     }
-    s += __shfl_xor(s, 1); ss += __shfl_xor(ss, 1);
-    s += __shfl_xor(s, 2); ss += __shfl_xor(ss, 2);
+    const int cl = threadIdx.x & (FIN_CH - 1);
+    sm[(q * FIN_CH + cl) * 2] = (double)a0;
+    sm[(q * FIN_CH + cl) * 2 + 1] = (double)a1;
+    __syncthreads();
+    s0 = 0.0; s1 = 0.0;
+    if (q == 0) {
+        for (int i = 0; i < FIN_LANES; ++i) { s0 += sm[(i * FIN_CH + cl) * 2]; s1 += sm[(i * FIN_CH + cl) * 2 + 1]; }
+    }
+}
+
+__global__ void __launch_bounds__(FIN_CH * FIN_LANES)
+k_bn_finalize(const float* __restrict__ partials, int nparts, int C, double count,
+              const float* __restrict__ gamma, const float* __restrict__ beta,
+              float* __restrict__ rmean, float* __restrict__ rvar, float momentum, float eps,
+              float* __restrict__ bnstate) {
+    __shared__ double sm[FIN_CH * FIN_LANES * 2];
+    const int c = blockIdx.x * FIN_CH + (threadIdx.x & (FIN_CH - 1)), q = threadIdx.x / FIN_CH;
+    double s, ss;
+    fin_reduce(partials, nparts, C, c, q, sm, s, ss);
     if (c < C && q == 0) {
         const double mean = s / count;
         double var = ss / count - mean * mean;
@@ -264,21 +279,15 @@ __global__ void k_bn_eval_coeffs(const float* __restrict__ gamma, const float* _
     bnstate[3 * C + c] = rstd;
 }
 
-__global__ void k_bn_bwd_finalize(const float* __restrict__ partials, int nparts, int C, double count,
-                                  const float* __restrict__ gamma, const float* __restrict__ bnstate, int train,
-                                  float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate,
-                                  float* __restrict__ coef) {
-    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
-    const int c = gid >> 2, q = gid & 3;
-    double s1 = 0.0, s2 = 0.0;
-    if (c < C) {
-        for (int p = q; p < nparts; p += 4) {
-            s1 += (double)partials[(long)p * 2 * C + c];
-            s2 += (double)partials[(long)p * 2 * C + C + c];
-        }
-    }
-    s1 += __shfl_xor(s1, 1); s2 += __shfl_xor(s2, 1);
-    s1 += __shfl_xor(s1, 2); s2 += __shfl_xor(s2, 2);
+__global__ void __launch_bounds__(FIN_CH * FIN_LANES)
+k_bn_bwd_finalize(const float* __restrict__ partials, int nparts, int C, double count,
+                  const float* __restrict__ gamma, const float* __restrict__ bnstate, int train,
+                  float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate,
+                  float* __restrict__ coef) {
+    __shared__ double sm[FIN_CH * FIN_LANES * 2];
+    const int c = blockIdx.x * FIN_CH + (threadIdx.x & (FIN_CH - 1)), q = threadIdx.x / FIN_CH;
+    double s1, s2;
+    fin_reduce(partials, nparts, C, c, q, sm, s1, s2);
     if (c < C && q == 0) {
         if (dgamma) dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)s2;
         if (dbeta) dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)s1;
@@ -455,7 +464,7 @@ extern "C" int dfd_bn_finalize(const float* partials, int nparts, int C, double 
                                float* bnstate, dfd_stream stream) {
     if (!partials || nparts < 1 || C < 1 || count <= 0 || !bnstate) return DFD_EINVAL;
     if ((running_mean == nullptr) != (running_var == nullptr)) return DFD_EINVAL;
-    const int threads = 256, grid = (C * 4 + threads - 1) / threads;
+    const int threads = FIN_CH * FIN_LANES, grid = (C + FIN_CH - 1) / FIN_CH;
     hipLaunchKernelGGL(k_bn_finalize, dim3(grid), dim3(threads), 0, (hipStream_t)stream, partials, nparts, C, count, gamma,
                        beta, running_mean, running_var, momentum, eps, bnstate);
     return DFD_CHECK_LAUNCH();
@@ -472,7 +481,7 @@ extern "C" int dfd_bn_bwd_finalize(const float* partials, int nparts, int C, dou
                                    const float* bnstate, int train, float* dgamma, float* dbeta, int accumulate,
                                    float* coef, dfd_stream stream) {
     if (!partials || nparts < 1 || C < 1 || count <= 0 || !bnstate || !coef) return DFD_EINVAL;
-    const int threads = 256, grid = (C * 4 + threads - 1) / threads;
+    const int threads = FIN_CH * FIN_LANES, grid = (C + FIN_CH - 1) / FIN_CH;
     hipLaunchKernelGGL(k_bn_bwd_finalize, dim3(grid), dim3(threads), 0, (hipStream_t)stream, partials, nparts, C, count,
                        gamma, bnstate, train, dgamma, dbeta, accumulate, coef);
     return DFD_CHECK_LAUNCH();
