@@ -1,0 +1,268 @@
+"""ImageFolder dataset and the image transforms the reference's loaders use.
+
+The reference builds its pipelines from torchvision (trainers/efficientnet.py:111-234,
+orchestration/orchestrator.py:316-347,380-395); torchvision is not part of this stack, so
+the same operations are provided here on PIL images / torch tensors, with torch's RNG as
+the source of randomness (so `apply_seed` governs augmentation):
+
+  Lambda, Resize(shorter side, bilinear), CenterCrop, RandomCrop,
+  RandomResizedCrop(size, scale, ratio), RandomRotation(degrees), RandomHorizontalFlip(p),
+  ColorJitter(brightness, contrast, saturation, hue), ToTensor, Normalize(mean, std),
+  RandomErasing(p, scale, ratio, value), Compose.
+
+Batches leave the loaders as float32 [N,3,H,W] + int64 [N] exactly like the reference's.
+"""
+
+from __future__ import annotations
+
+import math
+import os
+from collections.abc import Callable, Sequence
+from pathlib import Path
+from typing import Any
+
+import numpy as np
+import torch
+from PIL import Image, ImageEnhance
+
+IMG_EXTENSIONS = (".jpg", ".jpeg", ".png", ".ppm", ".bmp", ".pgm", ".tif", ".tiff", ".webp")
+
+
+def _rand() -> float:
+    return float(torch.rand(1).item())
+
+
+def _uniform(lo: float, hi: float) -> float:
+    return float(torch.empty(1).uniform_(lo, hi).item())
+
+
+class Compose:
+    def __init__(self, ops: Sequence[Callable]) -> None:
+        self.ops = list(ops)
+
+    def __call__(self, img: Any) -> Any:
+        for op in self.ops:
+            img = op(img)
+        return img
+
+
+class Lambda:
+    def __init__(self, fn: Callable) -> None:
+        self.fn = fn
+
+    def __call__(self, img: Any) -> Any:
+        return self.fn(img)
+
+
+class Resize:
+    """Shorter side -> `size` (int) keeping the aspect ratio, or exact (h, w); bilinear."""
+
+    def __init__(self, size: int | tuple[int, int], interpolation: int = Image.BILINEAR) -> None:
+        self.size, self.interpolation = size, interpolation
+
+    def __call__(self, img: Image.Image) -> Image.Image:
+        w, h = img.size
+        if isinstance(self.size, int):
+            short, long = (w, h) if w <= h else (h, w)
+            if short == self.size:
+                return img
+            new_short, new_long = self.size, int(self.size * long / short)
+            nw, nh = (new_short, new_long) if w <= h else (new_long, new_short)
+        else:
+            nh, nw = self.size
+        return img.resize((nw, nh), self.interpolation)
+
+
+def _pad_to(img: Image.Image, th: int, tw: int) -> Image.Image:
+    w, h = img.size
+    if w >= tw and h >= th:
+        return img
+    canvas = Image.new(img.mode, (max(w, tw), max(h, th)))
+    canvas.paste(img, ((max(w, tw) - w) // 2, (max(h, th) - h) // 2))
+    return canvas
+
+
+class CenterCrop:
+    def __init__(self, size: int | tuple[int, int]) -> None:
+        self.size = (size, size) if isinstance(size, int) else tuple(size)
+
+    def __call__(self, img: Image.Image) -> Image.Image:
+        th, tw = self.size
+        img = _pad_to(img, th, tw)
+        w, h = img.size
+        top, left = int(round((h - th) / 2.0)), int(round((w - tw) / 2.0))
+        return img.crop((left, top, left + tw, top + th))
+
+
+class RandomCrop:
+    def __init__(self, size: int | tuple[int, int]) -> None:
+        self.size = (size, size) if isinstance(size, int) else tuple(size)
+
+    def __call__(self, img: Image.Image) -> Image.Image:
+        th, tw = self.size
+        img = _pad_to(img, th, tw)
+        w, h = img.size
+        top = int(torch.randint(0, h - th + 1, (1,)).item())
+        left = int(torch.randint(0, w - tw + 1, (1,)).item())
+        return img.crop((left, top, left + tw, top + th))
+
+
+class RandomResizedCrop:
+    """Random area fraction in `scale`, log-uniform aspect in `ratio`, resized to size x size."""
+
+    def __init__(self, size: int, scale: tuple[float, float] = (0.08, 1.0), ratio: tuple[float, float] = (3 / 4, 4 / 3),
+                 interpolation: int = Image.BILINEAR) -> None:
+        self.size, self.scale, self.ratio, self.interpolation = size, scale, ratio, interpolation
+
+    def _box(self, w: int, h: int) -> tuple[int, int, int, int]:
+        area = w * h
+        log_lo, log_hi = math.log(self.ratio[0]), math.log(self.ratio[1])
+        for _ in range(10):
+            target = area * _uniform(*self.scale)
+            aspect = math.exp(_uniform(log_lo, log_hi))
+            cw, ch = int(round(math.sqrt(target * aspect))), int(round(math.sqrt(target / aspect)))
+            if 0 < cw <= w and 0 < ch <= h:
+                top = int(torch.randint(0, h - ch + 1, (1,)).item())
+                left = int(torch.randint(0, w - cw + 1, (1,)).item())
+                return left, top, cw, ch
+        in_ratio = w / h
+        if in_ratio < self.ratio[0]:
+            cw, ch = w, int(round(w / self.ratio[0]))
+        elif in_ratio > self.ratio[1]:
+            ch, cw = h, int(round(h * self.ratio[1]))
+        else:
+            cw, ch = w, h
+        return (w - cw) // 2, (h - ch) // 2, cw, ch
+
+    def __call__(self, img: Image.Image) -> Image.Image:
+        left, top, cw, ch = self._box(*img.size)
+        return img.crop((left, top, left + cw, top + ch)).resize((self.size, self.size), self.interpolation)
+
+
+class RandomRotation:
+    def __init__(self, degrees: float) -> None:
+        self.degrees = float(degrees)
+
+    def __call__(self, img: Image.Image) -> Image.Image:
+        return img.rotate(_uniform(-self.degrees, self.degrees), resample=Image.NEAREST, expand=False)
+
+
+class RandomHorizontalFlip:
+    def __init__(self, p: float = 0.5) -> None:
+        self.p = p
+
+    def __call__(self, img: Image.Image) -> Image.Image:
+        return img.transpose(Image.FLIP_LEFT_RIGHT) if _rand() < self.p else img
+
+
+def _shift_hue(img: Image.Image, delta: float) -> Image.Image:
+    if img.mode not in ("RGB", "L"):
+        return img
+    if img.mode == "L":
+        return img
+    hsv = np.array(img.convert("HSV"), dtype=np.uint8)
+    hsv[..., 0] = (hsv[..., 0].astype(np.int16) + int(round(delta * 255))) % 256
+    return Image.fromarray(hsv, "HSV").convert("RGB")
+
+
+class ColorJitter:
+    def __init__(self, brightness: float = 0.0, contrast: float = 0.0, saturation: float = 0.0, hue: float = 0.0) -> None:
+        self.brightness, self.contrast, self.saturation, self.hue = brightness, contrast, saturation, hue
+
+    def __call__(self, img: Image.Image) -> Image.Image:
+        order = torch.randperm(4).tolist()
+        for which in order:
+            if which == 0 and self.brightness > 0:
+                img = ImageEnhance.Brightness(img).enhance(_uniform(max(0.0, 1 - self.brightness), 1 + self.brightness))
+            elif which == 1 and self.contrast > 0:
+                img = ImageEnhance.Contrast(img).enhance(_uniform(max(0.0, 1 - self.contrast), 1 + self.contrast))
+            elif which == 2 and self.saturation > 0:
+                img = ImageEnhance.Color(img).enhance(_uniform(max(0.0, 1 - self.saturation), 1 + self.saturation))
+            elif which == 3 and self.hue > 0:
+                img = _shift_hue(img, _uniform(-self.hue, self.hue))
+        return img
+
+
+class ToTensor:
+    """PIL image (uint8) -> float32 CHW in [0, 1]."""
+
+    def __call__(self, img: Image.Image) -> torch.Tensor:
+        arr = np.asarray(img, dtype=np.uint8)
+        if arr.ndim == 2:
+            arr = arr[:, :, None]
+        return torch.from_numpy(np.ascontiguousarray(arr.transpose(2, 0, 1))).to(torch.float32).div_(255.0)
+
+
+class Normalize:
+    def __init__(self, mean: Sequence[float], std: Sequence[float]) -> None:
+        self.mean = torch.tensor(mean, dtype=torch.float32).view(-1, 1, 1)
+        self.std = torch.tensor(std, dtype=torch.float32).view(-1, 1, 1)
+
+    def __call__(self, t: torch.Tensor) -> torch.Tensor:
+        return (t - self.mean) / self.std
+
+
+class RandomErasing:
+    def __init__(self, p: float = 0.5, scale: tuple[float, float] = (0.02, 0.33), ratio: tuple[float, float] = (0.3, 3.3),
+                 value: float = 0.0) -> None:
+        self.p, self.scale, self.ratio, self.value = p, scale, ratio, value
+
+    def __call__(self, t: torch.Tensor) -> torch.Tensor:
+        if _rand() >= self.p:
+            return t
+        _, h, w = t.shape
+        area = h * w
+        log_lo, log_hi = math.log(self.ratio[0]), math.log(self.ratio[1])
+        for _ in range(10):
+            target = area * _uniform(*self.scale)
+            aspect = math.exp(_uniform(log_lo, log_hi))
+            eh, ew = int(round(math.sqrt(target * aspect))), int(round(math.sqrt(target / aspect)))
+            if eh < h and ew < w:
+                top = int(torch.randint(0, h - eh + 1, (1,)).item())
+                left = int(torch.randint(0, w - ew + 1, (1,)).item())
+                t = t.clone()
+                t[:, top:top + eh, left:left + ew] = self.value
+                return t
+        return t
+
+
+def pil_rgb_loader(path: str | os.PathLike) -> Image.Image:
+    with open(path, "rb") as handle:
+        return Image.open(handle).convert("RGB")
+
+
+class ImageFolder(torch.utils.data.Dataset):
+    """root/<class>/<image> layout; classes are the sorted sub-directory names."""
+
+    def __init__(self, root: str | os.PathLike, transform: Callable | None = None,
+                 loader: Callable[[str], Any] = pil_rgb_loader) -> None:
+        self.root = Path(root)
+        self.transform, self.loader = transform, loader
+        self.classes = sorted(entry.name for entry in os.scandir(self.root) if entry.is_dir())
+        if not self.classes:
+            raise FileNotFoundError(f"Couldn't find any class folder in {self.root}.")
+        self.class_to_idx = {name: i for i, name in enumerate(self.classes)}
+        self.samples: list[tuple[str, int]] = []
+        for name in self.classes:
+            for folder, _, files in sorted(os.walk(self.root / name, followlinks=True)):
+                for fname in sorted(files):
+                    if fname.lower().endswith(IMG_EXTENSIONS):
+                        self.samples.append((os.path.join(folder, fname), self.class_to_idx[name]))
+        self.targets = [target for _, target in self.samples]
+        self.imgs = self.samples
+
+    def __len__(self) -> int:
+        return len(self.samples)
+
+    def __getitem__(self, index: int):
+        path, target = self.samples[index]
+        sample = self.loader(path)
+        if self.transform is not None:
+            sample = self.transform(sample)
+        return sample, target
+
+
+__all__ = [
+    "CenterCrop", "ColorJitter", "Compose", "ImageFolder", "Lambda", "Normalize", "RandomCrop", "RandomErasing",
+    "RandomHorizontalFlip", "RandomResizedCrop", "RandomRotation", "Resize", "ToTensor", "pil_rgb_loader",
+]

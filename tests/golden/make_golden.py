@@ -35,9 +35,10 @@ def reference_contract() -> dict:
     from orchestration.config_schema import OrchestratorConfig         # noqa: PLC0415
     from pydantic import ValidationError                               # noqa: PLC0415
 
-    out: dict = {"configs": {}, "validation_errors": {}, "env": {}}
+    out: dict = {"configs": {}, "config_inputs": {}, "validation_errors": {}, "env": {}}
     for name in ("train.yaml", "train_imagenette.yaml", "inference.yaml"):
         raw = yaml.safe_load((REF / "config" / name).read_text())
+        out["config_inputs"][name] = raw                      # the parsed YAML (data), fed to our schema in the test
         out["configs"][name] = OrchestratorConfig(**raw).model_dump()
     base = {"data": {"root": "d"}, "models": {"a": {}}}
     cases = {
@@ -52,6 +53,10 @@ def reference_contract() -> dict:
         except ValidationError as exc:
             out["validation_errors"][key] = [e["msg"] for e in exc.errors()]
     out["defaults"] = OrchestratorConfig(**base).model_dump()
+    out["validation_inputs"] = cases
+    extra = {"data": {"root": "d", "bogus": 1}, "models": {"a": {"training": {"lr": 0.5, "x": [1]}, "zzz": 3}}, "top_extra": True}
+    out["extras_input"] = extra
+    out["extras_output"] = OrchestratorConfig(**extra).model_dump()
 
     env = out["env"]
     os.environ["TRANSFORMS"] = '{"train_to_tensor":false,"train_color_jitter":"yes","x":0}'

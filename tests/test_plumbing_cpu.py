@@ -1,0 +1,126 @@
+"""BASELINE.json configs[0] — the reference's CPU-runnable plumbing case: the whole
+registry / YAML / env-var / trainer / checkpoint / inference surface end to end on CPU with
+a tiny generated ImageFolder.  The HIP engine cannot (and must not) run on CPU, so the
+model is a plug-in stub registered through the public registry hook; everything around it
+is the product code.
+"""
+
+from __future__ import annotations
+
+import json
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+import yaml
+from PIL import Image
+from torch import nn
+
+from deepfakedetection_amd.orchestration import model_registry as reg
+from deepfakedetection_amd.orchestration.orchestrator import orchestrate
+
+
+class TinyNet(nn.Module):
+    """Stand-in classifier with the head naming the trainers' freeze mask looks for."""
+
+    def __init__(self, num_classes: int) -> None:
+        super().__init__()
+        self.conv_stem = nn.Conv2d(3, 8, 3, stride=2, padding=1, bias=False)
+        self.bn1 = nn.BatchNorm2d(8)
+        self.classifier = nn.Linear(8, num_classes)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return self.classifier(torch.relu(self.bn1(self.conv_stem(x))).mean((2, 3)))
+
+
+def _make_dataset(root: Path, classes=("cat", "dog", "eel"), per_class=6, size=40) -> None:
+    rng = np.random.default_rng(0)
+    for split in ("train", "val", "test"):
+        for ci, name in enumerate(classes):
+            folder = root / split / name
+            folder.mkdir(parents=True)
+            for i in range(per_class):
+                arr = (rng.random((size, size + 8, 3)) * 255).astype(np.uint8)
+                arr[..., ci % 3] //= 2
+                mode_l = (i == 0)
+                Image.fromarray(arr[..., 0] if mode_l else arr).save(folder / f"{i}.png")   # one grayscale: ensure_rgb path
+
+
+@pytest.fixture()
+def workspace(tmp_path, monkeypatch):
+    monkeypatch.chdir(tmp_path)
+    _make_dataset(tmp_path / "data")
+    reg.register_model_spec(reg.ModelSpec("tinynet_stub", "deepfakedetection_amd.trainers.efficientnet", "tinynet_stub", 32,
+                                          lambda _name, nc: TinyNet(nc)))
+    return tmp_path
+
+
+def _config(tmp_path: Path, **model_block) -> Path:
+    cfg = {
+        "seed": 1, "device": "cpu",
+        "data": {"root": str(tmp_path / "data"), "train_split": "train", "val_split": "val", "test_split": "test",
+                 "num_classes": 3, "img_size": 32},
+        "models": {"tinynet_stub": {"output_dir": str(tmp_path / "runs" / "tiny"), **model_block}},
+        "selection": ["tinynet_stub"],
+    }
+    path = tmp_path / "cfg.yaml"
+    path.write_text(yaml.safe_dump(cfg))
+    return path
+
+
+def test_training_then_inference_end_to_end(workspace):
+    tmp = workspace
+    cfg = _config(tmp, training={"epochs": 2, "batch_size": 6, "num_workers": 0, "resume": "auto", "accum_steps": 2,
+                                 "ft_batch_size": 4, "pretrained": False},
+                  transforms={"train": {"train_random_resized_crop": False, "train_center_crop": True, "train_random_rotation": True,
+                                        "train_color_jitter": True, "train_random_erasing": True},
+                              "eval": {"val_resize": True}})
+    orchestrate(cfg, mode="training")
+    runs = sorted((tmp / "runs" / "tiny").iterdir())
+    assert len(runs) == 1
+    run = runs[0]
+    for rel in ("checkpoints/latest.ckpt", "checkpoints/best.ckpt", "EfficientNetModel.pth", "logs/train.log", "config_snapshot.yaml"):
+        assert (run / rel).exists(), rel
+    ckpt = torch.load(run / "checkpoints" / "latest.ckpt")
+    assert ckpt["epoch"] == 2 and ckpt["warmup_done"] is True and "optimizer" in ckpt and "scheduler" in ckpt
+    assert set(torch.load(run / "EfficientNetModel.pth")) == set(TinyNet(3).state_dict())
+    log = (run / "logs" / "train.log").read_text()
+    assert "Warmup (head only)" in log and "Fine-tune" in log and "val_acc=" in log and "img/s" not in log.split("Data")[0]
+    snap = yaml.safe_load((run / "config_snapshot.yaml").read_text())
+    assert snap["model"]["name"] == "tinynet_stub" and snap["global"]["seed"] == 1
+
+    weights = run / "EfficientNetModel.pth"
+    cfg2 = _config(tmp, inference={"weights": str(weights), "split": "test", "batch_size": 5, "num_workers": 0, "img_size": 32})
+    orchestrate(cfg2, mode="inference")
+    run2 = sorted((tmp / "runs" / "tiny").iterdir())[-1]
+    rows = [json.loads(line) for line in (run2 / "logs" / "metrics.jsonl").read_text().splitlines()]
+    assert rows[0]["model"] == "tinynet_stub" and rows[0]["split"] == "test" and 0.0 <= rows[0]["accuracy"] <= 1.0
+    assert np.array(rows[0]["confusion_matrix"]).sum() == 18
+    assert (run2 / "logs" / "inference.log").exists()
+
+
+def test_class_count_mismatch_exits(workspace):
+    cfg = yaml.safe_load(_config(workspace, training={"epochs": 1, "batch_size": 4, "num_workers": 0}).read_text())
+    cfg["data"]["num_classes"] = 2
+    path = workspace / "bad.yaml"
+    path.write_text(yaml.safe_dump(cfg))
+    with pytest.raises(SystemExit) as err:
+        orchestrate(path, mode="training")
+    assert err.value.code == 1
+
+
+def test_missing_dataset_exits(workspace):
+    cfg = yaml.safe_load(_config(workspace, training={"epochs": 1, "batch_size": 4, "num_workers": 0}).read_text())
+    cfg["data"]["root"] = str(workspace / "nowhere")
+    path = workspace / "bad2.yaml"
+    path.write_text(yaml.safe_dump(cfg))
+    with pytest.raises(SystemExit):
+        orchestrate(path, mode="training")
+
+
+def test_hip_model_refuses_cpu_input():
+    """The product model has no CPU path: a CPU tensor raises instead of falling back."""
+    model = reg.get_model_spec("efficientnet_b0").builder("efficientnet_b0", 2)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        model(torch.zeros(1, 3, 32, 32))
