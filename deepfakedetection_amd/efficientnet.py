@@ -174,6 +174,14 @@ class HipEfficientNet(nn.Module):
                 nn.init.uniform_(m.weight, -bound, bound)
                 nn.init.zeros_(m.bias)
 
+    def to(self, *args, **kwargs):
+        """`.to(memory_format=torch.channels_last)` (trainers/efficientnet.py:409) is accepted and
+        ignored for the PARAMETERS: the kernels read weights in torch's default [O][I][kh][kw]
+        layout, while activations are NHWC inside the engine whatever the input's strides."""
+        kwargs.pop("memory_format", None)
+        args = tuple(a for a in args if not isinstance(a, torch.memory_format))
+        return super().to(*args, **kwargs) if (args or kwargs) else self
+
     # -- named parts, resolved at call time (the reference swaps `_fc` after construction)
     def _parts(self):
         if self.flavour == "lukemelas":

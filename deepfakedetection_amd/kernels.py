@@ -43,6 +43,8 @@ def _p(t: torch.Tensor | None):
         return None
     if not t.is_cuda:
         raise RuntimeError("dfd kernels need tensors on a HIP device (no CPU fallback)")
+    if not t.is_contiguous():
+        raise ValueError(f"dfd kernels need contiguous tensors, got shape {tuple(t.shape)} strides {t.stride()}")
     return t.data_ptr()
 
 

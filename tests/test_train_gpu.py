@@ -42,7 +42,9 @@ def test_orchestrated_training_and_inference_on_gpu(tmp_path, monkeypatch, model
     assert "Warmup (head only)" in log and "val_acc=" in log
 
     infer_cfg = {**base, "models": {model_name: {"output_dir": out_dir, "inference": {
-        "weights": str(run / weights_file), "split": "test", "batch_size": 16, "num_workers": 0, "img_size": 64}}}}
+        # best weights exist only if the fine-tune epoch beat the warm-up (reference behaviour);
+        # latest.ckpt always exists and load_model unwraps its "model" entry (orchestrator.py:370-374)
+        "weights": str(run / "checkpoints" / "latest.ckpt"), "split": "test", "batch_size": 16, "num_workers": 0, "img_size": 64}}}}
     path2 = tmp_path / "infer.yaml"
     path2.write_text(yaml.safe_dump(infer_cfg))
     orchestrate(path2, mode="inference")
