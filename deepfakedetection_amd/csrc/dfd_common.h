@@ -170,4 +170,5 @@ __device__ __forceinline__ void reduce_rowlanes(float (&acc)[NV], float* red, in
         default: return DFD_EUNSUPPORTED;                                            \
     }
 
-int dfd_launch_sum_partials(const float* partials, int P, long L, float* out, int accumulate, hipStream_t st);
+// sums P partial rows of L floats; the buffer needs room for P + ceil(P/32) rows (two-stage reduction)
+int dfd_launch_sum_partials(float* partials, int P, long L, float* out, int accumulate, hipStream_t st);

@@ -1,5 +1,5 @@
 // dfd_dwconv.hip — depthwise k x k convolution (k in {3,5}, stride in {1,2}) over
-// NHWC activations for gfx950: forward, data gradient, weight gradient.
+// NHWC activations for gfx950: data gradient and weight gradient (forward: dfd_dwfwd.hip).
 //
 // All three kernels share one structure:
 //   * a workgroup owns a power-of-two chunk of CVB channel vectors (16 B each) and
@@ -100,105 +100,6 @@ __device__ __forceinline__ void stage_weights(float* __restrict__ wl, const floa
         const int tap = i / per_tap, cc = i - tap * per_tap;
         const int c = chunk_c0 + cc;
         wl[i] = c < C ? round_to<T>(w[(long)c * K * K + tap]) : 0.f;
-    }
-}
-
-// ---------------------------------------------------------------------------
-// forward
-// ---------------------------------------------------------------------------
-template <typename T, int K, int S, int ACT, bool PRO, bool STATS>
-__global__ void __launch_bounds__(DFD_THREADS, 4)
-k_dw_fwd(const T* __restrict__ x, const float* __restrict__ bnstate, const float* __restrict__ w, T* __restrict__ y,
-         DwGeom g, float* __restrict__ partials, int tile_bytes) {
-    constexpr int V = Vec<T>::N;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    uint4* tile = reinterpret_cast<uint4*>(smem);
-    float* wl = reinterpret_cast<float*>(smem + tile_bytes);
-    const int cvb = 1 << g.cvb_log2, PL = DFD_THREADS >> g.cvb_log2;
-    const int t = threadIdx.x, vl = t & (cvb - 1), pl = t >> g.cvb_log2;
-    const int vglob = blockIdx.y * cvb + vl;
-    const bool cvalid = vglob < g.CV;
-    const int c0 = vglob * V;
-    const int TW = 1 << g.tw_log2;
-
-    stage_weights<T, K>(wl, w, g.C, blockIdx.y * cvb * V, cvb);
-    float sc[V], sh[V], zz[V];
-#pragma unroll
-    for (int j = 0; j < V; ++j) { sc[j] = 1.f; sh[j] = 0.f; zz[j] = 0.f; }
-    if (PRO && cvalid) { load_f32<V>(bnstate + c0, sc); load_f32<V>(bnstate + g.C + c0, sh); }
-
-    int loff[DW_NP], oyl[DW_NP], oxl[DW_NP];
-#pragma unroll
-    for (int i = 0; i < DW_NP; ++i) {
-        const int p = pl + i * PL;
-        oyl[i] = p >> g.tw_log2;
-        oxl[i] = p & (TW - 1);
-        loff[i] = (((oyl[i] * S) * g.IW + oxl[i] * S) << g.cvb_log2) + vl;
-    }
-    float s1[V], s2[V];
-#pragma unroll
-    for (int j = 0; j < V; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
-
-    const int tiles = g.tiles_y * g.tiles_x;
-    for (int work = blockIdx.x; work < g.nwork; work += gridDim.x) {
-        const int n = work / tiles, tr = work - n * tiles;
-        const int ty = tr / g.tiles_x, tx = tr - ty * g.tiles_x;
-        const int oy0 = ty * g.TH, ox0 = tx * TW;
-        __syncthreads();
-        stage_tile<T, ACT, PRO ? 1 : 0>(tile, x, x, sc, sh, zz, (long)n * g.H * g.W * g.C, g.H, g.W, g.C, c0, cvalid,
-                                        oy0 * S - g.pt, ox0 * S - g.pl, g.IH, g.IW, g.iw_magic, g.cvb_log2);
-        __syncthreads();
-        float acc[DW_NP][V];
-#pragma unroll
-        for (int i = 0; i < DW_NP; ++i)
-#pragma unroll
-            for (int j = 0; j < V; ++j) acc[i][j] = 0.f;
-#pragma unroll 1
-        for (int kh = 0; kh < K; ++kh) {
-#pragma unroll
-            for (int kw = 0; kw < K; ++kw) {
-                float wv[V];
-                load_f32<V>(wl + ((kh * K + kw) * cvb + vl) * V, wv);
-                const int toff = (kh * g.IW + kw) << g.cvb_log2;
-#pragma unroll
-                for (int i = 0; i < DW_NP; ++i) {
-                    if (oyl[i] < g.TH) {
-                        float xv[V];
-                        unpack_q<T>(tile[loff[i] + toff], xv);
-#pragma unroll
-                        for (int j = 0; j < V; ++j) acc[i][j] = fmaf(xv[j], wv[j], acc[i][j]);
-                    }
-                }
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < DW_NP; ++i) {
-            const int oy = oy0 + oyl[i], ox = ox0 + oxl[i];
-            if (cvalid && oyl[i] < g.TH && oy < g.Ho && ox < g.Wo) {
-#pragma unroll
-                for (int j = 0; j < V; ++j) {
-                    const float r = round_to<T>(acc[i][j]);
-                    acc[i][j] = r;
-                    if constexpr (STATS) { s1[j] += r; s2[j] = fmaf(r, r, s2[j]); }
-                }
-                Vec<T>::store(y + (((long)n * g.Ho + oy) * g.Wo + ox) * g.C + c0, acc[i]);
-            }
-        }
-    }
-    if constexpr (STATS) {
-        __syncthreads();
-        float acc2[2 * V];
-#pragma unroll
-        for (int j = 0; j < V; ++j) { acc2[j] = s1[j]; acc2[V + j] = s2[j]; }
-        reduce_rowlanes<2 * V>(acc2, reinterpret_cast<float*>(smem), cvb, PL, vl, pl, true);
-        if (pl == 0 && cvalid) {
-            float* p = partials + (long)blockIdx.x * 2 * g.C;
-            float a0[V], a1[V];
-#pragma unroll
-            for (int j = 0; j < V; ++j) { a0[j] = acc2[j]; a1[j] = acc2[V + j]; }
-            store_f32<V>(p + c0, a0);
-            store_f32<V>(p + g.C + c0, a1);
-        }
     }
 }
 
@@ -394,18 +295,33 @@ k_dw_bwd_weight(const T* __restrict__ dz, const T* __restrict__ yraw, const floa
     }
 }
 
-// out[i] (+)= sum_p partials[p][i]
-__global__ void k_sum_partials(const float* __restrict__ partials, int P, long L, float* __restrict__ out, int accumulate) {
+// out[i] (+)= sum_p partials[p][i], in a fixed order.  Two stages when there are many
+// partial rows: groups of SUM_GROUP rows are summed by independent workgroups into the
+// rows that FOLLOW the slab in the workspace ([P .. P + ceil(P/SUM_GROUP))), then those.
+#define SUM_GROUP 32
+__global__ void k_sum_partials(const float* __restrict__ partials, int P, long L, float* __restrict__ out,
+                               long out_stride, int accumulate) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= L) return;
+    const int p0 = blockIdx.y * SUM_GROUP;
+    const int p1 = (p0 + SUM_GROUP < P) ? p0 + SUM_GROUP : P;
     float s = 0.f;
-    for (int p = 0; p < P; ++p) s += partials[(long)p * L + i];
-    out[i] = (accumulate ? out[i] : 0.f) + s;
+    for (int p = p0; p < p1; ++p) s += partials[(long)p * L + i];
+    float* o = out + (long)blockIdx.y * out_stride + i;
+    *o = (accumulate ? *o : 0.f) + s;
 }
-int dfd_launch_sum_partials(const float* partials, int P, long L, float* out, int accumulate, hipStream_t st) {
+// `partials` must have room for P + ceil(P / SUM_GROUP) rows of L floats.
+int dfd_launch_sum_partials(float* partials, int P, long L, float* out, int accumulate, hipStream_t st) {
     const int threads = 256;
-    const long grid = (L + threads - 1) / threads;
-    hipLaunchKernelGGL(k_sum_partials, dim3((unsigned)grid), dim3(threads), 0, st, partials, P, L, out, accumulate);
+    const unsigned gx = (unsigned)((L + threads - 1) / threads);
+    if (P > SUM_GROUP) {
+        const int G = (P + SUM_GROUP - 1) / SUM_GROUP;          // <= 32 for P <= 1024
+        float* mid = partials + (long)P * L;
+        hipLaunchKernelGGL(k_sum_partials, dim3(gx, G), dim3(threads), 0, st, partials, P, L, mid, L, 0);
+        hipLaunchKernelGGL(k_sum_partials, dim3(gx, 1), dim3(threads), 0, st, mid, G, L, out, 0, accumulate);
+    } else {
+        hipLaunchKernelGGL(k_sum_partials, dim3(gx, 1), dim3(threads), 0, st, partials, P, L, out, 0, accumulate);
+    }
     return DFD_CHECK_LAUNCH();
 }
 
@@ -479,47 +395,6 @@ static inline int dw_grid_x(int nwork, int nchunks, int pcap) {
     else return DFD_EUNSUPPORTED;
 
 template <typename T>
-static int dw_fwd_t(const void* x, const float* in_bnstate, int in_act, const float* w, void* y,
-                    const dfd_dwconv_shape* s, float* partials, int pcap, int* nparts, hipStream_t st) {
-    constexpr int V = Vec<T>::N;
-    DwGeom g; int tile_bytes;
-    if (!make_geom(s, V, false, 16, 0, &g, &tile_bytes)) return DFD_EINVAL;
-    const int cvb = 1 << g.cvb_log2, nchunks = (g.CV + cvb - 1) / cvb;
-    const bool stats = partials != nullptr;
-    const int gx = dw_grid_x(g.nwork, nchunks, stats ? pcap : DFD_MAX_PARTIALS);
-    if (stats) *nparts = gx;
-    size_t lds = (size_t)tile_bytes + (size_t)s->k * s->k * cvb * V * 4;
-    const size_t red = (size_t)DFD_THREADS * 2 * V * 4;
-    if (lds < red) lds = red;
-    dim3 grid(gx, nchunks);
-    const bool pro = in_bnstate != nullptr;
-    if (!pro) in_act = DFD_ACT_NONE;
-#define LAUNCH_FWD(PRO, STATS) \
-    hipLaunchKernelGGL((k_dw_fwd<T, K, S, ACT, PRO, STATS>), grid, dim3(DFD_THREADS), lds, st, (const T*)x, in_bnstate, w, \
-                       (T*)y, g, partials, tile_bytes)
-    DISPATCH_KS(s->k, s->stride, {
-        if (pro) {
-            DISPATCH_ACT(in_act, { if (stats) LAUNCH_FWD(true, true); else LAUNCH_FWD(true, false); });
-        } else {
-            constexpr int ACT = DFD_ACT_NONE;
-            if (stats) LAUNCH_FWD(false, true); else LAUNCH_FWD(false, false);
-        }
-    });
-#undef LAUNCH_FWD
-    return DFD_CHECK_LAUNCH();
-}
-
-extern "C" int dfd_dwconv_fwd(int dtype, const void* x, const float* in_bnstate, int in_act, const float* w, void* y,
-                              const dfd_dwconv_shape* s, float* partials, int pcap, int* nparts, dfd_stream stream) {
-    if (!x || !w || !y || !s) return DFD_EINVAL;
-    if (partials && (!nparts || pcap < 1)) return DFD_EINVAL;
-    hipStream_t st = (hipStream_t)stream;
-    if (dtype == DFD_BF16) return dw_fwd_t<bf16>(x, in_bnstate, in_act, w, y, s, partials, pcap, nparts, st);
-    if (dtype == DFD_F32) return dw_fwd_t<float>(x, in_bnstate, in_act, w, y, s, partials, pcap, nparts, st);
-    return DFD_EINVAL;
-}
-
-template <typename T>
 static int dw_bwd_data_t(const void* dz, const void* y, const float* coef, const float* w, const void* xin,
                          const float* in_bnstate, int in_act, void* dzin, const dfd_dwconv_shape* s, float* partials,
                          int pcap, int* nparts, hipStream_t st) {
@@ -589,7 +464,7 @@ extern "C" size_t dfd_dwconv_bwd_weight_ws(const dfd_dwconv_shape* s) {
     if (!dw_wgrad_geom<bf16>(s, &g, &tile_bytes)) return 0;
     const size_t per = (size_t)g.C * s->k * s->k * 4;
     const size_t a = (size_t)16 << 20, b = per * 32;
-    return a > b ? a : b;
+    return (a > b ? a : b) + per * 34;      // + second-stage rows of the partial-slab reduction
 }
 
 template <typename T>
@@ -602,7 +477,7 @@ static int dw_bwd_weight_t(const void* dz, const void* y, const float* coef, con
     const int cvb = 1 << g.cvb_log2, nchunks = (g.CV + cvb - 1) / cvb;
     const int KK = s->k * s->k;
     const int P = dw_wgrad_parts(g, s->k, nchunks);
-    if ((size_t)P * g.C * KK * 4 > ws_bytes) return DFD_EWORKSPACE;
+    if ((size_t)(P + P / 32 + 2) * g.C * KK * 4 > ws_bytes) return DFD_EWORKSPACE;
     const int TW = 1 << g.tw_log2;
     size_t lds = (size_t)tile_bytes + (size_t)g.TH * TW * cvb * 16;
     const size_t red = (size_t)((DFD_THREADS / cvb) / KK) * KK * cvb * V * 4;

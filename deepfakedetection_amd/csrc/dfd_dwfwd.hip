@@ -1,0 +1,335 @@
+// dfd_dwfwd.hip — depthwise k x k convolution, forward, second-generation kernel.
+//
+// Measured motivation (profiles/, rocprofv3 PMC on MI355X): the first kernel spent ~440
+// VALU lane-ops per 16-byte output vector and ran at ~60 % VALU utilisation, i.e. it was
+// issue-bound at ~1.3 TB/s although the data path is HBM-bound by arithmetic intensity.
+// This version cuts the instruction count:
+//   * a lane computes a QUAD of four horizontally adjacent outputs, so each staged input
+//     vector is read from LDS and unpacked ONCE per kernel row and feeds up to 4*K taps;
+//   * all arithmetic is on float2 pairs -> v_pk_fma_f32 / v_pk_mul_f32 (two lanes' worth
+//     of FMAs per instruction);
+//   * tiles are chosen per layer by a small cost model (staged pixels vs. idle lanes vs.
+//     LDS bytes) instead of a fixed 8x16, so 14x14 / 7x7 images are one tile, not two
+//     ragged ones, and wide images use full-width strips with little halo;
+//   * the workgroup walks (image, tile) work items persistently as before: one partial
+//     (sum, sumsq) row per workgroup, BN + SiLU of the producer applied once per staged
+//     element, zero padding written in the activated domain.
+#include "dfd_common.h"
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+struct DwQGeom {
+    int N, H, W, C, Ho, Wo, pt, pl;
+    int CV, cvb_log2;
+    int TH, QW, NQ;            // tile = TH rows x QW quads (4*QW columns), NQ = TH*QW
+    unsigned qw_magic;         // q / QW == (q * qw_magic) >> 20
+    int tiles_y, tiles_x, nwork;
+    int IH, IW;
+    unsigned iw_magic;
+};
+
+template <typename T> struct V2 { static constexpr int N = Vec<T>::N / 2; };
+
+__device__ __forceinline__ void unpack2(const uint4& q, f2 (&v)[4]) {       // 8 x bf16
+    v[0] = (f2){__uint_as_float(q.x << 16), __uint_as_float(q.x & 0xffff0000u)};
+    v[1] = (f2){__uint_as_float(q.y << 16), __uint_as_float(q.y & 0xffff0000u)};
+    v[2] = (f2){__uint_as_float(q.z << 16), __uint_as_float(q.z & 0xffff0000u)};
+    v[3] = (f2){__uint_as_float(q.w << 16), __uint_as_float(q.w & 0xffff0000u)};
+}
+__device__ __forceinline__ void unpack2(const uint4& q, f2 (&v)[2]) {       // 4 x f32
+    v[0] = (f2){__uint_as_float(q.x), __uint_as_float(q.y)};
+    v[1] = (f2){__uint_as_float(q.z), __uint_as_float(q.w)};
+}
+__device__ __forceinline__ uint4 pack2(const f2 (&v)[4]) {
+    return make_uint4(pack_bf2(v[0].x, v[0].y), pack_bf2(v[1].x, v[1].y), pack_bf2(v[2].x, v[2].y), pack_bf2(v[3].x, v[3].y));
+}
+__device__ __forceinline__ uint4 pack2(const f2 (&v)[2]) {
+    return make_uint4(__float_as_uint(v[0].x), __float_as_uint(v[0].y), __float_as_uint(v[1].x), __float_as_uint(v[1].y));
+}
+template <typename T> __device__ __forceinline__ f2 round2(f2 v) {
+    if constexpr (sizeof(T) == 2) return (f2){bf2f(f2bf(v.x)), bf2f(f2bf(v.y))};
+    else return v;
+}
+
+// stage the input tile: tile[pix][vl] = rnd(act(scale*x+shift)) or x, zero outside the image
+template <typename T, int ACT, bool PRO>
+__device__ __forceinline__ void stage_q(uint4* __restrict__ tile, const T* __restrict__ src, const f2 (&sc)[V2<T>::N],
+                                        const f2 (&sh)[V2<T>::N], long img_base, int SH, int SW, int C, int c0, bool cvalid,
+                                        int gy0, int gx0, int IH, int IW, unsigned magic, int cvb_log2) {
+    constexpr int N2 = V2<T>::N;
+    const int total = (IH * IW) << cvb_log2;
+    for (int base = threadIdx.x; base < total; base += DFD_THREADS * 4) {
+        uint4 raw[4];
+        bool inb[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int idx = base + u * DFD_THREADS;
+            const int pix = idx >> cvb_log2;
+            const int iy = (int)(((unsigned)pix * magic) >> 20);
+            const int ix = pix - iy * IW;
+            const int gy = gy0 + iy, gx = gx0 + ix;
+            inb[u] = cvalid && idx < total && (unsigned)gy < (unsigned)SH && (unsigned)gx < (unsigned)SW;
+            if (inb[u]) raw[u] = *reinterpret_cast<const uint4*>(src + img_base + ((long)gy * SW + gx) * C + c0);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int idx = base + u * DFD_THREADS;
+            if (idx >= total) continue;
+            uint4 q = make_uint4(0, 0, 0, 0);
+            if (inb[u]) {
+                if constexpr (!PRO) {
+                    q = raw[u];
+                } else {
+                    f2 v[N2];
+                    unpack2(raw[u], v);
+#pragma unroll
+                    for (int j = 0; j < N2; ++j) {
+                        const f2 z = __builtin_elementwise_fma(sc[j], v[j], sh[j]);
+                        if constexpr (ACT == DFD_ACT_SILU) {
+                            const f2 e = (f2){__expf(-z.x), __expf(-z.y)};
+                            const f2 d = e + (f2){1.f, 1.f};
+                            v[j] = z * (f2){__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+                        } else {
+                            v[j] = (f2){act_fwd<ACT>(z.x), act_fwd<ACT>(z.y)};
+                        }
+                    }
+                    q = pack2(v);
+                }
+            }
+            tile[idx] = q;
+        }
+    }
+}
+
+template <typename T, int K, int S, int ACT, bool PRO, bool STATS>
+__global__ void __launch_bounds__(DFD_THREADS, 4)
+k_dw_fwd_q(const T* __restrict__ x, const float* __restrict__ bnstate, const float* __restrict__ w, T* __restrict__ y,
+           DwQGeom g, float* __restrict__ partials, int tile_bytes) {
+    constexpr int V = Vec<T>::N, N2 = V / 2;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint4* tile = reinterpret_cast<uint4*>(smem);
+    float* wl = reinterpret_cast<float*>(smem + tile_bytes);      // [tap][cvb*V] f32, rounded to T
+    const int cvb = 1 << g.cvb_log2, PL = DFD_THREADS >> g.cvb_log2;
+    const int t = threadIdx.x, vl = t & (cvb - 1), lane = t >> g.cvb_log2;
+    const int vglob = blockIdx.x * cvb + vl;           // channel chunk is the FAST grid index:
+    const bool cvalid = vglob < g.CV;                  // neighbouring chunks of one tile run together
+    const int c0 = vglob * V;
+
+    for (int i = t; i < K * K * cvb * V; i += DFD_THREADS) {
+        const int tap = i / (cvb * V), cc = i - tap * (cvb * V);
+        const int c = blockIdx.x * cvb * V + cc;
+        wl[i] = c < g.C ? round_to<T>(w[(long)c * K * K + tap]) : 0.f;
+    }
+    f2 sc[N2], sh[N2];
+#pragma unroll
+    for (int j = 0; j < N2; ++j) { sc[j] = (f2){1.f, 1.f}; sh[j] = (f2){0.f, 0.f}; }
+    if (PRO && cvalid) {
+#pragma unroll
+        for (int j = 0; j < N2; ++j) {
+            sc[j] = *reinterpret_cast<const f2*>(bnstate + c0 + 2 * j);
+            sh[j] = *reinterpret_cast<const f2*>(bnstate + g.C + c0 + 2 * j);
+        }
+    }
+    f2 s1[N2], s2[N2];
+#pragma unroll
+    for (int j = 0; j < N2; ++j) { s1[j] = (f2){0.f, 0.f}; s2[j] = (f2){0.f, 0.f}; }
+
+    const int tiles = g.tiles_y * g.tiles_x, TW = 4 * g.QW;
+    for (int work = blockIdx.y; work < g.nwork; work += gridDim.y) {
+        const int n = work / tiles, tr = work - n * tiles;
+        const int ty = tr / g.tiles_x, tx = tr - ty * g.tiles_x;
+        const int oy0 = ty * g.TH, ox0 = tx * TW;
+        __syncthreads();
+        stage_q<T, ACT, PRO>(tile, x, sc, sh, (long)n * g.H * g.W * g.C, g.H, g.W, g.C, c0, cvalid, oy0 * S - g.pt,
+                             ox0 * S - g.pl, g.IH, g.IW, g.iw_magic, g.cvb_log2);
+        __syncthreads();
+        if (!cvalid) continue;
+#pragma unroll 1
+        for (int q = lane; q < g.NQ; q += PL) {
+            const int qy = (int)(((unsigned)q * g.qw_magic) >> 20), qx = q - qy * g.QW;
+            const int oy = oy0 + qy, ox = ox0 + 4 * qx;
+            if (oy >= g.Ho || ox >= g.Wo) continue;
+            f2 acc[4][N2];
+#pragma unroll
+            for (int o = 0; o < 4; ++o)
+#pragma unroll
+                for (int j = 0; j < N2; ++j) acc[o][j] = (f2){0.f, 0.f};
+#pragma unroll 1
+            for (int kh = 0; kh < K; ++kh) {
+                const uint4* row = tile + ((((qy * S + kh) * g.IW) + qx * 4 * S) << g.cvb_log2) + vl;
+                f2 wv[K][N2];
+#pragma unroll
+                for (int kw = 0; kw < K; ++kw)
+#pragma unroll
+                    for (int j = 0; j < N2; ++j)
+                        wv[kw][j] = *reinterpret_cast<const f2*>(wl + ((kh * K + kw) * cvb + vl) * V + 2 * j);
+                if constexpr (S == 1) {
+                    f2 xv[K + 3][N2];
+#pragma unroll
+                    for (int c = 0; c < K + 3; ++c) unpack2(row[c << g.cvb_log2], xv[c]);
+#pragma unroll
+                    for (int kw = 0; kw < K; ++kw)
+#pragma unroll
+                        for (int o = 0; o < 4; ++o)
+#pragma unroll
+                            for (int j = 0; j < N2; ++j) acc[o][j] = __builtin_elementwise_fma(xv[o + kw][j], wv[kw][j], acc[o][j]);
+                } else {
+#pragma unroll
+                    for (int half = 0; half < 2; ++half) {
+                        f2 xv[K + 2][N2];
+#pragma unroll
+                        for (int c = 0; c < K + 2; ++c) unpack2(row[(4 * half + c) << g.cvb_log2], xv[c]);
+#pragma unroll
+                        for (int kw = 0; kw < K; ++kw)
+#pragma unroll
+                            for (int o = 0; o < 2; ++o)
+#pragma unroll
+                                for (int j = 0; j < N2; ++j)
+                                    acc[2 * half + o][j] = __builtin_elementwise_fma(xv[2 * o + kw][j], wv[kw][j], acc[2 * half + o][j]);
+                    }
+                }
+            }
+            T* dst = y + (((long)n * g.Ho + oy) * g.Wo + ox) * g.C + c0;
+#pragma unroll
+            for (int o = 0; o < 4; ++o) {
+                if (ox + o < g.Wo) {
+#pragma unroll
+                    for (int j = 0; j < N2; ++j) {
+                        const f2 r = round2<T>(acc[o][j]);
+                        acc[o][j] = r;
+                        if constexpr (STATS) { s1[j] += r; s2[j] = __builtin_elementwise_fma(r, r, s2[j]); }
+                    }
+                    *reinterpret_cast<uint4*>(dst + (long)o * g.C) = pack2(acc[o]);
+                }
+            }
+        }
+    }
+    if constexpr (STATS) {
+        __syncthreads();
+        float acc2[2 * V];
+#pragma unroll
+        for (int j = 0; j < N2; ++j) {
+            acc2[2 * j] = s1[j].x; acc2[2 * j + 1] = s1[j].y;
+            acc2[V + 2 * j] = s2[j].x; acc2[V + 2 * j + 1] = s2[j].y;
+        }
+        reduce_rowlanes<2 * V>(acc2, reinterpret_cast<float*>(smem), cvb, PL, vl, lane, true);
+        if (lane == 0 && cvalid) {
+            float* p = partials + (long)blockIdx.y * 2 * g.C;
+            float a0[V], a1[V];
+#pragma unroll
+            for (int j = 0; j < V; ++j) { a0[j] = acc2[j]; a1[j] = acc2[V + j]; }
+            store_f32<V>(p + c0, a0);
+            store_f32<V>(p + g.C + c0, a1);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// host: tile selection by a small cost model
+// ---------------------------------------------------------------------------
+static int ilog2p(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
+
+bool dfd_dwq_geom(const dfd_dwconv_shape* s, int vec, int max_cvb, DwQGeom* g, int* tile_bytes) {
+    if (!s || s->N <= 0 || s->H <= 0 || s->W <= 0 || s->Ho <= 0 || s->Wo <= 0 || s->C <= 0 || s->C % 8) return false;
+    if (!(s->k == 3 || s->k == 5) || !(s->stride == 1 || s->stride == 2)) return false;
+    if (s->pad_top < 0 || s->pad_left < 0 || s->pad_top >= s->k || s->pad_left >= s->k) return false;
+    if ((s->Ho - 1) * s->stride - s->pad_top > s->H - 1 || (s->Wo - 1) * s->stride - s->pad_left > s->W - 1) return false;
+    g->N = s->N; g->H = s->H; g->W = s->W; g->C = s->C; g->Ho = s->Ho; g->Wo = s->Wo; g->pt = s->pad_top; g->pl = s->pad_left;
+    g->CV = s->C / vec;
+    int best = 1, best_waste = 1 << 30;
+    for (int c = max_cvb; c >= 4; c >>= 1) {
+        const int waste = ((g->CV + c - 1) / c) * c - g->CV;
+        if (waste < best_waste) { best = c; best_waste = waste; }
+    }
+    if (g->CV < 4) best = g->CV >= 2 ? 2 : 1;
+    g->cvb_log2 = ilog2p(best);
+    const int cvb = best, PL = DFD_THREADS / cvb, K = s->k, S = s->stride;
+    const int maxQW = (s->Wo + 3) / 4;
+    double best_cost = 1e300;
+    int bTH = 1, bQW = 1;
+    for (int QW = 1; QW <= maxQW; ++QW) {
+        const int TW = 4 * QW, IW = (TW - 1) * S + K;
+        for (int TH = 1; TH <= s->Ho && TH <= 64; ++TH) {
+            const int IH = (TH - 1) * S + K;
+            const long px = (long)IH * IW;
+            if (px >= 4096) break;
+            const long lds = px * cvb * 16;
+            if (lds > 36 * 1024 && !(TH == 1 && QW == 1)) break;
+            const long tiles = (long)((s->Ho + TH - 1) / TH) * ((s->Wo + TW - 1) / TW);
+            const long rounds = ((long)TH * QW + PL - 1) / PL;
+            const double stage = (double)((px * cvb + DFD_THREADS - 1) / DFD_THREADS) * 120.0;
+            const double quad = 4.0 * K * K * (vec / 2) + (double)K * (K + 3) * (vec / 2) * 2 + 80.0;
+            const double cost = (double)tiles * (stage + rounds * quad + 250.0);
+            if (cost < best_cost) { best_cost = cost; bTH = TH; bQW = QW; }
+        }
+    }
+    g->TH = bTH; g->QW = bQW; g->NQ = bTH * bQW;
+    g->qw_magic = ((1u << 20) + bQW - 1) / bQW;
+    g->IH = (bTH - 1) * S + K; g->IW = (4 * bQW - 1) * S + K;
+    if ((long)g->IH * g->IW >= 4096 || g->NQ >= 4096) return false;
+    g->iw_magic = ((1u << 20) + g->IW - 1) / g->IW;
+    g->tiles_y = (s->Ho + bTH - 1) / bTH;
+    g->tiles_x = (s->Wo + 4 * bQW - 1) / (4 * bQW);
+    g->nwork = s->N * g->tiles_y * g->tiles_x;
+    *tile_bytes = g->IH * g->IW * cvb * 16;
+    return true;
+}
+
+#define DISPATCH_KS(KV, SV, ...)                                                        \
+    if (KV == 3 && SV == 1) { constexpr int K = 3, S = 1; __VA_ARGS__; }                \
+    else if (KV == 3 && SV == 2) { constexpr int K = 3, S = 2; __VA_ARGS__; }           \
+    else if (KV == 5 && SV == 1) { constexpr int K = 5, S = 1; __VA_ARGS__; }           \
+    else if (KV == 5 && SV == 2) { constexpr int K = 5, S = 2; __VA_ARGS__; }           \
+    else return DFD_EUNSUPPORTED;
+#define DISPATCH_ACT_DW(ACTV, ...)                                                   \
+    switch (ACTV) {                                                                  \
+        case DFD_ACT_NONE: { constexpr int ACT = DFD_ACT_NONE; __VA_ARGS__; } break; \
+        case DFD_ACT_SILU: { constexpr int ACT = DFD_ACT_SILU; __VA_ARGS__; } break; \
+        case DFD_ACT_RELU: { constexpr int ACT = DFD_ACT_RELU; __VA_ARGS__; } break; \
+        case DFD_ACT_GELU: { constexpr int ACT = DFD_ACT_GELU; __VA_ARGS__; } break; \
+        default: return DFD_EUNSUPPORTED;                                            \
+    }
+
+template <typename T>
+static int dw_fwd_q_t(const void* x, const float* in_bnstate, int in_act, const float* w, void* y,
+                      const dfd_dwconv_shape* s, float* partials, int pcap, int* nparts, hipStream_t st) {
+    constexpr int V = Vec<T>::N;
+    DwQGeom g; int tile_bytes;
+    if (!dfd_dwq_geom(s, V, 16, &g, &tile_bytes)) return DFD_EINVAL;
+    const int cvb = 1 << g.cvb_log2, nchunks = (g.CV + cvb - 1) / cvb;
+    const bool stats = partials != nullptr;
+    int cap = stats ? (pcap < DFD_MAX_PARTIALS ? pcap : DFD_MAX_PARTIALS) : DFD_MAX_PARTIALS;
+    int gy = 2048 / nchunks;
+    if (gy < 64) gy = 64;
+    if (gy > cap) gy = cap;
+    if (gy > g.nwork) gy = g.nwork;
+    if (stats) *nparts = gy;
+    size_t lds = (size_t)tile_bytes + (size_t)s->k * s->k * cvb * V * 4;
+    const size_t red = (size_t)DFD_THREADS * 2 * V * 4;
+    if (lds < red) lds = red;
+    dim3 grid(nchunks, gy);
+    const bool pro = in_bnstate != nullptr;
+#define LAUNCH_FWD(PRO, STATS) \
+    hipLaunchKernelGGL((k_dw_fwd_q<T, K, S, ACT, PRO, STATS>), grid, dim3(DFD_THREADS), lds, st, (const T*)x, in_bnstate, w, \
+                       (T*)y, g, partials, tile_bytes)
+    DISPATCH_KS(s->k, s->stride, {
+        if (pro) {
+            DISPATCH_ACT_DW(in_act, { if (stats) LAUNCH_FWD(true, true); else LAUNCH_FWD(true, false); });
+        } else {
+            constexpr int ACT = DFD_ACT_NONE;
+            if (stats) LAUNCH_FWD(false, true); else LAUNCH_FWD(false, false);
+        }
+    });
+#undef LAUNCH_FWD
+    return DFD_CHECK_LAUNCH();
+}
+
+extern "C" int dfd_dwconv_fwd(int dtype, const void* x, const float* in_bnstate, int in_act, const float* w, void* y,
+                              const dfd_dwconv_shape* s, float* partials, int pcap, int* nparts, dfd_stream stream) {
+    if (!x || !w || !y || !s) return DFD_EINVAL;
+    if (partials && (!nparts || pcap < 1)) return DFD_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == DFD_BF16) return dw_fwd_q_t<bf16>(x, in_bnstate, in_act, w, y, s, partials, pcap, nparts, st);
+    if (dtype == DFD_F32) return dw_fwd_q_t<float>(x, in_bnstate, in_act, w, y, s, partials, pcap, nparts, st);
+    return DFD_EINVAL;
+}

@@ -366,7 +366,7 @@ static int stem_wgrad_blocks(const dfd_stem_shape* s) {
 }
 extern "C" size_t dfd_stem_conv_wgrad_ws(const dfd_stem_shape* s) {
     if (!stem_ok(s)) return 0;
-    return (size_t)1024 * s->Cout * 27 * 4;
+    return (size_t)(1024 + 34) * s->Cout * 27 * 4;
 }
 extern "C" int dfd_stem_conv_wgrad(int dtype, const float* x, const void* dz, const void* y, const float* coef,
                                    float* dw, const dfd_stem_shape* s, int accumulate, float* ws, size_t ws_bytes,
@@ -375,7 +375,7 @@ extern "C" int dfd_stem_conv_wgrad(int dtype, const float* x, const void* dz, co
     if (!stem_ok(s)) return DFD_EINVAL;
     if (DFD_THREADS / s->Cout < 1 || (27 + DFD_THREADS / s->Cout - 1) / (DFD_THREADS / s->Cout) > STEM_TPT) return DFD_EUNSUPPORTED;
     const int P = stem_wgrad_blocks(s);
-    if ((size_t)P * s->Cout * 27 * 4 > ws_bytes) return DFD_EWORKSPACE;
+    if ((size_t)(P + P / 32 + 2) * s->Cout * 27 * 4 > ws_bytes) return DFD_EWORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     if (dtype == DFD_BF16)
         hipLaunchKernelGGL((k_stem_wgrad<bf16, 3>), dim3(P), dim3(DFD_THREADS), 0, st, x, (const bf16*)dz, (const bf16*)y, coef, *s, ws);
@@ -574,15 +574,21 @@ k_adamw(const int64_t* __restrict__ table, const float* __restrict__ hp) {
     const int cnt = (int)row[4];
     const float lr = hp[0], b1 = hp[1], b2 = hp[2], eps = hp[3], wd = hp[4], bc1 = hp[5], bc2 = hp[6], gs = hp[7];
     const float step = lr / bc1, rs2 = 1.0f / sqrtf(bc2), decay = 1.f - lr * wd;
-    for (int i = threadIdx.x; i < cnt; i += DFD_THREADS) {
-        const float gg = g[i] * gs;
-        const float mm = b1 * m[i] + (1.f - b1) * gg;
-        const float vv = b2 * v[i] + (1.f - b2) * gg * gg;
-        m[i] = mm;
-        v[i] = vv;
-        const float denom = sqrtf(vv) * rs2 + eps;
-        p[i] = p[i] * decay - step * (mm / denom);
+    auto upd = [&](float& pp, float gg, float& mm, float& vv) {
+        gg *= gs;
+        mm = b1 * mm + (1.f - b1) * gg;
+        vv = b2 * vv + (1.f - b2) * gg * gg;
+        pp = pp * decay - step * (mm / (sqrtf(vv) * rs2 + eps));
+    };
+    const bool vec = ((row[0] | row[1] | row[2] | row[3]) & 15) == 0;
+    const int nv = vec ? cnt / 4 : 0;
+    for (int i = threadIdx.x; i < nv; i += DFD_THREADS) {
+        float4 pq = reinterpret_cast<float4*>(p)[i], mq = reinterpret_cast<float4*>(m)[i], vq = reinterpret_cast<float4*>(v)[i];
+        const float4 gq = reinterpret_cast<const float4*>(g)[i];
+        upd(pq.x, gq.x, mq.x, vq.x); upd(pq.y, gq.y, mq.y, vq.y); upd(pq.z, gq.z, mq.z, vq.z); upd(pq.w, gq.w, mq.w, vq.w);
+        reinterpret_cast<float4*>(p)[i] = pq; reinterpret_cast<float4*>(m)[i] = mq; reinterpret_cast<float4*>(v)[i] = vq;
     }
+    for (int i = nv * 4 + threadIdx.x; i < cnt; i += DFD_THREADS) upd(p[i], g[i], m[i], v[i]);
 }
 extern "C" int dfd_adamw_step(const int64_t* table, int nchunks, const float* hp, dfd_stream stream) {
     if (!table || !hp || nchunks < 1) return DFD_EINVAL;

@@ -600,7 +600,7 @@ extern "C" size_t dfd_pwconv_wgrad_ws(int M, int Ni, int Nj) {
     size_t best = 0;
     for (int dt = 0; dt < 2; ++dt) {
         tn_plan(dt, M, Ni, Nj, &it, &jt, &s, &rps);
-        const size_t b = (size_t)s * Ni * Nj * 4;
+        const size_t b = (size_t)(s + s / 32 + 2) * Ni * Nj * 4;
         if (b > best) best = b;
     }
     return best;
@@ -611,7 +611,7 @@ static int pw_tn_t(const void* p, const dfd_prologue* pro_p, int Ni, const void*
                    int M, float* dw, int accumulate, float* ws, size_t ws_bytes, hipStream_t st) {
     int it, jt, splits, rps;
     tn_plan(sizeof(T) == 2 ? DFD_BF16 : DFD_F32, M, Ni, Nj, &it, &jt, &splits, &rps);
-    if ((size_t)splits * Ni * Nj * 4 > ws_bytes) return DFD_EWORKSPACE;
+    if ((size_t)(splits + splits / 32 + 2) * Ni * Nj * 4 > ws_bytes) return DFD_EWORKSPACE;
     constexpr int BMK = (sizeof(T) == 2) ? 64 : 32;
     constexpr int ROWB = (sizeof(T) == 2) ? 256 : TN_F32_ROW;
     const int lds = 2 * 2 * BMK * ROWB;
