@@ -52,7 +52,7 @@ SIGNATURES: dict[str, tuple] = {
     "dfd_pool_act": (c_int, [c_int, P, P, c_int, P, c_int, c_int, c_int, P]),
     "dfd_pool_bwd_reduce": (c_int, [c_int, P, P, P, c_int, P, c_int, c_int, c_int, P]),
     "dfd_scale_rows": (c_int, [c_int, P, P, P, c_int, c_int, c_int, P]),
-    "dfd_se_fc_fwd": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, P, P, P]),
+    "dfd_se_fc_fwd": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, P, P, P, P]),
     "dfd_se_fc_bwd": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, P, P, P, P, P, c_int, P, P]),
     "dfd_dwconv_fwd": (c_int, [c_int, P, P, c_int, P, P, POINTER(DwShape), P, c_int, _PI, P]),
     "dfd_dwconv_bwd_data": (c_int, [c_int, P, P, P, P, P, P, c_int, P, POINTER(DwShape), P, c_int, _PI, P]),

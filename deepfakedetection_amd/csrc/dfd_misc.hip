@@ -21,71 +21,87 @@ template <int ACT> __device__ __forceinline__ float act_rt(float z) { return act
 #define SE_MAX_C 4096
 #define SE_MAX_R 128
 
+// ---- forward, two short kernels instead of one long per-image loop:
+//   A: grid (ceil(R/4), N): one wave per hidden unit r: hpre[n][r] = b1[r] + <pooled[n,:], w1[r,:]>
+//   B: grid (ceil(C/256), N): one lane per channel c: gate = sigmoid(b2[c] + sum_r w2t[r][c]*act(hpre[n][r]))
+__device__ __forceinline__ float wave_dot(const float* __restrict__ a, const float* __restrict__ b, int C, int lane) {
+    float s = 0.f;
+    for (int c = lane * 4; c < C; c += 256) {                 // C % 8 == 0: float4 loads
+        const float4 x = *reinterpret_cast<const float4*>(a + c);
+        const float4 y = *reinterpret_cast<const float4*>(b + c);
+        s = fmaf(x.x, y.x, fmaf(x.y, y.y, fmaf(x.z, y.z, fmaf(x.w, y.w, s))));
+    }
+    return wave_sum(s);
+}
+
+__global__ void __launch_bounds__(DFD_THREADS)
+k_se_hidden(const float* __restrict__ pooled, const float* __restrict__ w1, const float* __restrict__ b1, int C, int R,
+            float* __restrict__ hpre) {
+    const int n = blockIdx.y, lane = threadIdx.x & 63, r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= R) return;
+    const float s = wave_dot(pooled + (long)n * C, w1 + (long)r * C, C, lane);
+    if (lane == 0) hpre[(long)n * R + r] = s + (b1 ? b1[r] : 0.f);
+}
+
 template <int ACT>
 __global__ void __launch_bounds__(DFD_THREADS)
-k_se_fc_fwd(const float* __restrict__ pooled, const float* __restrict__ w1, const float* __restrict__ b1,
-            const float* __restrict__ w2, const float* __restrict__ b2, int C, int R, float* __restrict__ hpre,
-            float* __restrict__ gate) {
-    __shared__ float sp[SE_MAX_C];
+k_se_gate(const float* __restrict__ hpre, const float* __restrict__ w2t, const float* __restrict__ b2, int C, int R,
+          float* __restrict__ gate) {
     __shared__ float sh[SE_MAX_R];
-    const int n = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    for (int c = t; c < C; c += DFD_THREADS) sp[c] = pooled[(long)n * C + c];
+    const int n = blockIdx.y, t = threadIdx.x, c = blockIdx.x * DFD_THREADS + t;
+    if (t < R) sh[t] = act_rt<ACT>(hpre[(long)n * R + t]);
     __syncthreads();
-    for (int r = wave; r < R; r += 4) {
-        float s = 0.f;
-        for (int c = lane; c < C; c += 64) s = fmaf(w1[(long)r * C + c], sp[c], s);
-        s = wave_sum(s);
-        if (lane == 0) {
-            const float z = s + (b1 ? b1[r] : 0.f);
-            hpre[(long)n * R + r] = z;
-            sh[r] = act_rt<ACT>(z);
-        }
+    if (c >= C) return;
+    float s = b2 ? b2[c] : 0.f;
+    for (int r = 0; r < R; ++r) s = fmaf(w2t[(long)r * C + c], sh[r], s);
+    gate[(long)n * C + c] = sigmoid_f(s);
+}
+
+// ---- backward, per-image part:
+//   A: grid (ceil(R/4), N): wave per r: dh = <dgate*g*(1-g), w2t[r,:]>; dhpre = dh*act'(hpre); also
+//      writes ws_g (by the r-block 0) / ws_dh / ws_h for the weight-gradient kernel
+//   B: grid (ceil(C/256), N): lane per c: dpooled[n][c] = sum_r dhpre[n][r] * w1[r][c]
+template <int ACT>
+__global__ void __launch_bounds__(DFD_THREADS)
+k_se_bwd_hidden(const float* __restrict__ dgate, const float* __restrict__ gate, const float* __restrict__ hpre,
+                const float* __restrict__ w2t, int N, int C, int R, float* __restrict__ ws) {
+    const int n = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = blockIdx.x * 4 + wave;
+    float* ws_g = ws;
+    float* ws_dh = ws + (long)N * C;
+    float* ws_h = ws_dh + (long)N * R;
+    if (r >= R) return;
+    const float* dg = dgate + (long)n * C;
+    const float* gt = gate + (long)n * C;
+    const float* wr = w2t + (long)r * C;
+    const bool writer = blockIdx.x == 0 && wave == 0;
+    float s = 0.f;
+    for (int c = lane * 4; c < C; c += 256) {
+        const float4 d = *reinterpret_cast<const float4*>(dg + c);
+        const float4 g = *reinterpret_cast<const float4*>(gt + c);
+        const float4 w = *reinterpret_cast<const float4*>(wr + c);
+        const float4 v = make_float4(d.x * g.x * (1.f - g.x), d.y * g.y * (1.f - g.y), d.z * g.z * (1.f - g.z), d.w * g.w * (1.f - g.w));
+        if (writer) *reinterpret_cast<float4*>(ws_g + (long)n * C + c) = v;
+        s = fmaf(v.x, w.x, fmaf(v.y, w.y, fmaf(v.z, w.z, fmaf(v.w, w.w, s))));
     }
-    __syncthreads();
-    for (int c = t; c < C; c += DFD_THREADS) {
-        float s = b2 ? b2[c] : 0.f;
-        for (int r = 0; r < R; ++r) s = fmaf(w2[(long)c * R + r], sh[r], s);
-        gate[(long)n * C + c] = sigmoid_f(s);
+    s = wave_sum(s);
+    if (lane == 0) {
+        const float z = hpre[(long)n * R + r];
+        ws_dh[(long)n * R + r] = s * act_grad<ACT>(z);
+        ws_h[(long)n * R + r] = act_rt<ACT>(z);
     }
 }
 
-// per-image part of the backward: dg_pre, dhpre, hact -> ws ; dpooled
-template <int ACT>
 __global__ void __launch_bounds__(DFD_THREADS)
-k_se_fc_bwd_a(const float* __restrict__ dgate, const float* __restrict__ gate, const float* __restrict__ hpre,
-              const float* __restrict__ w1, const float* __restrict__ w2, int N, int C, int R,
-              float* __restrict__ dpooled, float* __restrict__ ws) {
-    __shared__ float sg[SE_MAX_C];
+k_se_bwd_pooled(const float* __restrict__ ws, const float* __restrict__ w1, int N, int C, int R, float* __restrict__ dpooled) {
     __shared__ float sd[SE_MAX_R];
-    const int n = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    float* ws_g = ws;                         // [N][C]
-    float* ws_dh = ws + (long)N * C;          // [N][R]
-    float* ws_h = ws_dh + (long)N * R;        // [N][R]
-    for (int c = t; c < C; c += DFD_THREADS) {
-        const float g = gate[(long)n * C + c];
-        const float v = dgate[(long)n * C + c] * g * (1.f - g);
-        sg[c] = v;
-        ws_g[(long)n * C + c] = v;
-    }
+    const float* ws_dh = ws + (long)N * C;
+    const int n = blockIdx.y, t = threadIdx.x, c = blockIdx.x * DFD_THREADS + t;
+    if (t < R) sd[t] = ws_dh[(long)n * R + t];
     __syncthreads();
-    for (int r = wave; r < R; r += 4) {
-        float s = 0.f;
-        for (int c = lane; c < C; c += 64) s = fmaf(sg[c], w2[(long)c * R + r], s);
-        s = wave_sum(s);
-        if (lane == 0) {
-            const float z = hpre[(long)n * R + r];
-            const float d = s * act_grad<ACT>(z);
-            sd[r] = d;
-            ws_dh[(long)n * R + r] = d;
-            ws_h[(long)n * R + r] = act_rt<ACT>(z);
-        }
-    }
-    __syncthreads();
-    for (int c = t; c < C; c += DFD_THREADS) {
-        float s = 0.f;
-        for (int r = 0; r < R; ++r) s = fmaf(sd[r], w1[(long)r * C + c], s);
-        dpooled[(long)n * C + c] = s;
-    }
+    if (c >= C) return;
+    float s = 0.f;
+    for (int r = 0; r < R; ++r) s = fmaf(sd[r], w1[(long)r * C + c], s);
+    dpooled[(long)n * C + c] = s;
 }
 
 // weight gradients: grid (C/64, R); thread (c, nl) sums every 4th image, the four image
@@ -102,7 +118,18 @@ k_se_fc_bwd_w(const float* __restrict__ pooled, const float* __restrict__ ws, in
     const int c = blockIdx.x * 64 + cl, r = blockIdx.y;
     float a1 = 0.f, a2 = 0.f, sb2 = 0.f;
     if (c < C) {
-        for (int n = nl; n < N; n += 4) {
+        int n = nl;
+        for (; n + 12 < N; n += 16) {                           // four images in flight per lane
+            float g[4], pc[4], h[4], dh[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const long m = n + 4 * u;
+                g[u] = ws_g[m * C + c]; pc[u] = pooled[m * C + c]; h[u] = ws_h[m * R + r]; dh[u] = ws_dh[m * R + r];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { a2 = fmaf(g[u], h[u], a2); a1 = fmaf(dh[u], pc[u], a1); sb2 += g[u]; }
+        }
+        for (; n < N; n += 4) {
             const float g = ws_g[(long)n * C + c], pc = pooled[(long)n * C + c];
             a2 = fmaf(g, ws_h[(long)n * R + r], a2);
             a1 = fmaf(ws_dh[(long)n * R + r], pc, a1);
@@ -134,27 +161,41 @@ k_se_fc_bwd_w(const float* __restrict__ pooled, const float* __restrict__ ws, in
     }
 }
 
+__global__ void k_transpose_f32(const float* __restrict__ in, float* __restrict__ out, int rows, int cols) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;       // index into out [cols][rows]
+    if (i >= rows * cols) return;
+    const int c = i / rows, r = i - c * rows;
+    out[i] = in[(long)r * cols + c];
+}
+
 extern "C" int dfd_se_fc_fwd(const float* pooled, const float* w1, const float* b1, const float* w2, const float* b2,
-                             int N, int C, int R, int act, float* hpre, float* gate, dfd_stream stream) {
-    if (!pooled || !w1 || !w2 || !hpre || !gate || N < 1 || C < 1 || R < 1) return DFD_EINVAL;
+                             int N, int C, int R, int act, float* hpre, float* gate, float* w2t, dfd_stream stream) {
+    if (!pooled || !w1 || !w2 || !hpre || !gate || !w2t || N < 1 || C < 1 || R < 1) return DFD_EINVAL;
     if (C > SE_MAX_C || R > SE_MAX_R) return DFD_EUNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
+    // w2 is [C][R]; every use sums over r for many c (or over c for few r): keep an [R][C] copy
+    hipLaunchKernelGGL(k_transpose_f32, dim3((C * R + 255) / 256), dim3(256), 0, st, w2, w2t, C, R);
+    hipLaunchKernelGGL(k_se_hidden, dim3((R + 3) / 4, N), dim3(DFD_THREADS), 0, st, pooled, w1, b1, C, R, hpre);
     DISPATCH_ACT(act, {
-        hipLaunchKernelGGL((k_se_fc_fwd<ACT>), dim3(N), dim3(DFD_THREADS), 0, st, pooled, w1, b1, w2, b2, C, R, hpre, gate);
+        hipLaunchKernelGGL((k_se_gate<ACT>), dim3((C + DFD_THREADS - 1) / DFD_THREADS, N), dim3(DFD_THREADS), 0, st, hpre, w2t,
+                           b2, C, R, gate);
     });
     return DFD_CHECK_LAUNCH();
 }
 
 extern "C" int dfd_se_fc_bwd(const float* dgate, const float* gate, const float* hpre, const float* pooled,
-                             const float* w1, const float* w2, int N, int C, int R, int act, float* dpooled,
+                             const float* w1, const float* w2t, int N, int C, int R, int act, float* dpooled,
                              float* dw1, float* db1, float* dw2, float* db2, int accumulate, float* ws,
                              dfd_stream stream) {
-    if (!dgate || !gate || !hpre || !pooled || !w1 || !w2 || !dpooled || !ws || N < 1 || C < 1 || R < 1) return DFD_EINVAL;
+    if (!dgate || !gate || !hpre || !pooled || !w1 || !w2t || !dpooled || !ws || N < 1 || C < 1 || R < 1) return DFD_EINVAL;
     if (C > SE_MAX_C || R > SE_MAX_R) return DFD_EUNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     DISPATCH_ACT(act, {
-        hipLaunchKernelGGL((k_se_fc_bwd_a<ACT>), dim3(N), dim3(DFD_THREADS), 0, st, dgate, gate, hpre, w1, w2, N, C, R, dpooled, ws);
+        hipLaunchKernelGGL((k_se_bwd_hidden<ACT>), dim3((R + 3) / 4, N), dim3(DFD_THREADS), 0, st, dgate, gate, hpre, w2t, N, C,
+                           R, ws);
     });
+    hipLaunchKernelGGL(k_se_bwd_pooled, dim3((C + DFD_THREADS - 1) / DFD_THREADS, N), dim3(DFD_THREADS), 0, st, ws, w1, N, C, R,
+                       dpooled);
     if (hipGetLastError() != hipSuccess) return DFD_ELAUNCH;
     if (dw1 && dw2) {
         hipLaunchKernelGGL(k_se_fc_bwd_w, dim3((C + 63) / 64, R), dim3(DFD_THREADS), 0, st, pooled, ws, N, C, R, dw1, db1,
@@ -242,26 +283,34 @@ k_stem_fwd(const float* __restrict__ x, const float* __restrict__ w, T* __restri
     }
 }
 
-// weight gradient.  A workgroup stages chunks of 64 output pixels: dy [64][Co] (after
-// the affine map) and the 3*K*K input patch values [64][TAPS]; thread (co, g) owns
-// taps g, g+G, ... ; partial layout [workgroup][Co][TAPS].
-#define STEM_CHUNK 64
-#define STEM_TPT 8
+// weight gradient = a skinny GEMM  dw[co][tap] = sum_pix dy[pix][co] * patch[pix][tap].
+// A workgroup stages chunks of STEM_CHUNK output pixels in LDS: dy [pix][Co] (after the
+// BN-backward affine map) and the 3*K*K input patch [pix][32] (taps padded to 32).  Threads
+// form pixel groups of (Co/4) x 4 lanes; a lane owns a 4(co) x 8(tap) register tile, reads
+// one 16-byte dy vector and two 16-byte patch vectors per pixel (3 LDS reads per 32 FMAs)
+// and keeps its sums in registers over the whole persistent loop.
+// partial layout: [workgroup][Co][TAPS]
+#define STEM_CHUNK 128
+#define STEM_TAPP 32
 template <typename T, int K>
 __global__ void __launch_bounds__(DFD_THREADS)
 k_stem_wgrad(const float* __restrict__ x, const T* __restrict__ dz, const T* __restrict__ yraw,
              const float* __restrict__ coef, dfd_stem_shape s, float* __restrict__ ws) {
     constexpr int V = Vec<T>::N;
     constexpr int TAPS = 3 * K * K;
-    __shared__ float sdy[STEM_CHUNK * STEM_MAX_CO];
-    __shared__ float sx[STEM_CHUNK * TAPS];
+    static_assert(TAPS <= STEM_TAPP, "patch padding");
+    __shared__ __attribute__((aligned(16))) float sdy[STEM_CHUNK * STEM_MAX_CO];
+    __shared__ __attribute__((aligned(16))) float sx[STEM_CHUNK * STEM_TAPP];
     const int t = threadIdx.x, Co = s.Cout;
-    const int G = DFD_THREADS / Co;
-    const int co = t % Co, g = t / Co;
-    const bool on = g < G;
-    float acc[STEM_TPT];
+    const int COG = Co / 4, TPG = COG * 4, NG = DFD_THREADS / TPG;      // lanes per pixel group, groups
+    const int grp = t / TPG, r = t - grp * TPG, cog = r >> 2, tg = r & 3;
+    const bool on = grp < NG;
+    float acc[4][8];
 #pragma unroll
-    for (int i = 0; i < STEM_TPT; ++i) acc[i] = 0.f;
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = 0.f;
+    for (int i = t; i < STEM_CHUNK * STEM_TAPP; i += DFD_THREADS) sx[i] = 0.f;      // pad taps stay zero
     const long npix = (long)s.N * s.Ho * s.Wo;
     const int CV = Co / V;
     for (long base = (long)blockIdx.x * STEM_CHUNK; base < npix; base += (long)gridDim.x * STEM_CHUNK) {
@@ -284,43 +333,69 @@ k_stem_wgrad(const float* __restrict__ x, const T* __restrict__ dz, const T* __r
                     for (int j = 0; j < V; ++j) d[j] = round_to<T>(fmaf(ka[j], d[j], fmaf(kb[j], yv[j], kc[j])));
                 }
             }
-#pragma unroll
-            for (int j = 0; j < V; ++j) sdy[p * Co + v * V + j] = d[j];
+            store_f32<V>(sdy + p * Co + v * V, d);
         }
-        for (int i = t; i < STEM_CHUNK * TAPS; i += DFD_THREADS) {
-            const int p = i / TAPS, tap = i - p * TAPS;
+        for (int i = t; i < STEM_CHUNK * K; i += DFD_THREADS) {          // one (pixel, kernel row) per item
+            const int p = i / K, kh = i - p * K;
             const long pix = base + p;
-            float v = 0.f;
+            float v[3 * K];
+#pragma unroll
+            for (int j = 0; j < 3 * K; ++j) v[j] = 0.f;
             if (pix < npix) {
-                const int ci = tap / (K * K), kk = tap - ci * K * K, kh = kk / K, kw = kk - kh * K;
                 const int ox = (int)(pix % s.Wo);
                 const long tq = pix / s.Wo;
                 const int oy = (int)(tq % s.Ho);
                 const long n = tq / s.Ho;
-                const int iy = oy * s.stride - s.pad_top + kh, ix = ox * s.stride - s.pad_left + kw;
-                if (iy >= 0 && iy < s.H && ix >= 0 && ix < s.W) v = round_to<T>(x[((n * s.H + iy) * (long)s.W + ix) * 3 + ci]);
+                const int iy = oy * s.stride - s.pad_top + kh, ix0 = ox * s.stride - s.pad_left;
+                if (iy >= 0 && iy < s.H) {
+                    const float* row = x + ((n * s.H + iy) * (long)s.W) * 3;
+#pragma unroll
+                    for (int kw = 0; kw < K; ++kw) {
+                        const int ix = ix0 + kw;
+                        if (ix >= 0 && ix < s.W) {
+#pragma unroll
+                            for (int ci = 0; ci < 3; ++ci) v[kw * 3 + ci] = round_to<T>(row[(long)ix * 3 + ci]);
+                        }
+                    }
+                }
             }
-            sx[p * TAPS + tap] = v;
+            // torch's tap order is (ci, kh, kw)
+#pragma unroll
+            for (int kw = 0; kw < K; ++kw)
+#pragma unroll
+                for (int ci = 0; ci < 3; ++ci) sx[p * STEM_TAPP + (ci * K + kh) * K + kw] = v[kw * 3 + ci];
         }
         __syncthreads();
         if (on) {
-            for (int p = 0; p < STEM_CHUNK; ++p) {
-                const float d = sdy[p * Co + co];
+            for (int p = grp; p < STEM_CHUNK; p += NG) {
+                const float4 d = *reinterpret_cast<const float4*>(sdy + p * Co + cog * 4);
+                const float4 xa = *reinterpret_cast<const float4*>(sx + p * STEM_TAPP + tg * 8);
+                const float4 xb = *reinterpret_cast<const float4*>(sx + p * STEM_TAPP + tg * 8 + 4);
+                const float dv[4] = {d.x, d.y, d.z, d.w};
+                const float xv[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
 #pragma unroll
-                for (int i = 0; i < STEM_TPT; ++i) {
-                    const int tap = g + i * G;
-                    if (tap < TAPS) acc[i] = fmaf(d, sx[p * TAPS + tap], acc[i]);
-                }
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[i][j] = fmaf(dv[i], xv[j], acc[i][j]);
             }
         }
     }
+    // combine the pixel groups through LDS (reuse sdy: NG * Co * 32 floats <= chunk buffer)
+    __syncthreads();
+    float* red = sdy;
     if (on) {
-        float* o = ws + (long)blockIdx.x * Co * TAPS;
 #pragma unroll
-        for (int i = 0; i < STEM_TPT; ++i) {
-            const int tap = g + i * G;
-            if (tap < TAPS) o[co * TAPS + tap] = acc[i];
-        }
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) red[(grp * Co + cog * 4 + i) * STEM_TAPP + tg * 8 + j] = acc[i][j];
+    }
+    __syncthreads();
+    float* o = ws + (long)blockIdx.x * Co * TAPS;
+    for (int i = t; i < Co * TAPS; i += DFD_THREADS) {
+        const int co = i / TAPS, tap = i - co * TAPS;
+        float sum = 0.f;
+        for (int gq = 0; gq < NG; ++gq) sum += red[(gq * Co + co) * STEM_TAPP + tap];
+        o[i] = sum;
     }
 }
 
@@ -359,7 +434,7 @@ extern "C" int dfd_stem_conv_fwd(int dtype, const float* x, const float* w, void
 
 static int stem_wgrad_blocks(const dfd_stem_shape* s) {
     const long npix = (long)s->N * s->Ho * s->Wo;
-    long b = (npix + STEM_CHUNK * 8 - 1) / (STEM_CHUNK * 8);
+    long b = (npix + STEM_CHUNK * 4 - 1) / (STEM_CHUNK * 4);
     if (b > 1024) b = 1024;
     if (b < 1) b = 1;
     return (int)b;
@@ -373,7 +448,6 @@ extern "C" int dfd_stem_conv_wgrad(int dtype, const float* x, const void* dz, co
                                    dfd_stream stream) {
     if (!x || !dz || !dw || !ws || (coef && !y)) return DFD_EINVAL;
     if (!stem_ok(s)) return DFD_EINVAL;
-    if (DFD_THREADS / s->Cout < 1 || (27 + DFD_THREADS / s->Cout - 1) / (DFD_THREADS / s->Cout) > STEM_TPT) return DFD_EUNSUPPORTED;
     const int P = stem_wgrad_blocks(s);
     if ((size_t)(P + P / 32 + 2) * s->Cout * 27 * 4 > ws_bytes) return DFD_EWORKSPACE;
     hipStream_t st = (hipStream_t)stream;

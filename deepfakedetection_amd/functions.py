@@ -155,7 +155,7 @@ class MBConvFunction(torch.autograd.Function):
         st2 = _bn_state(parts, n, N * Ho * Wo, cfg.bn_dw, g_dw, b_dw, tr)
         pooled = K.pool_act(y2, st2, ACT_SILU)
         w1, w2 = se_w1.reshape(se_w1.shape[0], -1), se_w2.reshape(se_w2.shape[0], -1)
-        hpre, gate = K.se_fc_fwd(pooled, w1, se_b1, w2, se_b2, ACT_SILU)
+        hpre, gate, w2t = K.se_fc_fwd(pooled, w1, se_b1, w2, se_b2, ACT_SILU)
         wproj_nk, wproj_kn = K.prep_weights(w_proj, dt, True, need_bwd)
         pro = K.pro_bn_act_gate(st2, ACT_SILU, gate, Ho * Wo)
         y3, parts, n = K.pwconv(y2, pro, wproj_nk, None, stats=tr)
@@ -165,14 +165,14 @@ class MBConvFunction(torch.autograd.Function):
         ctx.pptr = _ptrs(x, w_exp, g_exp, b_exp, w_dw, g_dw, b_dw, se_w1, se_b1, se_w2, se_b2, w_proj, g_proj, b_proj)
         ctx.in_shape = (N, H, W, Cin)
         ctx.has_rs = cfg.skip and row_scale is not None
-        ctx.save_for_backward(x, y1, y2, y3, st1, st2, st3, pooled, hpre, gate, wexp_kn, wproj_kn, w_dw, w1, w2,
+        ctx.save_for_backward(x, y1, y2, y3, st1, st2, st3, pooled, hpre, gate, wexp_kn, wproj_kn, w_dw, w1, w2t,
                               g_exp, g_dw, g_proj, row_scale if ctx.has_rs else None)
         return out
 
     @staticmethod
     def backward(ctx, g):
         cfg: MBConvCtx = ctx.cfg
-        (x, y1, y2, y3, st1, st2, st3, pooled, hpre, gate, wexp_kn, wproj_kn, w_dw, w1, w2,
+        (x, y1, y2, y3, st1, st2, st3, pooled, hpre, gate, wexp_kn, wproj_kn, w_dw, w1, w2t,
          g_exp, g_dw, g_proj, row_scale) = ctx.saved_tensors
         need = ctx.needs_input_grad
         tr = cfg.training
@@ -196,7 +196,7 @@ class MBConvFunction(torch.autograd.Function):
         dgate = K.pool_bwd_reduce(D, y2, st2, ACT_SILU)
         want_se = need[7] or need[8] or need[9] or need[10]
         se_outs = (_dest(ctx, 7, (R, Cmid)), _dest(ctx, 8, (R,)), _dest(ctx, 9, (Cmid, R)), _dest(ctx, 10, (Cmid,)))
-        dpooled, dw1, db1, dw2, db2 = K.se_fc_bwd(dgate, gate, hpre, pooled, w1, w2, ACT_SILU, want_se, se_outs)
+        dpooled, dw1, db1, dw2, db2 = K.se_fc_bwd(dgate, gate, hpre, pooled, w1, w2t, ACT_SILU, want_se, se_outs)
         if dw1 is not None:
             dw1, dw2 = dw1.view(dw1.shape[0], -1, 1, 1), dw2.view(dw2.shape[0], -1, 1, 1)
         # ---- SiLU' and depthwise BN backward

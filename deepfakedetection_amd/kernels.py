@@ -184,12 +184,14 @@ def se_fc_fwd(pooled: torch.Tensor, w1, b1, w2, b2, act: int):
     R = w1.shape[0]
     hpre = torch.empty((N, R), dtype=torch.float32, device=pooled.device)
     gate = torch.empty((N, C), dtype=torch.float32, device=pooled.device)
-    check(_L().dfd_se_fc_fwd(_p(pooled), _p(w1), _p(b1), _p(w2), _p(b2), N, C, R, act, _p(hpre), _p(gate), _stream()),
-          "dfd_se_fc_fwd", f"C={C} R={R}")
-    return hpre, gate
+    w2t = torch.empty((R, C), dtype=torch.float32, device=pooled.device)
+    check(_L().dfd_se_fc_fwd(_p(pooled), _p(w1), _p(b1), _p(w2), _p(b2), N, C, R, act, _p(hpre), _p(gate), _p(w2t),
+                             _stream()), "dfd_se_fc_fwd", f"C={C} R={R}")
+    return hpre, gate, w2t
 
 
-def se_fc_bwd(dgate, gate, hpre, pooled, w1, w2, act: int, want_param_grads: bool = True, outs=(None, None, None, None)):
+def se_fc_bwd(dgate, gate, hpre, pooled, w1, w2t, act: int, want_param_grads: bool = True, outs=(None, None, None, None)):
+    """w2t: the [R, C] transpose returned by se_fc_fwd."""
     N, C = pooled.shape
     R = w1.shape[0]
     dev = pooled.device
@@ -202,7 +204,7 @@ def se_fc_bwd(dgate, gate, hpre, pooled, w1, w2, act: int, want_param_grads: boo
         db2 = _dst(outs[3], (C,), dev)
     else:
         dw1 = db1 = dw2 = db2 = None
-    check(_L().dfd_se_fc_bwd(_p(dgate), _p(gate), _p(hpre), _p(pooled), _p(w1), _p(w2), N, C, R, act, _p(dpooled),
+    check(_L().dfd_se_fc_bwd(_p(dgate), _p(gate), _p(hpre), _p(pooled), _p(w1), _p(w2t), N, C, R, act, _p(dpooled),
                              _p(dw1), _p(db1), _p(dw2), _p(db2), 0, _p(ws), _stream()), "dfd_se_fc_bwd")
     return dpooled, dw1, db1, dw2, db2
 

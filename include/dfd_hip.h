@@ -112,12 +112,14 @@ int dfd_scale_rows(int dtype, const void* x, const float* row_scale, void* out,
 /* ------------------------------------------------------------ squeeze-excite ---
  * MBConvBlock._se_reduce/_se_expand (efficientnet_pytorch), SqueezeExcite (timm):
  * gate = sigmoid(W2 * act(W1*pooled + b1) + b2).                                 */
+/* w2 is torch's [C][R]; w2t [R][C] is written by the forward (coalesced reads) and is
+ * what the backward takes. */
 int dfd_se_fc_fwd(const float* pooled, const float* w1, const float* b1, const float* w2,
                   const float* b2, int N, int C, int R, int act, float* hpre, float* gate,
-                  dfd_stream stream);
+                  float* w2t, dfd_stream stream);
 /* ws: float[N*C + 2*N*R] scratch; R <= 128, C <= 4096 */
 int dfd_se_fc_bwd(const float* dgate, const float* gate, const float* hpre,
-                  const float* pooled, const float* w1, const float* w2,
+                  const float* pooled, const float* w1, const float* w2t,
                   int N, int C, int R, int act, float* dpooled,
                   float* dw1, float* db1, float* dw2, float* db2, int accumulate,
                   float* ws, dfd_stream stream);

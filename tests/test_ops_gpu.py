@@ -299,11 +299,12 @@ def test_se_fc(case):
     hpre, gate = R.se_fc(pr, w1, b1, w2, b2, R.ACT_SILU)
     dgate = torch.randn((N, C), generator=g)
     gate.backward(dgate)
-    h2, g2 = K.se_fc_fwd(dev(pooled), dev(w1.detach()), dev(b1.detach()), dev(w2.detach()), dev(b2.detach()), R.ACT_SILU)
+    h2, g2, w2t = K.se_fc_fwd(dev(pooled), dev(w1.detach()), dev(b1.detach()), dev(w2.detach()), dev(b2.detach()), R.ACT_SILU)
+    close(w2t, w2.detach().t(), 0.0, "se w2t")
     close(h2, hpre, 1e-4, "se hpre")
     close(g2, gate, 1e-4, "se gate")
     # the kernel takes d(loss)/d(gate) and applies sigmoid' itself
-    dp, dw1, db1, dw2, db2 = K.se_fc_bwd(dev(dgate), g2, h2, dev(pooled), dev(w1.detach()), dev(w2.detach()), R.ACT_SILU)
+    dp, dw1, db1, dw2, db2 = K.se_fc_bwd(dev(dgate), g2, h2, dev(pooled), dev(w1.detach()), w2t, R.ACT_SILU)
     close(dp, pr.grad, 2e-4, "se dpooled")
     close(dw1, w1.grad, 2e-4, "se dw1")
     close(db1, b1.grad, 2e-4, "se db1")
