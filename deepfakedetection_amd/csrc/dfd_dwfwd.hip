@@ -14,92 +14,7 @@
 //   * the workgroup walks (image, tile) work items persistently as before: one partial
 //     (sum, sumsq) row per workgroup, BN + SiLU of the producer applied once per staged
 //     element, zero padding written in the activated domain.
-#include "dfd_common.h"
-
-typedef float f2 __attribute__((ext_vector_type(2)));
-
-struct DwQGeom {
-    int N, H, W, C, Ho, Wo, pt, pl;
-    int CV, cvb_log2;
-    int TH, QW, NQ;            // tile = TH rows x QW quads (4*QW columns), NQ = TH*QW
-    unsigned qw_magic;         // q / QW == (q * qw_magic) >> 20
-    int tiles_y, tiles_x, nwork;
-    int IH, IW;
-    unsigned iw_magic;
-};
-
-template <typename T> struct V2 { static constexpr int N = Vec<T>::N / 2; };
-
-__device__ __forceinline__ void unpack2(const uint4& q, f2 (&v)[4]) {       // 8 x bf16
-    v[0] = (f2){__uint_as_float(q.x << 16), __uint_as_float(q.x & 0xffff0000u)};
-    v[1] = (f2){__uint_as_float(q.y << 16), __uint_as_float(q.y & 0xffff0000u)};
-    v[2] = (f2){__uint_as_float(q.z << 16), __uint_as_float(q.z & 0xffff0000u)};
-    v[3] = (f2){__uint_as_float(q.w << 16), __uint_as_float(q.w & 0xffff0000u)};
-}
-__device__ __forceinline__ void unpack2(const uint4& q, f2 (&v)[2]) {       // 4 x f32
-    v[0] = (f2){__uint_as_float(q.x), __uint_as_float(q.y)};
-    v[1] = (f2){__uint_as_float(q.z), __uint_as_float(q.w)};
-}
-__device__ __forceinline__ uint4 pack2(const f2 (&v)[4]) {
-    return make_uint4(pack_bf2(v[0].x, v[0].y), pack_bf2(v[1].x, v[1].y), pack_bf2(v[2].x, v[2].y), pack_bf2(v[3].x, v[3].y));
-}
-__device__ __forceinline__ uint4 pack2(const f2 (&v)[2]) {
-    return make_uint4(__float_as_uint(v[0].x), __float_as_uint(v[0].y), __float_as_uint(v[1].x), __float_as_uint(v[1].y));
-}
-template <typename T> __device__ __forceinline__ f2 round2(f2 v) {
-    if constexpr (sizeof(T) == 2) return (f2){bf2f(f2bf(v.x)), bf2f(f2bf(v.y))};
-    else return v;
-}
-
-// stage the input tile: tile[pix][vl] = rnd(act(scale*x+shift)) or x, zero outside the image
-template <typename T, int ACT, bool PRO>
-__device__ __forceinline__ void stage_q(uint4* __restrict__ tile, const T* __restrict__ src, const f2 (&sc)[V2<T>::N],
-                                        const f2 (&sh)[V2<T>::N], long img_base, int SH, int SW, int C, int c0, bool cvalid,
-                                        int gy0, int gx0, int IH, int IW, unsigned magic, int cvb_log2) {
-    constexpr int N2 = V2<T>::N;
-    const int total = (IH * IW) << cvb_log2;
-    for (int base = threadIdx.x; base < total; base += DFD_THREADS * 4) {
-        uint4 raw[4];
-        bool inb[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int idx = base + u * DFD_THREADS;
-            const int pix = idx >> cvb_log2;
-            const int iy = (int)(((unsigned)pix * magic) >> 20);
-            const int ix = pix - iy * IW;
-            const int gy = gy0 + iy, gx = gx0 + ix;
-            inb[u] = cvalid && idx < total && (unsigned)gy < (unsigned)SH && (unsigned)gx < (unsigned)SW;
-            if (inb[u]) raw[u] = *reinterpret_cast<const uint4*>(src + img_base + ((long)gy * SW + gx) * C + c0);
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int idx = base + u * DFD_THREADS;
-            if (idx >= total) continue;
-            uint4 q = make_uint4(0, 0, 0, 0);
-            if (inb[u]) {
-                if constexpr (!PRO) {
-                    q = raw[u];
-                } else {
-                    f2 v[N2];
-                    unpack2(raw[u], v);
-#pragma unroll
-                    for (int j = 0; j < N2; ++j) {
-                        const f2 z = __builtin_elementwise_fma(sc[j], v[j], sh[j]);
-                        if constexpr (ACT == DFD_ACT_SILU) {
-                            const f2 e = (f2){__expf(-z.x), __expf(-z.y)};
-                            const f2 d = e + (f2){1.f, 1.f};
-                            v[j] = z * (f2){__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
-                        } else {
-                            v[j] = (f2){act_fwd<ACT>(z.x), act_fwd<ACT>(z.y)};
-                        }
-                    }
-                    q = pack2(v);
-                }
-            }
-            tile[idx] = q;
-        }
-    }
-}
+#include "dfd_dwq.h"
 
 template <typename T, int K, int S, int ACT, bool PRO, bool STATS>
 __global__ void __launch_bounds__(DFD_THREADS, 4)
@@ -163,29 +78,20 @@ k_dw_fwd_q(const T* __restrict__ x, const float* __restrict__ bnstate, const flo
 #pragma unroll
                     for (int j = 0; j < N2; ++j)
                         wv[kw][j] = *reinterpret_cast<const f2*>(wl + ((kh * K + kw) * cvb + vl) * V + 2 * j);
-                if constexpr (S == 1) {
-                    f2 xv[K + 3][N2];
+                // walk the INPUT columns of the quad's window: one vector is unpacked at a time and
+                // feeds every (output, tap) pair it belongs to (keeps the live set at acc + weights)
+                constexpr int NCOL = 3 * S + K;
 #pragma unroll
-                    for (int c = 0; c < K + 3; ++c) unpack2(row[c << g.cvb_log2], xv[c]);
+                for (int c = 0; c < NCOL; ++c) {
+                    f2 xc[N2];
+                    unpack2(row[c << g.cvb_log2], xc);
 #pragma unroll
-                    for (int kw = 0; kw < K; ++kw)
+                    for (int o = 0; o < 4; ++o) {
+                        const int kw = c - S * o;
+                        if (kw >= 0 && kw < K) {
 #pragma unroll
-                        for (int o = 0; o < 4; ++o)
-#pragma unroll
-                            for (int j = 0; j < N2; ++j) acc[o][j] = __builtin_elementwise_fma(xv[o + kw][j], wv[kw][j], acc[o][j]);
-                } else {
-#pragma unroll
-                    for (int half = 0; half < 2; ++half) {
-                        f2 xv[K + 2][N2];
-#pragma unroll
-                        for (int c = 0; c < K + 2; ++c) unpack2(row[(4 * half + c) << g.cvb_log2], xv[c]);
-#pragma unroll
-                        for (int kw = 0; kw < K; ++kw)
-#pragma unroll
-                            for (int o = 0; o < 2; ++o)
-#pragma unroll
-                                for (int j = 0; j < N2; ++j)
-                                    acc[2 * half + o][j] = __builtin_elementwise_fma(xv[2 * o + kw][j], wv[kw][j], acc[2 * half + o][j]);
+                            for (int j = 0; j < N2; ++j) acc[o][j] = __builtin_elementwise_fma(xc[j], wv[kw][j], acc[o][j]);
+                        }
                     }
                 }
             }
@@ -229,7 +135,8 @@ k_dw_fwd_q(const T* __restrict__ x, const float* __restrict__ bnstate, const flo
 // ---------------------------------------------------------------------------
 static int ilog2p(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 
-bool dfd_dwq_geom(const dfd_dwconv_shape* s, int vec, int max_cvb, DwQGeom* g, int* tile_bytes) {
+bool dfd_dwq_geom(const dfd_dwconv_shape* s, int vec, int max_cvb, bool centre_is_input, size_t extra_lds,
+                  int extra_centre, int lane_div, DwQGeom* g, int* tile_bytes) {
     if (!s || s->N <= 0 || s->H <= 0 || s->W <= 0 || s->Ho <= 0 || s->Wo <= 0 || s->C <= 0 || s->C % 8) return false;
     if (!(s->k == 3 || s->k == 5) || !(s->stride == 1 || s->stride == 2)) return false;
     if (s->pad_top < 0 || s->pad_left < 0 || s->pad_top >= s->k || s->pad_left >= s->k) return false;
@@ -244,19 +151,26 @@ bool dfd_dwq_geom(const dfd_dwconv_shape* s, int vec, int max_cvb, DwQGeom* g, i
     if (g->CV < 4) best = g->CV >= 2 ? 2 : 1;
     g->cvb_log2 = ilog2p(best);
     const int cvb = best, PL = DFD_THREADS / cvb, K = s->k, S = s->stride;
-    const int maxQW = (s->Wo + 3) / 4;
+    // centre grid: outputs (forward) or inputs (data gradient); the staged tile is the other side
+    const int CH = centre_is_input ? s->H : s->Ho, CW = centre_is_input ? s->W : s->Wo;
+    auto ext = [&](int centre) {            // staged extent along one axis for `centre` centre pixels
+        if (!centre_is_input) return (centre - 1) * S + K;
+        return S == 1 ? centre + K - 1 : (centre + K - 2) / 2 + 2;
+    };
+    const int maxQW = (CW + 3) / 4;
     double best_cost = 1e300;
     int bTH = 1, bQW = 1;
     for (int QW = 1; QW <= maxQW; ++QW) {
-        const int TW = 4 * QW, IW = (TW - 1) * S + K;
-        for (int TH = 1; TH <= s->Ho && TH <= 64; ++TH) {
-            const int IH = (TH - 1) * S + K;
+        const int TW = 4 * QW, IW = ext(TW);
+        for (int TH = 1; TH <= CH && TH <= 64; ++TH) {
+            const int IH = ext(TH);
             const long px = (long)IH * IW;
             if (px >= 4096) break;
-            const long lds = px * cvb * 16;
+            const long lds = px * cvb * 16 + (long)extra_lds + (long)TH * TW * cvb * extra_centre;
             if (lds > 36 * 1024 && !(TH == 1 && QW == 1)) break;
-            const long tiles = (long)((s->Ho + TH - 1) / TH) * ((s->Wo + TW - 1) / TW);
-            const long rounds = ((long)TH * QW + PL - 1) / PL;
+            const long tiles = (long)((CH + TH - 1) / TH) * ((CW + TW - 1) / TW);
+            const long lanes = PL / lane_div > 0 ? PL / lane_div : 1;      // lanes that share the quads of a tile
+            const long rounds = ((long)TH * QW + lanes - 1) / lanes;
             const double stage = (double)((px * cvb + DFD_THREADS - 1) / DFD_THREADS) * 120.0;
             const double quad = 4.0 * K * K * (vec / 2) + (double)K * (K + 3) * (vec / 2) * 2 + 80.0;
             const double cost = (double)tiles * (stage + rounds * quad + 250.0);
@@ -265,37 +179,22 @@ bool dfd_dwq_geom(const dfd_dwconv_shape* s, int vec, int max_cvb, DwQGeom* g, i
     }
     g->TH = bTH; g->QW = bQW; g->NQ = bTH * bQW;
     g->qw_magic = ((1u << 20) + bQW - 1) / bQW;
-    g->IH = (bTH - 1) * S + K; g->IW = (4 * bQW - 1) * S + K;
+    g->IH = ext(bTH); g->IW = ext(4 * bQW);
     if ((long)g->IH * g->IW >= 4096 || g->NQ >= 4096) return false;
     g->iw_magic = ((1u << 20) + g->IW - 1) / g->IW;
-    g->tiles_y = (s->Ho + bTH - 1) / bTH;
-    g->tiles_x = (s->Wo + 4 * bQW - 1) / (4 * bQW);
+    g->tiles_y = (CH + bTH - 1) / bTH;
+    g->tiles_x = (CW + 4 * bQW - 1) / (4 * bQW);
     g->nwork = s->N * g->tiles_y * g->tiles_x;
     *tile_bytes = g->IH * g->IW * cvb * 16;
     return true;
 }
-
-#define DISPATCH_KS(KV, SV, ...)                                                        \
-    if (KV == 3 && SV == 1) { constexpr int K = 3, S = 1; __VA_ARGS__; }                \
-    else if (KV == 3 && SV == 2) { constexpr int K = 3, S = 2; __VA_ARGS__; }           \
-    else if (KV == 5 && SV == 1) { constexpr int K = 5, S = 1; __VA_ARGS__; }           \
-    else if (KV == 5 && SV == 2) { constexpr int K = 5, S = 2; __VA_ARGS__; }           \
-    else return DFD_EUNSUPPORTED;
-#define DISPATCH_ACT_DW(ACTV, ...)                                                   \
-    switch (ACTV) {                                                                  \
-        case DFD_ACT_NONE: { constexpr int ACT = DFD_ACT_NONE; __VA_ARGS__; } break; \
-        case DFD_ACT_SILU: { constexpr int ACT = DFD_ACT_SILU; __VA_ARGS__; } break; \
-        case DFD_ACT_RELU: { constexpr int ACT = DFD_ACT_RELU; __VA_ARGS__; } break; \
-        case DFD_ACT_GELU: { constexpr int ACT = DFD_ACT_GELU; __VA_ARGS__; } break; \
-        default: return DFD_EUNSUPPORTED;                                            \
-    }
 
 template <typename T>
 static int dw_fwd_q_t(const void* x, const float* in_bnstate, int in_act, const float* w, void* y,
                       const dfd_dwconv_shape* s, float* partials, int pcap, int* nparts, hipStream_t st) {
     constexpr int V = Vec<T>::N;
     DwQGeom g; int tile_bytes;
-    if (!dfd_dwq_geom(s, V, 16, &g, &tile_bytes)) return DFD_EINVAL;
+    if (!dfd_dwq_geom(s, V, 16, false, 0, 0, 1, &g, &tile_bytes)) return DFD_EINVAL;
     const int cvb = 1 << g.cvb_log2, nchunks = (g.CV + cvb - 1) / cvb;
     const bool stats = partials != nullptr;
     int cap = stats ? (pcap < DFD_MAX_PARTIALS ? pcap : DFD_MAX_PARTIALS) : DFD_MAX_PARTIALS;

@@ -1,0 +1,112 @@
+// dfd_dwq.h — shared pieces of the quad-based depthwise kernels (forward, data gradient).
+#pragma once
+#include "dfd_common.h"
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+struct DwQGeom {
+    int N, H, W, C, Ho, Wo, pt, pl;
+    int CV, cvb_log2;
+    int TH, QW, NQ;            // tile = TH rows x QW quads (4*QW columns), NQ = TH*QW
+    unsigned qw_magic;         // q / QW == (q * qw_magic) >> 20
+    int tiles_y, tiles_x, nwork;
+    int IH, IW;
+    unsigned iw_magic;
+};
+
+template <typename T> struct V2 { static constexpr int N = Vec<T>::N / 2; };
+
+__device__ __forceinline__ void unpack2(const uint4& q, f2 (&v)[4]) {       // 8 x bf16
+    v[0] = (f2){__uint_as_float(q.x << 16), __uint_as_float(q.x & 0xffff0000u)};
+    v[1] = (f2){__uint_as_float(q.y << 16), __uint_as_float(q.y & 0xffff0000u)};
+    v[2] = (f2){__uint_as_float(q.z << 16), __uint_as_float(q.z & 0xffff0000u)};
+    v[3] = (f2){__uint_as_float(q.w << 16), __uint_as_float(q.w & 0xffff0000u)};
+}
+__device__ __forceinline__ void unpack2(const uint4& q, f2 (&v)[2]) {       // 4 x f32
+    v[0] = (f2){__uint_as_float(q.x), __uint_as_float(q.y)};
+    v[1] = (f2){__uint_as_float(q.z), __uint_as_float(q.w)};
+}
+__device__ __forceinline__ uint4 pack2(const f2 (&v)[4]) {
+    return make_uint4(pack_bf2(v[0].x, v[0].y), pack_bf2(v[1].x, v[1].y), pack_bf2(v[2].x, v[2].y), pack_bf2(v[3].x, v[3].y));
+}
+__device__ __forceinline__ uint4 pack2(const f2 (&v)[2]) {
+    return make_uint4(__float_as_uint(v[0].x), __float_as_uint(v[0].y), __float_as_uint(v[1].x), __float_as_uint(v[1].y));
+}
+template <typename T> __device__ __forceinline__ f2 round2(f2 v) {
+    if constexpr (sizeof(T) == 2) return (f2){bf2f(f2bf(v.x)), bf2f(f2bf(v.y))};
+    else return v;
+}
+
+
+// tile geometry chosen by a small cost model; centre_is_input selects the data-gradient form
+// extra_lds: fixed bytes; extra_centre: bytes per centre pixel per channel vector (second tile);
+// lane_div: pixel lanes are shared by this many roles (weight gradient: K kernel rows)
+bool dfd_dwq_geom(const dfd_dwconv_shape* s, int vec, int max_cvb, bool centre_is_input, size_t extra_lds,
+                  int extra_centre, int lane_div, DwQGeom* g, int* tile_bytes);
+
+// stage the input tile: tile[pix][vl] = rnd(act(scale*x+shift)) or x, zero outside the image
+template <typename T, int ACT, bool PRO>
+__device__ __forceinline__ void stage_q(uint4* __restrict__ tile, const T* __restrict__ src, const f2 (&sc)[V2<T>::N],
+                                        const f2 (&sh)[V2<T>::N], long img_base, int SH, int SW, int C, int c0, bool cvalid,
+                                        int gy0, int gx0, int IH, int IW, unsigned magic, int cvb_log2) {
+    constexpr int N2 = V2<T>::N;
+    const int total = (IH * IW) << cvb_log2;
+    for (int base = threadIdx.x; base < total; base += DFD_THREADS * 4) {
+        uint4 raw[4];
+        bool inb[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int idx = base + u * DFD_THREADS;
+            const int pix = idx >> cvb_log2;
+            const int iy = (int)(((unsigned)pix * magic) >> 20);
+            const int ix = pix - iy * IW;
+            const int gy = gy0 + iy, gx = gx0 + ix;
+            inb[u] = cvalid && idx < total && (unsigned)gy < (unsigned)SH && (unsigned)gx < (unsigned)SW;
+            if (inb[u]) raw[u] = *reinterpret_cast<const uint4*>(src + img_base + ((long)gy * SW + gx) * C + c0);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int idx = base + u * DFD_THREADS;
+            if (idx >= total) continue;
+            uint4 q = make_uint4(0, 0, 0, 0);
+            if (inb[u]) {
+                if constexpr (!PRO) {
+                    q = raw[u];
+                } else {
+                    f2 v[N2];
+                    unpack2(raw[u], v);
+#pragma unroll
+                    for (int j = 0; j < N2; ++j) {
+                        const f2 z = __builtin_elementwise_fma(sc[j], v[j], sh[j]);
+                        if constexpr (ACT == DFD_ACT_SILU) {
+                            const f2 e = (f2){__expf(-z.x), __expf(-z.y)};
+                            const f2 d = e + (f2){1.f, 1.f};
+                            v[j] = z * (f2){__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+                        } else {
+                            v[j] = (f2){act_fwd<ACT>(z.x), act_fwd<ACT>(z.y)};
+                        }
+                    }
+                    q = pack2(v);
+                }
+            }
+            tile[idx] = q;
+        }
+    }
+}
+
+
+
+#define DISPATCH_KS(KV, SV, ...)                                                        \
+    if (KV == 3 && SV == 1) { constexpr int K = 3, S = 1; __VA_ARGS__; }                \
+    else if (KV == 3 && SV == 2) { constexpr int K = 3, S = 2; __VA_ARGS__; }           \
+    else if (KV == 5 && SV == 1) { constexpr int K = 5, S = 1; __VA_ARGS__; }           \
+    else if (KV == 5 && SV == 2) { constexpr int K = 5, S = 2; __VA_ARGS__; }           \
+    else return DFD_EUNSUPPORTED;
+#define DISPATCH_ACT_DW(ACTV, ...)                                                   \
+    switch (ACTV) {                                                                  \
+        case DFD_ACT_NONE: { constexpr int ACT = DFD_ACT_NONE; __VA_ARGS__; } break; \
+        case DFD_ACT_SILU: { constexpr int ACT = DFD_ACT_SILU; __VA_ARGS__; } break; \
+        case DFD_ACT_RELU: { constexpr int ACT = DFD_ACT_RELU; __VA_ARGS__; } break; \
+        case DFD_ACT_GELU: { constexpr int ACT = DFD_ACT_GELU; __VA_ARGS__; } break; \
+        default: return DFD_EUNSUPPORTED;                                            \
+    }
