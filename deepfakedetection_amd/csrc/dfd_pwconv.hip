@@ -18,6 +18,7 @@
 //   * workgroups are persistent over M tiles: per-channel (sum, sumsq) stay in
 //     registers and leave as ONE partial row per workgroup (reproducible reductions).
 #include "dfd_common.h"
+#include <type_traits>
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(4))) short short4_t;
@@ -291,7 +292,7 @@ __device__ __forceinline__ int tn_off_bf16(int m, int ch) {
 #define TN_F32_ROW 576  // (128 + 16) floats: kq rows land on disjoint bank halves
 
 template <typename T, int PROP, int PROQ, int ACT>
-__global__ void __launch_bounds__(DFD_THREADS)
+__global__ void __launch_bounds__(DFD_THREADS, 2)
 k_pw_tn(const T* __restrict__ p, ProArgs pp, int Ni, const T* __restrict__ q, ProArgs pq, int Nj, int M,
         int i_tiles, int j_tiles, int rows_per_split, float* __restrict__ ws) {
     constexpr int E = El<T>::EPC;
@@ -313,10 +314,30 @@ k_pw_tn(const T* __restrict__ p, ProArgs pp, int Ni, const T* __restrict__ q, Pr
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wi = wave >> 1, wj = wave & 1;
-    const int sc = t % CPRW, sr = t / CPRW;
-    const int ci = i0 + sc * E, cj = j0 + sc * E;   // this thread's channel chunk in p / q
     const T* p2 = reinterpret_cast<const T*>(pp.a2);
-    const T* q2 = reinterpret_cast<const T*>(pq.a2);
+
+    // Staging work is spread over the VALID 16-byte chunks only (channel counts of 16..48 are
+    // common: with a fixed chunk-column per lane most lanes would idle through the prologue).
+    // Items are numbered P rows first, then Q rows, so at most one wave mixes the two prologues.
+    int cp = (Ni - i0 + E - 1) / E; if (cp > CPRW) cp = CPRW;
+    int cq = (Nj - j0 + E - 1) / E; if (cq > CPRW) cq = CPRW;
+    // per operand: item i of this lane is flat index t + 256*i over (row, valid chunk)
+    constexpr int MAXI = (BMK * CPRW) / DFD_THREADS;           // 4
+    int mp_[MAXI], mq_[MAXI];                                  // row | chunk << 8 | ok << 16
+#pragma unroll
+    for (int i = 0; i < MAXI; ++i) {
+        const int idx = t + DFD_THREADS * i;
+        const bool okp = idx < BMK * cp, okq = idx < BMK * cq;
+        const int rp_ = okp ? idx / cp : 0, rq_ = okq ? idx / cq : 0;
+        mp_[i] = rp_ | ((okp ? idx - rp_ * cp : 0) << 8) | ((int)okp << 16);
+        mq_[i] = rq_ | ((okq ? idx - rq_ * cq : 0) << 8) | ((int)okq << 16);
+    }
+    // chunks beyond cp / cq are never written: clear the tiles once so partly valid 16-wide MFMA
+    // tiles read zeros there
+    if (cp < CPRW || cq < CPRW) {
+        for (int i = t; i < 4 * TILE / 16; i += DFD_THREADS) reinterpret_cast<uint4*>(smem)[i] = make_uint4(0, 0, 0, 0);
+        __syncthreads();
+    }
 
     f32x4_t acc[4][4];
 #pragma unroll
@@ -324,50 +345,53 @@ k_pw_tn(const T* __restrict__ p, ProArgs pp, int Ni, const T* __restrict__ q, Pr
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
-    uint4 rp[NPASS], rp2[NPASS], rq[NPASS], rq2[NPASS];
+    uint4 rp[MAXI], rp2[MAXI], rq[MAXI];
     auto g_load = [&](int mb) {
 #pragma unroll
-        for (int i = 0; i < NPASS; ++i) {
-            const int m = mb + sr + RPP * i;
+        for (int i = 0; i < MAXI; ++i) {
             rp[i] = make_uint4(0, 0, 0, 0); rq[i] = make_uint4(0, 0, 0, 0);
             if (PROP == DFD_PRO_AFFINE2) rp2[i] = make_uint4(0, 0, 0, 0);
-            if (PROQ == DFD_PRO_AFFINE2) rq2[i] = make_uint4(0, 0, 0, 0);
-            if (m < mend) {
-                if (ci < Ni) {
-                    rp[i] = *reinterpret_cast<const uint4*>(p + (long)m * Ni + ci);
-                    if constexpr (PROP == DFD_PRO_AFFINE2) rp2[i] = *reinterpret_cast<const uint4*>(p2 + (long)m * Ni + ci);
-                }
-                if (cj < Nj) {
-                    rq[i] = *reinterpret_cast<const uint4*>(q + (long)m * Nj + cj);
-                    if constexpr (PROQ == DFD_PRO_AFFINE2) rq2[i] = *reinterpret_cast<const uint4*>(q2 + (long)m * Nj + cj);
-                }
+            const int a_ = mp_[i], b_ = mq_[i];
+            const int ma = mb + (a_ & 255), mbq = mb + (b_ & 255);
+            if ((a_ >> 16) && ma < mend) {
+                const long off = (long)ma * Ni + i0 + ((a_ >> 8) & 255) * E;
+                rp[i] = *reinterpret_cast<const uint4*>(p + off);
+                if constexpr (PROP == DFD_PRO_AFFINE2) rp2[i] = *reinterpret_cast<const uint4*>(p2 + off);
             }
+            if ((b_ >> 16) && mbq < mend)
+                rq[i] = *reinterpret_cast<const uint4*>(q + (long)mbq * Nj + j0 + ((b_ >> 8) & 255) * E);
         }
     };
     auto s_store = [&](int mb, int buf) {
         unsigned char* pb_ = smem + buf * 2 * TILE;
         unsigned char* qb_ = pb_ + TILE;
 #pragma unroll
-        for (int i = 0; i < NPASS; ++i) {
-            const int r = sr + RPP * i, m = mb + r;
-            uint4 vp = rp[i], vq = rq[i];
-            if (m < mend) {
-                if (PROP != DFD_PRO_NONE && ci < Ni) vp = apply_pro<T, PROP, DFD_ACT_NONE>(rp[i], rp2[i], pp.coef, nullptr, ci, Ni);
-                if (PROQ != DFD_PRO_NONE && cj < Nj) {
+        for (int i = 0; i < MAXI; ++i) {
+            const int a_ = mp_[i], b_ = mq_[i];
+            if (a_ >> 16) {
+                const int r = a_ & 255, chk = (a_ >> 8) & 255;
+                uint4 v = rp[i];
+                if (PROP != DFD_PRO_NONE && mb + r < mend)
+                    v = apply_pro<T, PROP, DFD_ACT_NONE>(rp[i], rp2[i], pp.coef, nullptr, i0 + chk * E, Ni);
+                if constexpr (sizeof(T) == 2) *reinterpret_cast<uint4*>(pb_ + tn_off_bf16(r, chk)) = v;
+                else *reinterpret_cast<uint4*>(pb_ + r * ROWB + chk * 16) = v;
+            }
+            if (b_ >> 16) {
+                const int r = b_ & 255, chk = (b_ >> 8) & 255, m = mb + r;
+                uint4 v = rq[i];
+                if (PROQ != DFD_PRO_NONE && m < mend) {
                     const float* grow = nullptr;
                     if constexpr (PROQ == DFD_PRO_BN_ACT_GATE) grow = pq.gate + (long)(m / pq.HW) * Nj;
-                    vq = apply_pro<T, PROQ, ACT>(rq[i], rq2[i], pq.coef, grow, cj, Nj);
+                    v = apply_pro<T, PROQ, ACT>(rq[i], rq[i], pq.coef, grow, j0 + chk * E, Nj);
                 }
-            }
-            if constexpr (sizeof(T) == 2) {
-                *reinterpret_cast<uint4*>(pb_ + tn_off_bf16(r, sc)) = vp;
-                *reinterpret_cast<uint4*>(qb_ + tn_off_bf16(r, sc)) = vq;
-            } else {
-                *reinterpret_cast<uint4*>(pb_ + r * ROWB + sc * 16) = vp;
-                *reinterpret_cast<uint4*>(qb_ + r * ROWB + sc * 16) = vq;
+                if constexpr (sizeof(T) == 2) *reinterpret_cast<uint4*>(qb_ + tn_off_bf16(r, chk)) = v;
+                else *reinterpret_cast<uint4*>(qb_ + r * ROWB + chk * 16) = v;
             }
         }
     };
+    // 16-wide MFMA tiles of this wave that hold any valid channel
+    int na = (Ni - i0 - wi * 64 + 15) / 16; na = na < 0 ? 0 : (na > 4 ? 4 : na);
+    int nb = (Nj - j0 - wj * 64 + 15) / 16; nb = nb < 0 ? 0 : (nb > 4 ? 4 : nb);
 
     const int nsteps = (mend > mbeg) ? (mend - mbeg + BMK - 1) / BMK : 0;
     if (nsteps > 0) {
@@ -384,33 +408,39 @@ k_pw_tn(const T* __restrict__ p, ProArgs pp, int Ni, const T* __restrict__ q, Pr
             // two k-substeps of 32 rows; fragment = 8 consecutive m for one channel:
             // two transposed 4x16 block reads per operand tile
             const int g = lane >> 4, li = lane & 15, qrow = li >> 2, pcol = li & 3;
+            auto mfma_step = [&](auto full_tag) {
+                constexpr bool FULL = decltype(full_tag)::value;
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                short8_t fa[4], fb[4];
+                for (int ks = 0; ks < 2; ++ks) {
+                    short8_t fa[4], fb[4];
 #pragma unroll
-                for (int x = 0; x < 4; ++x) {
-                    const int chA = ((wi * 64 + x * 16) >> 3) + (pcol >> 1);
-                    const int chB = ((wj * 64 + x * 16) >> 3) + (pcol >> 1);
-                    const int m_lo = ks * 32 + 8 * g + qrow, m_hi = m_lo + 4;
-                    const int sub = (pcol & 1) << 3;
-                    short4_t a_lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                        (__attribute__((address_space(3))) short4_t*)(pb_ + tn_off_bf16(m_lo, chA) + sub));
-                    short4_t a_hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                        (__attribute__((address_space(3))) short4_t*)(pb_ + tn_off_bf16(m_hi, chA) + sub));
-                    short4_t b_lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                        (__attribute__((address_space(3))) short4_t*)(qb_ + tn_off_bf16(m_lo, chB) + sub));
-                    short4_t b_hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                        (__attribute__((address_space(3))) short4_t*)(qb_ + tn_off_bf16(m_hi, chB) + sub));
-                    fa[x] = (short8_t){a_lo[0], a_lo[1], a_lo[2], a_lo[3], a_hi[0], a_hi[1], a_hi[2], a_hi[3]};
-                    fb[x] = (short8_t){b_lo[0], b_lo[1], b_lo[2], b_lo[3], b_hi[0], b_hi[1], b_hi[2], b_hi[3]};
+                    for (int x = 0; x < 4; ++x) {
+                        if (!FULL && x >= na && x >= nb) continue;
+                        const int chA = ((wi * 64 + x * 16) >> 3) + (pcol >> 1);
+                        const int chB = ((wj * 64 + x * 16) >> 3) + (pcol >> 1);
+                        const int m_lo = ks * 32 + 8 * g + qrow, m_hi = m_lo + 4;
+                        const int sub = (pcol & 1) << 3;
+                        short4_t a_lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                            (__attribute__((address_space(3))) short4_t*)(pb_ + tn_off_bf16(m_lo, chA) + sub));
+                        short4_t a_hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                            (__attribute__((address_space(3))) short4_t*)(pb_ + tn_off_bf16(m_hi, chA) + sub));
+                        short4_t b_lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                            (__attribute__((address_space(3))) short4_t*)(qb_ + tn_off_bf16(m_lo, chB) + sub));
+                        short4_t b_hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                            (__attribute__((address_space(3))) short4_t*)(qb_ + tn_off_bf16(m_hi, chB) + sub));
+                        fa[x] = (short8_t){a_lo[0], a_lo[1], a_lo[2], a_lo[3], a_hi[0], a_hi[1], a_hi[2], a_hi[3]};
+                        fb[x] = (short8_t){b_lo[0], b_lo[1], b_lo[2], b_lo[3], b_hi[0], b_hi[1], b_hi[2], b_hi[3]};
+                    }
+#pragma unroll
+                    for (int a = 0; a < 4; ++a)
+#pragma unroll
+                        for (int b = 0; b < 4; ++b)
+                            if (FULL || (a < na && b < nb))
+                                acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, fa[a]),
+                                                                                  __builtin_bit_cast(bf16x8_t, fb[b]), acc[a][b], 0, 0, 0);
                 }
-#pragma unroll
-                for (int a = 0; a < 4; ++a)
-#pragma unroll
-                    for (int b = 0; b < 4; ++b)
-                        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, fa[a]),
-                                                                          __builtin_bit_cast(bf16x8_t, fb[b]), acc[a][b], 0, 0, 0);
-            }
+            };
+            if (na == 4 && nb == 4) mfma_step(std::true_type{}); else mfma_step(std::false_type{});
         } else {
             const int col = lane & 15, kq = lane >> 4;
 #pragma unroll
@@ -426,7 +456,7 @@ k_pw_tn(const T* __restrict__ p, ProArgs pp, int Ni, const T* __restrict__ q, Pr
                 for (int a = 0; a < 4; ++a)
 #pragma unroll
                     for (int b = 0; b < 4; ++b)
-                        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[a], fb[b], acc[a][b], 0, 0, 0);
+                        if (a < na && b < nb) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[a], fb[b], acc[a][b], 0, 0, 0);
             }
         }
         if (st + 1 < nsteps) s_store(mbeg + (st + 1) * BMK, buf ^ 1);
