@@ -84,6 +84,17 @@ __device__ __forceinline__ uint4 apply_pro(uint4 q, uint4 q2, const float* __res
 // ===========================================================================
 // NT kernel
 // ===========================================================================
+// LDS layout of the NT kernel: A double buffer at 0, then (past the epilogue overlay, so a
+// resident weight tile survives it) the B double buffer.
+template <typename T, int BN> struct NtLds {
+    static constexpr int A_BYTES = PW_BM * 128;
+    static constexpr int B_BYTES = BN * 128;
+    static constexpr int OROW = BN * (int)sizeof(T) + 16;                   // epilogue row stride
+    static constexpr int OBYTES = PW_BM * OROW;
+    static constexpr int BOFF = ((2 * A_BYTES > OBYTES ? 2 * A_BYTES : OBYTES) + 15) / 16 * 16;
+    static constexpr int TOTAL = BOFF + 2 * B_BYTES;
+};
+
 template <typename T, int BN, int PRO, int ACT, bool RES, bool STATS>
 __global__ void __launch_bounds__(DFD_THREADS)
 k_pw_nt(const T* __restrict__ a, ProArgs pa, const T* __restrict__ w, T* __restrict__ out, const T* __restrict__ res,
@@ -91,10 +102,8 @@ k_pw_nt(const T* __restrict__ a, ProArgs pa, const T* __restrict__ w, T* __restr
     constexpr int E = El<T>::EPC;
     constexpr int BK = El<T>::BK;
     constexpr int NTW = BN / 32;            // 16-wide n tiles per wave
-    constexpr int A_BYTES = PW_BM * 128;
-    constexpr int B_BYTES = BN * 128;
-    constexpr int STAGE = A_BYTES + B_BYTES;
-    constexpr int OROW = BN * (int)sizeof(T) + 16;   // epilogue row stride in bytes
+    using L = NtLds<T, BN>;
+    constexpr int OROW = L::OROW;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     // XCD-aware remap: workgroups that share an M tile (different n tiles) sit on one XCD
@@ -109,7 +118,6 @@ k_pw_nt(const T* __restrict__ a, ProArgs pa, const T* __restrict__ w, T* __restr
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int sc = t & 7, sr = t >> 3;      // staging: chunk column, first row
     const int frow = lane & 15, fk = lane >> 4;
 
     // epilogue mapping
@@ -121,66 +129,95 @@ k_pw_nt(const T* __restrict__ a, ProArgs pa, const T* __restrict__ w, T* __restr
     for (int j = 0; j < E; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
 
     const int nk = (K + BK - 1) / BK;
+    const bool b_resident = nk == 1;        // the whole weight tile fits one K step: stage it once
     const T* a2 = reinterpret_cast<const T*>(pa.a2);
+    if (pb >= m_tiles) return;
 
-    for (int mt = pb; mt < m_tiles; mt += gx) {
-        const int m0 = mt * PW_BM;
-        f32x4_t acc[NTW][4];
-#pragma unroll
-        for (int i = 0; i < NTW; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    // staging geometry of a K tile: kc valid 16-byte chunks, kc4 = chunks an MFMA sub-step may
+    // read (written as zeros beyond kc); work is spread over rows x kc4 chunks
+    auto tile_kc = [&](int kt, int& kc, int& kc4, unsigned& magic) {
+        int rem = (K - kt * BK + E - 1) / E;
+        kc = rem > 8 ? 8 : rem;
+        kc4 = (kc + 3) & ~3;
+        magic = (65536u + kc4 - 1) / kc4;
+    };
 
-        uint4 ra[4], ra2[4], rb[BN / 32];
-        auto g_load = [&](int kt) {
-            const int k = kt * BK + sc * E;
+    uint4 ra[4], ra2[4], rb[BN / 32];
+    auto g_load = [&](int mt, int kt, bool with_b) {
+        int kc, kc4; unsigned magic;
+        tile_kc(kt, kc, kc4, magic);
+        const int m0 = mt * PW_BM, k0 = kt * BK;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int m = m0 + sr + 32 * i;
-                ra[i] = make_uint4(0, 0, 0, 0);
-                if (PRO == DFD_PRO_AFFINE2) ra2[i] = make_uint4(0, 0, 0, 0);
-                if (m < M && k < K) {
-                    ra[i] = *reinterpret_cast<const uint4*>(a + (long)m * K + k);
-                    if constexpr (PRO == DFD_PRO_AFFINE2) ra2[i] = *reinterpret_cast<const uint4*>(a2 + (long)m * K + k);
-                }
+        for (int i = 0; i < 4; ++i) {
+            const int idx = t + DFD_THREADS * i;
+            const int r = (int)(((unsigned)idx * magic) >> 16), c = idx - r * kc4;
+            ra[i] = make_uint4(0, 0, 0, 0);
+            if (PRO == DFD_PRO_AFFINE2) ra2[i] = make_uint4(0, 0, 0, 0);
+            if (r < PW_BM && c < kc && m0 + r < M) {
+                const long off = (long)(m0 + r) * K + k0 + c * E;
+                ra[i] = *reinterpret_cast<const uint4*>(a + off);
+                if constexpr (PRO == DFD_PRO_AFFINE2) ra2[i] = *reinterpret_cast<const uint4*>(a2 + off);
             }
+        }
+        if (with_b) {
 #pragma unroll
             for (int i = 0; i < BN / 32; ++i) {
-                const int n = n0 + sr + 32 * i;
-                rb[i] = (n < Nout && k < K) ? *reinterpret_cast<const uint4*>(w + (long)n * K + k) : make_uint4(0, 0, 0, 0);
+                const int idx = t + DFD_THREADS * i;
+                const int r = (int)(((unsigned)idx * magic) >> 16), c = idx - r * kc4;
+                rb[i] = (r < BN && c < kc && n0 + r < Nout) ? *reinterpret_cast<const uint4*>(w + (long)(n0 + r) * K + k0 + c * E)
+                                                           : make_uint4(0, 0, 0, 0);
             }
-        };
-        auto s_store = [&](int kt, int buf) {
-            unsigned char* ab = smem + buf * STAGE;
-            unsigned char* bb = ab + A_BYTES;
-            const int k = kt * BK + sc * E;
+        }
+    };
+    auto s_store = [&](int mt, int kt, int buf, bool with_b) {
+        int kc, kc4; unsigned magic;
+        tile_kc(kt, kc, kc4, magic);
+        unsigned char* ab = smem + buf * L::A_BYTES;
+        unsigned char* bb = smem + L::BOFF + buf * L::B_BYTES;
+        const int m0 = mt * PW_BM, k0 = kt * BK;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int r = sr + 32 * i, m = m0 + r;
-                uint4 q = ra[i];
-                if (PRO != DFD_PRO_NONE && m < M && k < K) {
-                    const float* grow = nullptr;
-                    if constexpr (PRO == DFD_PRO_BN_ACT_GATE) grow = pa.gate + (long)(m / pa.HW) * K;
-                    q = apply_pro<T, PRO, ACT>(ra[i], ra2[i], pa.coef, grow, k, K);
-                }
-                *reinterpret_cast<uint4*>(ab + r * 128 + ((sc ^ (r & 7)) << 4)) = q;
+        for (int i = 0; i < 4; ++i) {
+            const int idx = t + DFD_THREADS * i;
+            const int r = (int)(((unsigned)idx * magic) >> 16), c = idx - r * kc4;
+            if (r >= PW_BM) continue;
+            uint4 q = ra[i];
+            if (PRO != DFD_PRO_NONE && c < kc && m0 + r < M) {
+                const float* grow = nullptr;
+                if constexpr (PRO == DFD_PRO_BN_ACT_GATE) grow = pa.gate + (long)((m0 + r) / pa.HW) * K;
+                q = apply_pro<T, PRO, ACT>(ra[i], ra2[i], pa.coef, grow, k0 + c * E, K);
             }
+            *reinterpret_cast<uint4*>(ab + r * 128 + ((c ^ (r & 7)) << 4)) = q;
+        }
+        if (with_b) {
 #pragma unroll
             for (int i = 0; i < BN / 32; ++i) {
-                const int r = sr + 32 * i;
-                *reinterpret_cast<uint4*>(bb + r * 128 + ((sc ^ (r & 7)) << 4)) = rb[i];
+                const int idx = t + DFD_THREADS * i;
+                const int r = (int)(((unsigned)idx * magic) >> 16), c = idx - r * kc4;
+                if (r < BN) *reinterpret_cast<uint4*>(bb + r * 128 + ((c ^ (r & 7)) << 4)) = rb[i];
             }
-        };
+        }
+    };
 
-        __syncthreads();   // previous tile's epilogue reads are done
-        g_load(0);
-        s_store(0, 0);
-        __syncthreads();
-        for (int kt = 0; kt < nk; ++kt) {
-            const int buf = kt & 1;
-            if (kt + 1 < nk) g_load(kt + 1);
-            const unsigned char* ab = smem + buf * STAGE;
-            const unsigned char* bb = ab + A_BYTES;
+    // flat software pipeline over (M tile, K tile): the global loads of the next stage (possibly
+    // the next M tile) are in flight while the current stage's MFMAs and epilogue run
+    int mt = pb, kt = 0, buf = 0;
+    g_load(mt, 0, true);
+    s_store(mt, 0, 0, true);
+    __syncthreads();
+    f32x4_t acc[NTW][4];
+#pragma unroll
+    for (int i = 0; i < NTW; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    for (;;) {
+        int nmt = mt, nkt = kt + 1;
+        if (nkt == nk) { nkt = 0; nmt = mt + gx; }
+        const bool has_next = nmt < m_tiles;
+        const bool next_b = !b_resident;
+        if (has_next) g_load(nmt, nkt, next_b);
+        {
+            const unsigned char* ab = smem + buf * L::A_BYTES;
+            const unsigned char* bb = smem + L::BOFF + (b_resident ? 0 : buf) * L::B_BYTES;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 const int klim = kt * BK + ks * (BK / 2);
@@ -215,49 +252,62 @@ k_pw_nt(const T* __restrict__ a, ProArgs pa, const T* __restrict__ w, T* __restr
                         }
                 }
             }
-            if (kt + 1 < nk) s_store(kt + 1, buf ^ 1);
+        }
+        if (kt == nk - 1) {
+            // ---- tile done: accumulators -> LDS overlay [m][n] -> 16-byte row-major stores
+            const int m0 = mt * PW_BM;
+            __syncthreads();            // every wave is done reading the A buffers the overlay covers
+#pragma unroll
+            for (int i = 0; i < NTW; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int m = wm * 64 + j * 16 + frow;
+                    const int n = wn * (BN / 2) + i * 16 + fk * 4;
+                    unsigned char* p = smem + m * OROW + n * (int)sizeof(T);
+                    if constexpr (sizeof(T) == 2) {
+                        uint2 q;
+                        q.x = pack_bf2(acc[i][j][0], acc[i][j][1]);
+                        q.y = pack_bf2(acc[i][j][2], acc[i][j][3]);
+                        *reinterpret_cast<uint2*>(p) = q;
+                    } else {
+                        *reinterpret_cast<float4*>(p) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+                    }
+                    acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+                }
             __syncthreads();
-        }
-        // ---- epilogue: accumulators -> LDS [m][n] -> 16-byte row-major stores
-        // acc[i][j][r]: n = wn*BN/2 + i*16 + fk*4 + r ; m = wm*64 + j*16 + frow
-#pragma unroll
-        for (int i = 0; i < NTW; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int m = wm * 64 + j * 16 + frow;
-                const int n = wn * (BN / 2) + i * 16 + fk * 4;
-                unsigned char* p = smem + m * OROW + n * (int)sizeof(T);
-                if constexpr (sizeof(T) == 2) {
-                    uint2 q;
-                    q.x = pack_bf2(acc[i][j][0], acc[i][j][1]);
-                    q.y = pack_bf2(acc[i][j][2], acc[i][j][3]);
-                    *reinterpret_cast<uint2*>(p) = q;
-                } else {
-                    *reinterpret_cast<float4*>(p) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
-                }
-            }
-        __syncthreads();
-        const int n = n0 + ec * E;
-        if (n < Nout) {
+            const int n = n0 + ec * E;
+            if (n < Nout) {
 #pragma unroll 4
-            for (int r = er; r < PW_BM; r += RL) {
-                const int m = m0 + r;
-                if (m >= M) break;
-                float v[E];
-                q_to_f(*reinterpret_cast<const uint4*>(smem + r * OROW + ec * 16), v);
-                if constexpr (RES) {
-                    float q[E];
-                    Vec<T>::load(res + (long)m * Nout + n, q);
+                for (int r = er; r < PW_BM; r += RL) {
+                    const int m = m0 + r;
+                    if (m >= M) break;
+                    float v[E];
+                    q_to_f(*reinterpret_cast<const uint4*>(smem + r * OROW + ec * 16), v);
+                    if constexpr (RES) {
+                        float q[E];
+                        Vec<T>::load(res + (long)m * Nout + n, q);
 #pragma unroll
-                    for (int j = 0; j < E; ++j) v[j] = round_to<T>(v[j] + q[j]);
-                }
-                if constexpr (STATS) {
+                        for (int j = 0; j < E; ++j) v[j] = round_to<T>(v[j] + q[j]);
+                    }
+                    if constexpr (STATS) {
 #pragma unroll
-                    for (int j = 0; j < E; ++j) { s1[j] += v[j]; s2[j] = fmaf(v[j], v[j], s2[j]); }
+                        for (int j = 0; j < E; ++j) { s1[j] += v[j]; s2[j] = fmaf(v[j], v[j], s2[j]); }
+                    }
+                    Vec<T>::store(out + (long)m * Nout + n, v);
                 }
-                Vec<T>::store(out + (long)m * Nout + n, v);
             }
+            __syncthreads();            // overlay reads done before the next stage lands in the A buffers
         }
+        if (!has_next) break;
+        // the next stage goes to the other A buffer; its B tile (if not resident) likewise
+        const int nbuf = (kt == nk - 1) ? 0 : (buf ^ 1);
+        if (kt != nk - 1 && nk > 1) {
+            // within a tile the other buffer may still be read by slower waves of the PREVIOUS stage:
+            // the barrier at the end of that stage already ordered it
+        }
+        s_store(nmt, nkt, nbuf, next_b);
+        __syncthreads();
+        mt = nmt; kt = nkt; buf = nbuf;
     }
     if constexpr (STATS) {
         __syncthreads();
@@ -545,11 +595,8 @@ static int pw_nt_launch(const void* a, const dfd_prologue* pro, const void* w, v
     if (gx > cap) gx = cap;
     if (gx > m_tiles) gx = m_tiles;
     if (partials) *nparts = gx;
-    constexpr int STAGE = PW_BM * 128 + BN * 128;
-    constexpr int OBYTES = PW_BM * (BN * (int)sizeof(T) + 16);
     constexpr int RED = DFD_THREADS * 2 * El<T>::EPC * 4;
-    int lds = 2 * STAGE;
-    if (lds < OBYTES) lds = OBYTES;
+    int lds = NtLds<T, BN>::TOTAL;
     if (lds < RED) lds = RED;
     const ProArgs pa = pro_args(pro);
     const int mode = pro ? pro->mode : DFD_PRO_NONE;
