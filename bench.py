@@ -170,7 +170,7 @@ def main() -> None:
 
     # ---- live per-kernel measurement (eager, HIP events on the compute stream)
     roofline, breakdown = None, []
-    if rank == 0:
+    if rank == 0 and args.profile_steps > 0:
         sink: list = []
         step_body()
         torch.cuda.synchronize()
