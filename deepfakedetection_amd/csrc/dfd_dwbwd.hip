@@ -299,21 +299,14 @@ k_dw_bwd_weight_q(const T* __restrict__ dz, const T* __restrict__ yraw, const fl
     const int kh = lane % K, prl = lane / K;
     const bool lane_on = prl < NPR;
 
-    for (int i = t; i < 3 * cvbV; i += DFD_THREADS) {
+    for (int i = t; i < 5 * cvbV; i += DFD_THREADS) {          // ka, kb, kc, scale, shift
         const int which = i / cvbV, cc = i - which * cvbV, c = chunk_c0 + cc;
-        float v = which == 0 ? 1.f : 0.f;
-        if (COEF && c < g.C) v = coef[which * g.C + c];
-        cf[i] = v;
-    }
-    f2 sc[N2], sh[N2];
-#pragma unroll
-    for (int j = 0; j < N2; ++j) { sc[j] = (f2){1.f, 1.f}; sh[j] = (f2){0.f, 0.f}; }
-    if (PRO && cvalid) {
-#pragma unroll
-        for (int j = 0; j < N2; ++j) {
-            sc[j] = *reinterpret_cast<const f2*>(in_bnstate + c0 + 2 * j);
-            sh[j] = *reinterpret_cast<const f2*>(in_bnstate + g.C + c0 + 2 * j);
+        float v = (which == 0 || which == 3) ? 1.f : 0.f;
+        if (c < g.C) {
+            if (which < 3) { if (COEF) v = coef[which * g.C + c]; }
+            else if (PRO) v = in_bnstate[(which - 3) * g.C + c];
         }
+        cf[i] = v;
     }
     f2 accw[K][N2];
 #pragma unroll
@@ -328,8 +321,16 @@ k_dw_bwd_weight_q(const T* __restrict__ dz, const T* __restrict__ yraw, const fl
         const int ty = tr / g.tiles_x, tx = tr - ty * g.tiles_x;
         const int oy0 = ty * g.TH, ox0 = tx * TW;
         __syncthreads();
-        stage_q<T, ACT, PRO>(tile, xin, sc, sh, (long)n * g.H * g.W * g.C, g.H, g.W, g.C, c0, cvalid, oy0 * S - g.pt,
-                             ox0 * S - g.pl, g.IH, g.IW, g.iw_magic, g.cvb_log2);
+        {
+            f2 sc[N2], sh[N2];                       // short-lived: the coefficients live in LDS
+#pragma unroll
+            for (int j = 0; j < N2; ++j) {
+                sc[j] = *reinterpret_cast<const f2*>(cf + 3 * cvbV + vl * V + 2 * j);
+                sh[j] = *reinterpret_cast<const f2*>(cf + 4 * cvbV + vl * V + 2 * j);
+            }
+            stage_q<T, ACT, PRO>(tile, xin, sc, sh, (long)n * g.H * g.W * g.C, g.H, g.W, g.C, c0, cvalid, oy0 * S - g.pt,
+                                 ox0 * S - g.pl, g.IH, g.IW, g.iw_magic, g.cvb_log2);
+        }
         stage_dy<T, COEF>(dyt, dz, yraw, cf, cvbV, vl, (long)n * g.Ho * g.Wo * g.C, g.Ho, g.Wo, g.C, c0, cvalid, oy0, ox0,
                           g.TH, TW, tw_magic, g.cvb_log2);
         __syncthreads();
@@ -387,7 +388,7 @@ k_dw_bwd_weight_q(const T* __restrict__ dz, const T* __restrict__ yraw, const fl
 
 static bool dw_wgrad_q_geom(const dfd_dwconv_shape* s, int vec, DwQGeom* g, int* tile_bytes) {
     const int max_cvb = (s && s->k == 5) ? 8 : 16;          // needs 256/cvb >= K lanes per run
-    return dfd_dwq_geom(s, vec, max_cvb, false, (size_t)3 * 16 * vec * 4, 16, s ? s->k : 1, g, tile_bytes);
+    return dfd_dwq_geom(s, vec, max_cvb, false, (size_t)5 * 16 * vec * 4, 16, s ? s->k : 1, g, tile_bytes);
 }
 
 static int dw_wgrad_q_parts(const DwQGeom& g, int k, int nchunks) {
@@ -419,7 +420,7 @@ static int dw_bwd_weight_q_t(const void* dz, const void* y, const float* coef, c
     const int cvb = 1 << g.cvb_log2, nchunks = (g.CV + cvb - 1) / cvb, KK = s->k * s->k;
     const int P = dw_wgrad_q_parts(g, s->k, nchunks);
     if ((size_t)(P + P / 32 + 2) * g.C * KK * 4 > ws_bytes) return DFD_EWORKSPACE;
-    size_t lds = (size_t)tile_bytes + (size_t)g.TH * 4 * g.QW * cvb * 16 + (size_t)3 * cvb * V * 4;
+    size_t lds = (size_t)tile_bytes + (size_t)g.TH * 4 * g.QW * cvb * 16 + (size_t)5 * cvb * V * 4;
     const size_t red = (size_t)((DFD_THREADS / cvb) / s->k) * KK * cvb * V * 4;
     if (lds < red) lds = red;
     dim3 grid(nchunks, P);

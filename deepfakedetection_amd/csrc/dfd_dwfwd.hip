@@ -35,15 +35,10 @@ k_dw_fwd_q(const T* __restrict__ x, const float* __restrict__ bnstate, const flo
         const int c = blockIdx.x * cvb * V + cc;
         wl[i] = c < g.C ? round_to<T>(w[(long)c * K * K + tap]) : 0.f;
     }
-    f2 sc[N2], sh[N2];
-#pragma unroll
-    for (int j = 0; j < N2; ++j) { sc[j] = (f2){1.f, 1.f}; sh[j] = (f2){0.f, 0.f}; }
-    if (PRO && cvalid) {
-#pragma unroll
-        for (int j = 0; j < N2; ++j) {
-            sc[j] = *reinterpret_cast<const f2*>(bnstate + c0 + 2 * j);
-            sh[j] = *reinterpret_cast<const f2*>(bnstate + g.C + c0 + 2 * j);
-        }
+    float* cf = wl + K * K * cvb * V;                              // scale, shift : [2][cvb*V]
+    for (int i = t; i < 2 * cvb * V; i += DFD_THREADS) {
+        const int which = i / (cvb * V), cc = i - which * (cvb * V), c = blockIdx.x * cvb * V + cc;
+        cf[i] = (PRO && c < g.C) ? bnstate[which * g.C + c] : (which == 0 ? 1.f : 0.f);
     }
     f2 s1[N2], s2[N2];
 #pragma unroll
@@ -55,8 +50,16 @@ k_dw_fwd_q(const T* __restrict__ x, const float* __restrict__ bnstate, const flo
         const int ty = tr / g.tiles_x, tx = tr - ty * g.tiles_x;
         const int oy0 = ty * g.TH, ox0 = tx * TW;
         __syncthreads();
-        stage_q<T, ACT, PRO>(tile, x, sc, sh, (long)n * g.H * g.W * g.C, g.H, g.W, g.C, c0, cvalid, oy0 * S - g.pt,
-                             ox0 * S - g.pl, g.IH, g.IW, g.iw_magic, g.cvb_log2);
+        {
+            f2 sc[N2], sh[N2];                       // short-lived: the coefficients live in LDS
+#pragma unroll
+            for (int j = 0; j < N2; ++j) {
+                sc[j] = *reinterpret_cast<const f2*>(cf + vl * V + 2 * j);
+                sh[j] = *reinterpret_cast<const f2*>(cf + cvb * V + vl * V + 2 * j);
+            }
+            stage_q<T, ACT, PRO>(tile, x, sc, sh, (long)n * g.H * g.W * g.C, g.H, g.W, g.C, c0, cvalid, oy0 * S - g.pt,
+                                 ox0 * S - g.pl, g.IH, g.IW, g.iw_magic, g.cvb_log2);
+        }
         __syncthreads();
         if (!cvalid) continue;
 #pragma unroll 1
@@ -194,7 +197,7 @@ static int dw_fwd_q_t(const void* x, const float* in_bnstate, int in_act, const 
                       const dfd_dwconv_shape* s, float* partials, int pcap, int* nparts, hipStream_t st) {
     constexpr int V = Vec<T>::N;
     DwQGeom g; int tile_bytes;
-    if (!dfd_dwq_geom(s, V, 16, false, 0, 0, 1, &g, &tile_bytes)) return DFD_EINVAL;
+    if (!dfd_dwq_geom(s, V, 16, false, (size_t)(s ? s->k * s->k + 2 : 0) * 16 * V * 4, 0, 1, &g, &tile_bytes)) return DFD_EINVAL;
     const int cvb = 1 << g.cvb_log2, nchunks = (g.CV + cvb - 1) / cvb;
     const bool stats = partials != nullptr;
     int cap = stats ? (pcap < DFD_MAX_PARTIALS ? pcap : DFD_MAX_PARTIALS) : DFD_MAX_PARTIALS;
@@ -203,7 +206,7 @@ static int dw_fwd_q_t(const void* x, const float* in_bnstate, int in_act, const 
     if (gy > cap) gy = cap;
     if (gy > g.nwork) gy = g.nwork;
     if (stats) *nparts = gy;
-    size_t lds = (size_t)tile_bytes + (size_t)s->k * s->k * cvb * V * 4;
+    size_t lds = (size_t)tile_bytes + (size_t)(s->k * s->k + 2) * cvb * V * 4;
     const size_t red = (size_t)DFD_THREADS * 2 * V * 4;
     if (lds < red) lds = red;
     dim3 grid(nchunks, gy);
