@@ -131,6 +131,14 @@ k_dw_bwd_data_q(const T* __restrict__ dz, const T* __restrict__ yraw, const floa
             for (int o = 0; o < 4; ++o)
 #pragma unroll
                 for (int j = 0; j < N2; ++j) acc[o][j] = (f2){0.f, 0.f};
+            // the epilogue's xin vectors are requested now so that HBM latency hides under the taps
+            const long off = (((long)n * g.H + h) * g.W + wq) * g.C + c0;
+            uint4 xr[4];
+            if constexpr (EPI) {
+#pragma unroll
+                for (int o = 0; o < 4; ++o)
+                    xr[o] = (wq + o < g.W) ? *reinterpret_cast<const uint4*>(xin + off + (long)o * g.C) : make_uint4(0, 0, 0, 0);
+            }
 #pragma unroll 1
             for (int kh = 0; kh < K; ++kh) {
                 int r;
@@ -164,13 +172,12 @@ k_dw_bwd_data_q(const T* __restrict__ dz, const T* __restrict__ yraw, const floa
                     }
                 }
             }
-            const long off = (((long)n * g.H + h) * g.W + wq) * g.C + c0;
 #pragma unroll
             for (int o = 0; o < 4; ++o) {
                 if (wq + o < g.W) {
                     if constexpr (EPI) {
                         f2 xv[N2];
-                        unpack2(*reinterpret_cast<const uint4*>(xin + off + (long)o * g.C), xv);
+                        unpack2(xr[o], xv);
 #pragma unroll
                         for (int j = 0; j < N2; ++j) {
                             const f2 sc = *reinterpret_cast<const f2*>(cf + 3 * cvbV + vl * V + 2 * j);
