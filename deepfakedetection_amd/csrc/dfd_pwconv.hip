@@ -32,7 +32,12 @@ struct ProArgs {
     const float* coef;
     const float* gate;
     int HW;
+    unsigned hw_magic;      // row -> image: umulhi(m, hw_magic) >> hw_shift  (hw_shift < 0: HW == 1)
+    int hw_shift;
 };
+__device__ __forceinline__ int pro_image(const ProArgs& pa, int m) {
+    return pa.hw_shift < 0 ? m : (int)(__umulhi((unsigned)m, pa.hw_magic) >> pa.hw_shift);
+}
 
 template <typename T> struct El;
 template <> struct El<bf16> { static constexpr int EPC = 8; static constexpr int BK = 64; };   // elements per 16-B chunk, K tile
@@ -81,6 +86,34 @@ __device__ __forceinline__ uint4 apply_pro(uint4 q, uint4 q2, const float* __res
     }
 }
 
+// same with the per-channel coefficient vectors already in registers
+template <typename T, int PRO, int ACT, int E>
+__device__ __forceinline__ uint4 apply_pro_c(uint4 q, uint4 q2, const float (&c0)[E], const float (&c1)[E], const float (&c2)[E],
+                                             const float* __restrict__ gate_k) {
+    if constexpr (PRO == DFD_PRO_NONE) {
+        return q;
+    } else {
+        float v[E];
+        q_to_f(q, v);
+        if constexpr (PRO == DFD_PRO_AFFINE2) {
+            float v2[E];
+            q_to_f(q2, v2);
+#pragma unroll
+            for (int j = 0; j < E; ++j) v[j] = fmaf(c0[j], v[j], fmaf(c1[j], v2[j], c2[j]));
+        } else {
+#pragma unroll
+            for (int j = 0; j < E; ++j) v[j] = act_fwd<ACT>(fmaf(c0[j], v[j], c1[j]));
+            if constexpr (PRO == DFD_PRO_BN_ACT_GATE) {
+                float gt[E];
+                load_f32<E>(gate_k, gt);
+#pragma unroll
+                for (int j = 0; j < E; ++j) v[j] = round_to<T>(v[j]) * gt[j];
+            }
+        }
+        return f_to_q(v);
+    }
+}
+
 // ===========================================================================
 // NT kernel
 // ===========================================================================
@@ -96,7 +129,7 @@ template <typename T, int BN> struct NtLds {
 };
 
 template <typename T, int BN, int PRO, int ACT, bool RES, bool STATS>
-__global__ void __launch_bounds__(DFD_THREADS)
+__global__ void __launch_bounds__(DFD_THREADS, 2)
 k_pw_nt(const T* __restrict__ a, ProArgs pa, const T* __restrict__ w, T* __restrict__ out, const T* __restrict__ res,
         int M, int K, int Nout, int m_tiles, int n_tiles, int gx, float* __restrict__ partials) {
     constexpr int E = El<T>::EPC;
@@ -133,181 +166,206 @@ k_pw_nt(const T* __restrict__ a, ProArgs pa, const T* __restrict__ w, T* __restr
     const T* a2 = reinterpret_cast<const T*>(pa.a2);
     if (pb >= m_tiles) return;
 
-    // staging geometry of a K tile: kc valid 16-byte chunks, kc4 = chunks an MFMA sub-step may
-    // read (written as zeros beyond kc); work is spread over rows x kc4 chunks
-    auto tile_kc = [&](int kt, int& kc, int& kc4, unsigned& magic) {
+    // staging geometry of a K tile: kc valid 16-byte chunks, kc4 (4 or 8) = chunks an MFMA sub-step
+    // may read (written as zeros beyond kc).  A thread keeps ONE chunk column c per stage and walks
+    // rows r = t / kc4 + i * (256 / kc4), so its per-channel coefficients are loaded once per stage.
+    auto tile_kc = [&](int kt, int& kc, int& sh) {
         int rem = (K - kt * BK + E - 1) / E;
         kc = rem > 8 ? 8 : rem;
-        kc4 = (kc + 3) & ~3;
-        magic = (65536u + kc4 - 1) / kc4;
+        sh = kc > 4 ? 3 : 2;
     };
 
-    uint4 ra[4], ra2[4], rb[BN / 32];
-    auto g_load = [&](int mt, int kt, bool with_b) {
-        int kc, kc4; unsigned magic;
-        tile_kc(kt, kc, kc4, magic);
+    // two register sets: the loads of stage s+2 are issued while stage s computes and stage s+1
+    // waits in the other set for its turn through the prologue into LDS
+    struct Regs { uint4 a[4], a2[4], b[BN / 32]; };
+    Regs R0, R1;
+    auto g_load = [&](Regs& R, int mt, int kt, bool with_b) {
+        int kc, sh;
+        tile_kc(kt, kc, sh);
+        const int c = t & ((1 << sh) - 1), rb0 = t >> sh, rstep = DFD_THREADS >> sh;
         const int m0 = mt * PW_BM, k0 = kt * BK;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int idx = t + DFD_THREADS * i;
-            const int r = (int)(((unsigned)idx * magic) >> 16), c = idx - r * kc4;
-            ra[i] = make_uint4(0, 0, 0, 0);
-            if (PRO == DFD_PRO_AFFINE2) ra2[i] = make_uint4(0, 0, 0, 0);
+            const int r = rb0 + i * rstep;
+            R.a[i] = make_uint4(0, 0, 0, 0);
+            if (PRO == DFD_PRO_AFFINE2) R.a2[i] = make_uint4(0, 0, 0, 0);
             if (r < PW_BM && c < kc && m0 + r < M) {
                 const long off = (long)(m0 + r) * K + k0 + c * E;
-                ra[i] = *reinterpret_cast<const uint4*>(a + off);
-                if constexpr (PRO == DFD_PRO_AFFINE2) ra2[i] = *reinterpret_cast<const uint4*>(a2 + off);
+                R.a[i] = *reinterpret_cast<const uint4*>(a + off);
+                if constexpr (PRO == DFD_PRO_AFFINE2) R.a2[i] = *reinterpret_cast<const uint4*>(a2 + off);
             }
         }
         if (with_b) {
 #pragma unroll
             for (int i = 0; i < BN / 32; ++i) {
-                const int idx = t + DFD_THREADS * i;
-                const int r = (int)(((unsigned)idx * magic) >> 16), c = idx - r * kc4;
-                rb[i] = (r < BN && c < kc && n0 + r < Nout) ? *reinterpret_cast<const uint4*>(w + (long)(n0 + r) * K + k0 + c * E)
+                const int r = rb0 + i * rstep;
+                R.b[i] = (r < BN && c < kc && n0 + r < Nout) ? *reinterpret_cast<const uint4*>(w + (long)(n0 + r) * K + k0 + c * E)
                                                            : make_uint4(0, 0, 0, 0);
             }
         }
     };
-    auto s_store = [&](int mt, int kt, int buf, bool with_b) {
-        int kc, kc4; unsigned magic;
-        tile_kc(kt, kc, kc4, magic);
+    // per-channel prologue coefficients of the stage that is stored next
+    float c0[E], c1[E], c2[E];
+    auto c_load = [&](int kt) {
+        if constexpr (PRO != DFD_PRO_NONE) {
+            int kc, sh;
+            tile_kc(kt, kc, sh);
+            const int c = t & ((1 << sh) - 1);
+            const int k = c < kc ? kt * BK + c * E : 0;
+            load_f32<E>(pa.coef + k, c0);
+            load_f32<E>(pa.coef + K + k, c1);
+            if constexpr (PRO == DFD_PRO_AFFINE2) load_f32<E>(pa.coef + 2 * K + k, c2);
+        }
+    };
+    auto s_store = [&](const Regs& R, int mt, int kt, int buf, bool with_b) {
+        int kc, sh;
+        tile_kc(kt, kc, sh);
+        const int c = t & ((1 << sh) - 1), rb0 = t >> sh, rstep = DFD_THREADS >> sh;
         unsigned char* ab = smem + buf * L::A_BYTES;
         unsigned char* bb = smem + L::BOFF + buf * L::B_BYTES;
         const int m0 = mt * PW_BM, k0 = kt * BK;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int idx = t + DFD_THREADS * i;
-            const int r = (int)(((unsigned)idx * magic) >> 16), c = idx - r * kc4;
+            const int r = rb0 + i * rstep;
             if (r >= PW_BM) continue;
-            uint4 q = ra[i];
+            uint4 q = R.a[i];
             if (PRO != DFD_PRO_NONE && c < kc && m0 + r < M) {
-                const float* grow = nullptr;
-                if constexpr (PRO == DFD_PRO_BN_ACT_GATE) grow = pa.gate + (long)((m0 + r) / pa.HW) * K;
-                q = apply_pro<T, PRO, ACT>(ra[i], ra2[i], pa.coef, grow, k0 + c * E, K);
+                const float* gk = nullptr;
+                if constexpr (PRO == DFD_PRO_BN_ACT_GATE) gk = pa.gate + (long)pro_image(pa, m0 + r) * K + k0 + c * E;
+                q = apply_pro_c<T, PRO, ACT, E>(R.a[i], R.a2[i], c0, c1, c2, gk);
             }
             *reinterpret_cast<uint4*>(ab + r * 128 + ((c ^ (r & 7)) << 4)) = q;
         }
         if (with_b) {
 #pragma unroll
             for (int i = 0; i < BN / 32; ++i) {
-                const int idx = t + DFD_THREADS * i;
-                const int r = (int)(((unsigned)idx * magic) >> 16), c = idx - r * kc4;
-                if (r < BN) *reinterpret_cast<uint4*>(bb + r * 128 + ((c ^ (r & 7)) << 4)) = rb[i];
+                const int r = rb0 + i * rstep;
+                if (r < BN) *reinterpret_cast<uint4*>(bb + r * 128 + ((c ^ (r & 7)) << 4)) = R.b[i];
             }
         }
     };
 
-    // flat software pipeline over (M tile, K tile): the global loads of the next stage (possibly
-    // the next M tile) are in flight while the current stage's MFMAs and epilogue run
-    int mt = pb, kt = 0, buf = 0;
-    g_load(mt, 0, true);
-    s_store(mt, 0, 0, true);
-    __syncthreads();
+    // flat software pipeline over (M tile, K tile), two stages deep: while stage s runs its MFMAs
+    // (and epilogue), the loads of stage s+2 are issued and stage s+1 sits in registers; its
+    // prologue + LDS store follow the MFMAs, so a global load has a full stage to land
     f32x4_t acc[NTW][4];
 #pragma unroll
     for (int i = 0; i < NTW; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-    for (;;) {
-        int nmt = mt, nkt = kt + 1;
-        if (nkt == nk) { nkt = 0; nmt = mt + gx; }
-        const bool has_next = nmt < m_tiles;
-        const bool next_b = !b_resident;
-        if (has_next) g_load(nmt, nkt, next_b);
+    const bool next_b = !b_resident;
+    auto advance = [&](int& m_, int& k_) { if (++k_ == nk) { k_ = 0; m_ += gx; } };
+    auto compute = [&](int mt, int kt, int buf) {
         {
-            const unsigned char* ab = smem + buf * L::A_BYTES;
-            const unsigned char* bb = smem + L::BOFF + (b_resident ? 0 : buf) * L::B_BYTES;
+                const unsigned char* ab = smem + buf * L::A_BYTES;
+                const unsigned char* bb = smem + L::BOFF + (b_resident ? 0 : buf) * L::B_BYTES;
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                const int klim = kt * BK + ks * (BK / 2);
-                if (klim < K) {
-                    const int c = ks * 4 + fk;
-                    uint4 fa[4], fw[NTW];
+                for (int ks = 0; ks < 2; ++ks) {
+                    const int klim = kt * BK + ks * (BK / 2);
+                    if (klim < K) {
+                        const int c = ks * 4 + fk;
+                        uint4 fa[4], fw[NTW];
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const int r = wm * 64 + i * 16 + frow;
-                        fa[i] = *reinterpret_cast<const uint4*>(ab + r * 128 + ((c ^ (r & 7)) << 4));
-                    }
-#pragma unroll
-                    for (int i = 0; i < NTW; ++i) {
-                        const int r = wn * (BN / 2) + i * 16 + frow;
-                        fw[i] = *reinterpret_cast<const uint4*>(bb + r * 128 + ((c ^ (r & 7)) << 4));
-                    }
-#pragma unroll
-                    for (int i = 0; i < NTW; ++i)
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            if constexpr (sizeof(T) == 2) {
-                                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                                    __builtin_bit_cast(bf16x8_t, fw[i]), __builtin_bit_cast(bf16x8_t, fa[j]), acc[i][j], 0, 0, 0);
-                            } else {
-                                const f32x4_t wv = __builtin_bit_cast(f32x4_t, fw[i]);
-                                const f32x4_t av = __builtin_bit_cast(f32x4_t, fa[j]);
-                                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[0], av[0], acc[i][j], 0, 0, 0);
-                                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[1], av[1], acc[i][j], 0, 0, 0);
-                                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[2], av[2], acc[i][j], 0, 0, 0);
-                                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[3], av[3], acc[i][j], 0, 0, 0);
-                            }
+                        for (int i = 0; i < 4; ++i) {
+                            const int r = wm * 64 + i * 16 + frow;
+                            fa[i] = *reinterpret_cast<const uint4*>(ab + r * 128 + ((c ^ (r & 7)) << 4));
                         }
+#pragma unroll
+                        for (int i = 0; i < NTW; ++i) {
+                            const int r = wn * (BN / 2) + i * 16 + frow;
+                            fw[i] = *reinterpret_cast<const uint4*>(bb + r * 128 + ((c ^ (r & 7)) << 4));
+                        }
+#pragma unroll
+                        for (int i = 0; i < NTW; ++i)
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                if constexpr (sizeof(T) == 2) {
+                                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                                        __builtin_bit_cast(bf16x8_t, fw[i]), __builtin_bit_cast(bf16x8_t, fa[j]), acc[i][j], 0, 0, 0);
+                                } else {
+                                    const f32x4_t wv = __builtin_bit_cast(f32x4_t, fw[i]);
+                                    const f32x4_t av = __builtin_bit_cast(f32x4_t, fa[j]);
+                                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[0], av[0], acc[i][j], 0, 0, 0);
+                                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[1], av[1], acc[i][j], 0, 0, 0);
+                                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[2], av[2], acc[i][j], 0, 0, 0);
+                                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[3], av[3], acc[i][j], 0, 0, 0);
+                                }
+                            }
+                    }
                 }
             }
-        }
-        if (kt == nk - 1) {
-            // ---- tile done: accumulators -> LDS overlay [m][n] -> 16-byte row-major stores
-            const int m0 = mt * PW_BM;
-            __syncthreads();            // every wave is done reading the A buffers the overlay covers
+            if (kt == nk - 1) {
+                // ---- tile done: accumulators -> LDS overlay [m][n] -> 16-byte row-major stores
+                const int m0 = mt * PW_BM;
+                __syncthreads();            // every wave is done reading the A buffers the overlay covers
 #pragma unroll
-            for (int i = 0; i < NTW; ++i)
+                for (int i = 0; i < NTW; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int m = wm * 64 + j * 16 + frow;
-                    const int n = wn * (BN / 2) + i * 16 + fk * 4;
-                    unsigned char* p = smem + m * OROW + n * (int)sizeof(T);
-                    if constexpr (sizeof(T) == 2) {
-                        uint2 q;
-                        q.x = pack_bf2(acc[i][j][0], acc[i][j][1]);
-                        q.y = pack_bf2(acc[i][j][2], acc[i][j][3]);
-                        *reinterpret_cast<uint2*>(p) = q;
-                    } else {
-                        *reinterpret_cast<float4*>(p) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+                    for (int j = 0; j < 4; ++j) {
+                        const int m = wm * 64 + j * 16 + frow;
+                        const int n = wn * (BN / 2) + i * 16 + fk * 4;
+                        unsigned char* p = smem + m * OROW + n * (int)sizeof(T);
+                        if constexpr (sizeof(T) == 2) {
+                            uint2 q;
+                            q.x = pack_bf2(acc[i][j][0], acc[i][j][1]);
+                            q.y = pack_bf2(acc[i][j][2], acc[i][j][3]);
+                            *reinterpret_cast<uint2*>(p) = q;
+                        } else {
+                            *reinterpret_cast<float4*>(p) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+                        }
+                        acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
                     }
-                    acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-                }
-            __syncthreads();
-            const int n = n0 + ec * E;
-            if (n < Nout) {
+                __syncthreads();
+                const int n = n0 + ec * E;
+                if (n < Nout) {
 #pragma unroll 4
-                for (int r = er; r < PW_BM; r += RL) {
-                    const int m = m0 + r;
-                    if (m >= M) break;
-                    float v[E];
-                    q_to_f(*reinterpret_cast<const uint4*>(smem + r * OROW + ec * 16), v);
-                    if constexpr (RES) {
-                        float q[E];
-                        Vec<T>::load(res + (long)m * Nout + n, q);
+                    for (int r = er; r < PW_BM; r += RL) {
+                        const int m = m0 + r;
+                        if (m >= M) break;
+                        float v[E];
+                        q_to_f(*reinterpret_cast<const uint4*>(smem + r * OROW + ec * 16), v);
+                        if constexpr (RES) {
+                            float q[E];
+                            Vec<T>::load(res + (long)m * Nout + n, q);
 #pragma unroll
-                        for (int j = 0; j < E; ++j) v[j] = round_to<T>(v[j] + q[j]);
-                    }
-                    if constexpr (STATS) {
+                            for (int j = 0; j < E; ++j) v[j] = round_to<T>(v[j] + q[j]);
+                        }
+                        if constexpr (STATS) {
 #pragma unroll
-                        for (int j = 0; j < E; ++j) { s1[j] += v[j]; s2[j] = fmaf(v[j], v[j], s2[j]); }
+                            for (int j = 0; j < E; ++j) { s1[j] += v[j]; s2[j] = fmaf(v[j], v[j], s2[j]); }
+                        }
+                        Vec<T>::store(out + (long)m * Nout + n, v);
                     }
-                    Vec<T>::store(out + (long)m * Nout + n, v);
                 }
+                __syncthreads();            // overlay reads done before the next stage lands in the A buffers
             }
-            __syncthreads();            // overlay reads done before the next stage lands in the A buffers
-        }
-        if (!has_next) break;
-        // the next stage goes to the other A buffer; its B tile (if not resident) likewise
+    };
+    int mt = pb, kt = 0, buf = 0;
+    int mt1 = mt, kt1 = 0;
+    advance(mt1, kt1);
+    g_load(R0, mt, 0, true);
+    c_load(0);
+    if (mt1 < m_tiles) g_load(R1, mt1, kt1, next_b);
+    s_store(R0, mt, 0, 0, true);
+    __syncthreads();
+    // one step: stage (mt,kt) is in LDS buffer `buf`, stage (mt1,kt1) is in `rnext`, `rfree` is free
+    auto step = [&](Regs& rfree, const Regs& rnext) -> bool {
+        int mt2 = mt1, kt2 = kt1;
+        advance(mt2, kt2);
+        if (mt1 < m_tiles && mt2 < m_tiles) g_load(rfree, mt2, kt2, next_b);
+        if (mt1 < m_tiles) c_load(kt1);
+        compute(mt, kt, buf);
+        if (mt1 >= m_tiles) return false;
         const int nbuf = (kt == nk - 1) ? 0 : (buf ^ 1);
-        if (kt != nk - 1 && nk > 1) {
-            // within a tile the other buffer may still be read by slower waves of the PREVIOUS stage:
-            // the barrier at the end of that stage already ordered it
-        }
-        s_store(nmt, nkt, nbuf, next_b);
+        s_store(rnext, mt1, kt1, nbuf, next_b);
         __syncthreads();
-        mt = nmt; kt = nkt; buf = nbuf;
+        mt = mt1; kt = kt1; buf = nbuf;
+        mt1 = mt2; kt1 = kt2;
+        return true;
+    };
+    for (;;) {
+        if (!step(R0, R1)) break;
+        if (!step(R1, R0)) break;
     }
     if constexpr (STATS) {
         __syncthreads();
@@ -431,7 +489,7 @@ k_pw_tn(const T* __restrict__ p, ProArgs pp, int Ni, const T* __restrict__ q, Pr
                 uint4 v = rq[i];
                 if (PROQ != DFD_PRO_NONE && m < mend) {
                     const float* grow = nullptr;
-                    if constexpr (PROQ == DFD_PRO_BN_ACT_GATE) grow = pq.gate + (long)(m / pq.HW) * Nj;
+                    if constexpr (PROQ == DFD_PRO_BN_ACT_GATE) grow = pq.gate + (long)pro_image(pq, m) * Nj;
                     v = apply_pro<T, PROQ, ACT>(rq[i], rq[i], pq.coef, grow, j0 + chk * E, Nj);
                 }
                 if constexpr (sizeof(T) == 2) *reinterpret_cast<uint4*>(qb_ + tn_off_bf16(r, chk)) = v;
@@ -580,8 +638,15 @@ static bool pro_ok(const dfd_prologue* p) {
     }
 }
 static ProArgs pro_args(const dfd_prologue* p) {
-    ProArgs a{nullptr, nullptr, nullptr, 1};
+    ProArgs a{nullptr, nullptr, nullptr, 1, 0u, -1};
     if (p) { a.a2 = p->a2; a.coef = p->coef; a.gate = p->gate; a.HW = p->HW > 0 ? p->HW : 1; }
+    if (a.HW > 1) {
+        // exact for every m < 2^31: magic = ceil(2^(31+s) / HW), s = ceil(log2 HW)
+        int sh = 0;
+        while ((1ll << sh) < a.HW) ++sh;
+        a.hw_magic = (unsigned)(((1ull << (31 + sh)) + (unsigned long long)a.HW - 1) / (unsigned long long)a.HW);
+        a.hw_shift = sh - 1;
+    }
     return a;
 }
 
