@@ -17,102 +17,7 @@
 //     from tiles stored exactly as they sit in memory ([m][channel]).
 //   * workgroups are persistent over M tiles: per-channel (sum, sumsq) stay in
 //     registers and leave as ONE partial row per workgroup (reproducible reductions).
-#include "dfd_common.h"
-#include <type_traits>
-
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
-typedef __attribute__((ext_vector_type(4))) short short4_t;
-typedef __attribute__((ext_vector_type(8))) short short8_t;
-typedef __attribute__((ext_vector_type(4))) float f32x4_t;
-
-#define PW_BM 128
-
-struct ProArgs {
-    const void* a2;
-    const float* coef;
-    const float* gate;
-    int HW;
-    unsigned hw_magic;      // row -> image: umulhi(m, hw_magic) >> hw_shift  (hw_shift < 0: HW == 1)
-    int hw_shift;
-};
-__device__ __forceinline__ int pro_image(const ProArgs& pa, int m) {
-    return pa.hw_shift < 0 ? m : (int)(__umulhi((unsigned)m, pa.hw_magic) >> pa.hw_shift);
-}
-
-template <typename T> struct El;
-template <> struct El<bf16> { static constexpr int EPC = 8; static constexpr int BK = 64; };   // elements per 16-B chunk, K tile
-template <> struct El<float> { static constexpr int EPC = 4; static constexpr int BK = 32; };
-
-__device__ __forceinline__ void q_to_f(const uint4& q, float (&v)[8]) { Vec<bf16>::unpack(q, v); }
-__device__ __forceinline__ void q_to_f(const uint4& q, float (&v)[4]) {
-    v[0] = __uint_as_float(q.x); v[1] = __uint_as_float(q.y); v[2] = __uint_as_float(q.z); v[3] = __uint_as_float(q.w);
-}
-__device__ __forceinline__ uint4 f_to_q(const float (&v)[8]) { return Vec<bf16>::pack(v); }
-__device__ __forceinline__ uint4 f_to_q(const float (&v)[4]) {
-    return make_uint4(__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3]));
-}
-
-// apply the prologue to one 16-byte chunk (EPC consecutive k of one row)
-template <typename T, int PRO, int ACT>
-__device__ __forceinline__ uint4 apply_pro(uint4 q, uint4 q2, const float* __restrict__ coef, const float* __restrict__ gate_row,
-                                           int k, int K) {
-    constexpr int E = El<T>::EPC;
-    if constexpr (PRO == DFD_PRO_NONE) {
-        return q;
-    } else {
-        float v[E], c0[E], c1[E];
-        q_to_f(q, v);
-        load_f32<E>(coef + k, c0);
-        load_f32<E>(coef + K + k, c1);
-        if constexpr (PRO == DFD_PRO_AFFINE2) {
-            float v2[E], c2[E];
-            q_to_f(q2, v2);
-            load_f32<E>(coef + 2 * K + k, c2);
-#pragma unroll
-            for (int j = 0; j < E; ++j) v[j] = fmaf(c0[j], v[j], fmaf(c1[j], v2[j], c2[j]));
-        } else {
-#pragma unroll
-            for (int j = 0; j < E; ++j) v[j] = act_fwd<ACT>(fmaf(c0[j], v[j], c1[j]));
-            if constexpr (PRO == DFD_PRO_BN_ACT_GATE) {
-                float gt[E];
-                load_f32<E>(gate_row + k, gt);
-                // the activated tensor is rounded to T before the gate multiply, as an
-                // unfused pipeline would store it
-#pragma unroll
-                for (int j = 0; j < E; ++j) v[j] = round_to<T>(v[j]) * gt[j];
-            }
-        }
-        return f_to_q(v);
-    }
-}
-
-// same with the per-channel coefficient vectors already in registers
-template <typename T, int PRO, int ACT, int E>
-__device__ __forceinline__ uint4 apply_pro_c(uint4 q, uint4 q2, const float (&c0)[E], const float (&c1)[E], const float (&c2)[E],
-                                             const float* __restrict__ gate_k) {
-    if constexpr (PRO == DFD_PRO_NONE) {
-        return q;
-    } else {
-        float v[E];
-        q_to_f(q, v);
-        if constexpr (PRO == DFD_PRO_AFFINE2) {
-            float v2[E];
-            q_to_f(q2, v2);
-#pragma unroll
-            for (int j = 0; j < E; ++j) v[j] = fmaf(c0[j], v[j], fmaf(c1[j], v2[j], c2[j]));
-        } else {
-#pragma unroll
-            for (int j = 0; j < E; ++j) v[j] = act_fwd<ACT>(fmaf(c0[j], v[j], c1[j]));
-            if constexpr (PRO == DFD_PRO_BN_ACT_GATE) {
-                float gt[E];
-                load_f32<E>(gate_k, gt);
-#pragma unroll
-                for (int j = 0; j < E; ++j) v[j] = round_to<T>(v[j]) * gt[j];
-            }
-        }
-        return f_to_q(v);
-    }
-}
+#include "dfd_pw.h"
 
 // ===========================================================================
 // NT kernel
@@ -620,36 +525,6 @@ extern "C" int dfd_pw_prep_weights(int dtype, const float* w, void* w_nk, void* 
 // ===========================================================================
 // host dispatch
 // ===========================================================================
-// activations instantiated for the GEMM prologues (EfficientNet: SiLU)
-#define DISPATCH_ACT_PW(ACTV, ...)                                                   \
-    switch (ACTV) {                                                                  \
-        case DFD_ACT_NONE: { constexpr int ACT = DFD_ACT_NONE; __VA_ARGS__; } break; \
-        case DFD_ACT_SILU: { constexpr int ACT = DFD_ACT_SILU; __VA_ARGS__; } break; \
-        default: return DFD_EUNSUPPORTED;                                            \
-    }
-static bool pro_ok(const dfd_prologue* p) {
-    if (!p) return true;
-    switch (p->mode) {
-        case DFD_PRO_NONE: return true;
-        case DFD_PRO_BN_ACT: return p->coef != nullptr;
-        case DFD_PRO_BN_ACT_GATE: return p->coef && p->gate && p->HW > 0;
-        case DFD_PRO_AFFINE2: return p->coef && p->a2;
-        default: return false;
-    }
-}
-static ProArgs pro_args(const dfd_prologue* p) {
-    ProArgs a{nullptr, nullptr, nullptr, 1, 0u, -1};
-    if (p) { a.a2 = p->a2; a.coef = p->coef; a.gate = p->gate; a.HW = p->HW > 0 ? p->HW : 1; }
-    if (a.HW > 1) {
-        // exact for every m < 2^31: magic = ceil(2^(31+s) / HW), s = ceil(log2 HW)
-        int sh = 0;
-        while ((1ll << sh) < a.HW) ++sh;
-        a.hw_magic = (unsigned)(((1ull << (31 + sh)) + (unsigned long long)a.HW - 1) / (unsigned long long)a.HW);
-        a.hw_shift = sh - 1;
-    }
-    return a;
-}
-
 template <typename T, int BN>
 static int pw_nt_launch(const void* a, const dfd_prologue* pro, const void* w, void* out, const void* residual, int M,
                         int K, int Nout, float* partials, int pcap, int* nparts, hipStream_t st) {
@@ -709,6 +584,9 @@ extern "C" int dfd_pwconv_fwd(int dtype, const void* a, const dfd_prologue* pro,
     if (!a || !w || !out || M < 1 || K < 8 || Nout < 8 || K % 8 || Nout % 8 || !pro_ok(pro)) return DFD_EINVAL;
     if (partials && (!nparts || pcap < 1)) return DFD_EINVAL;
     hipStream_t st = (hipStream_t)stream;
+    // small weight panels (the large-M layers): wave-autonomous kernel with the panel resident in LDS
+    const int rc = dfd_pw_ntw(dtype, a, pro, w, out, residual, M, K, Nout, partials, pcap, nparts, st);
+    if (rc != DFD_EUNSUPPORTED) return rc;
     if (dtype == DFD_BF16) return pw_nt_t<bf16>(a, pro, w, out, residual, M, K, Nout, partials, pcap, nparts, st);
     if (dtype == DFD_F32) return pw_nt_t<float>(a, pro, w, out, residual, M, K, Nout, partials, pcap, nparts, st);
     return DFD_EINVAL;
