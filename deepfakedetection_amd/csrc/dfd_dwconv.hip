@@ -13,7 +13,15 @@ __global__ void k_sum_partials(const float* __restrict__ partials, int P, long L
     const int p0 = blockIdx.y * SUM_GROUP;
     const int p1 = (p0 + SUM_GROUP < P) ? p0 + SUM_GROUP : P;
     float s = 0.f;
-    for (int p = p0; p < p1; ++p) s += partials[(long)p * L + i];
+    int p = p0;
+    for (; p + 8 <= p1; p += 8) {          // eight independent loads in flight, added in row order
+        float u[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) u[k] = partials[(long)(p + k) * L + i];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s += u[k];
+    }
+    for (; p < p1; ++p) s += partials[(long)p * L + i];
     float* o = out + (long)blockIdx.y * out_stride + i;
     *o = (accumulate ? *o : 0.f) + s;
 }

@@ -222,7 +222,21 @@ __device__ __forceinline__ void fin_reduce(const float* __restrict__ partials, i
                                            double* sm, double& s0, double& s1) {
     float a0 = 0.f, a1 = 0.f;
     if (c < C) {
-        for (int p = q; p < nparts; p += FIN_LANES) {
+        // eight rows per trip, loaded before any of them is added: the loop is a chain of
+        // memory round trips, not of additions (order of the additions is fixed)
+        int p = q;
+        for (; p + 7 * FIN_LANES < nparts; p += 8 * FIN_LANES) {
+            float u[8], v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float* row = partials + (long)(p + i * FIN_LANES) * 2 * C;
+                u[i] = row[c];
+                v[i] = row[C + c];
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { a0 += u[i]; a1 += v[i]; }
+        }
+        for (; p < nparts; p += FIN_LANES) {
             a0 += partials[(long)p * 2 * C + c];
             a1 += partials[(long)p * 2 * C + C + c];
         }
