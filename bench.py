@@ -45,6 +45,9 @@ def parse() -> argparse.Namespace:
     ap.add_argument("--variant", default="b0")
     ap.add_argument("--flavour", default="timm")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--dp-mode", choices=("split", "overlap"), default="split",
+                    help="N>1: 'split' = hipGraph(fwd+bwd) | RCCL all-reduce | hipGraph(AdamW); "
+                         "'overlap' = eager step, buckets all-reduced from backward hooks")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=16)
     ap.add_argument("--cpu-steps", type=int, default=3)
@@ -87,7 +90,8 @@ def main() -> None:
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback)"
-    device = torch.device("cuda", local_rank)
+    # one rank per GPU; the modulo only matters when a rehearsal runs several ranks on a one-GPU box
+    device = torch.device("cuda", local_rank % max(1, torch.cuda.device_count()))
     torch.cuda.set_device(device)
 
     torch.manual_seed(1)
@@ -101,24 +105,53 @@ def main() -> None:
     y = torch.randint(0, args.classes, (args.batch,), generator=g).to(device)
     loss_box: list[torch.Tensor] = [torch.zeros((), device=device)]
 
-    def step_body() -> None:
+    overlap = reducer is not None and args.dp_mode == "overlap"
+    if overlap:
+        reducer.attach()
+
+    def fwd_bwd() -> None:
+        opt.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            loss = crit(model(x), y)
+        if overlap:
+            reducer.arm()
+        loss.backward()
+        loss_box[0] = loss.detach()
+
+    def fwd_bwd_plain() -> None:           # the same without arming the hooks (profiling on one rank)
         opt.zero_grad(set_to_none=True)
         with torch.autocast("cuda", dtype=torch.bfloat16):
             loss = crit(model(x), y)
         loss.backward()
+
+    gloo_on_gpu = world > 1 and dist.get_backend() == "gloo"     # one-GPU rehearsal only
+
+    def exchange() -> None:
+        if gloo_on_gpu and not overlap:
+            torch.cuda.synchronize()        # gloo stages CUDA tensors through the host: hand it finished data
         if reducer is not None:
-            reducer.reduce()
+            if overlap:
+                reducer.finish()
+            else:
+                reducer.reduce()
+
+    def step_body() -> None:
+        fwd_bwd()
+        exchange()
         opt.step()
-        loss_box[0] = loss.detach()
 
     # eager warm-up: sizes the scratch buffers, builds the optimizer state / tables
     for _ in range(3):
         step_body()
     torch.cuda.synchronize()
 
+    # Launch modes.  N = 1: the whole step is ONE hipGraph.  N > 1 ("split"): the collective stays
+    # outside of graph capture — graph A = zero_grad + forward + loss + backward, then the RCCL
+    # all-reduce of the flat gradient arena, then graph B = AdamW.  ("overlap" runs eagerly so the
+    # backward hooks can fire.)
     launch = "eager"
-    graph = None
-    if not args.no_graph:
+    graph_a = graph_b = None
+    if not args.no_graph and not overlap:
         try:
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
@@ -127,24 +160,49 @@ def main() -> None:
                     step_body()
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
-            graph = torch.cuda.CUDAGraph()
             opt.prepare_step()
-            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
-                step_body()
-            launch = "hipgraph"
+            if reducer is None:
+                graph_a = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph_a, capture_error_mode="thread_local"):
+                    fwd_bwd()
+                    opt.step()
+                launch = "hipgraph"
+            else:
+                pool = torch.cuda.graph_pool_handle()
+                graph_a = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph_a, pool=pool, capture_error_mode="thread_local"):
+                    fwd_bwd()
+                torch.cuda.synchronize()
+                exchange()
+                graph_b = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph_b, pool=pool, capture_error_mode="thread_local"):
+                    opt.step()
+                launch = "hipgraph(fwd+bwd) | rccl all-reduce | hipgraph(adamw)"
         except Exception as exc:  # noqa: BLE001 - any capture failure means: measure eagerly
             if rank == 0:
                 import traceback
 
                 traceback.print_exc()
                 print(f"[bench] hipGraph capture failed ({type(exc).__name__}); running eagerly", file=sys.stderr)
-            graph = None
+            graph_a = graph_b = None
             torch.cuda.synchronize()
+    elif overlap:
+        launch = "eager, all-reduce overlapped with backward"
+
+    debug = bool(os.environ.get("DFD_BENCH_DEBUG"))
 
     def run_step() -> None:
-        if graph is not None:
+        if graph_a is not None:
             opt.prepare_step()
-            graph.replay()
+            graph_a.replay()
+            if graph_b is not None:
+                if debug:
+                    torch.cuda.synchronize(); t_a = time.perf_counter()
+                exchange()
+                if debug:
+                    torch.cuda.synchronize(); t_b = time.perf_counter()
+                    print(f"[bench rank {rank}] exchange {1e3 * (t_b - t_a):.2f} ms", file=sys.stderr)
+                graph_b.replay()
         else:
             step_body()
 
@@ -167,16 +225,28 @@ def main() -> None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     final_loss = float(loss_box[0])
+    in_sync = None
+    if world > 1:
+        # replicas started from rank 0's weights and applied the same averaged gradients
+        chk = torch.stack([p.detach().double().sum() for p in model.parameters()]).sum().reshape(1)
+        parts = [torch.zeros_like(chk) for _ in range(world)]
+        dist.all_gather(parts, chk)
+        in_sync = all(bool(torch.equal(parts[0], q)) for q in parts)
 
     # ---- live per-kernel measurement (eager, HIP events on the compute stream)
     roofline, breakdown = None, []
     if rank == 0 and args.profile_steps > 0:
         sink: list = []
-        step_body()
+
+        def local_step() -> None:          # rank 0 alone: no collective in here
+            fwd_bwd_plain()
+            opt.step()
+
+        local_step()
         torch.cuda.synchronize()
         K.set_profile_sink(sink)
         for _ in range(args.profile_steps):
-            step_body()
+            local_step()
         torch.cuda.synchronize()
         K.set_profile_sink(None)
         agg: dict[str, list[float]] = {}
@@ -212,7 +282,7 @@ def main() -> None:
             "config": {"workload": f"EfficientNet-{args.variant} ({args.flavour} flavour) {args.size}x{args.size} train step: "
                                    f"bf16 fwd + label-smoothed CE + bwd + AdamW, random-init weights, {args.classes} classes",
                        "per_gpu_batch": args.batch, "global_batch": args.batch * world, "parallelism": f"dp{world}",
-                       "launch": launch, "final_loss": round(final_loss, 4)},
+                       "launch": launch, "final_loss": round(final_loss, 4), "replicas_in_sync": in_sync},
             "roofline": roofline,
             "kernels": breakdown,
         }

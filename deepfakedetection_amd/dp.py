@@ -41,7 +41,9 @@ def init_distributed(backend: str | None = None) -> tuple[int, int, int]:
         os.environ.setdefault("MASTER_PORT", "29500")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            # DFD_DIST_BACKEND=gloo lets several ranks share ONE GPU (rehearsals on a one-GPU box;
+            # RCCL refuses two ranks on a device)
+            backend = os.environ.get("DFD_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         kwargs = {}
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
@@ -60,7 +62,18 @@ def broadcast_module_state(module: torch.nn.Module, src: int = 0) -> None:
 
 
 class GradAllReducer:
-    """Bucketed gradient all-reduce (sum); pair with an optimizer whose grad_scale = 1/world."""
+    """Bucketed gradient all-reduce (sum); pair with an optimizer whose grad_scale = 1/world.
+
+    Two ways to drive it:
+      * ``reduce()`` after ``backward()``: every bucket is launched at once (used between the two
+        captured hipGraphs of bench.py, where backward itself is one graph replay);
+      * ``attach()`` once, then ``arm()`` before and ``finish()`` after the ``backward()`` that
+        completes an optimizer step (the last micro-batch of an accumulation cycle): a
+        post-accumulate-grad hook per parameter counts a bucket down and launches its all-reduce
+        the moment its last gradient has been produced, so RCCL traffic of the late layers' buckets
+        runs on RCCL's stream while the backward kernels of the early layers are still executing
+        (the eager training loop).
+    """
 
     def __init__(self, params: Iterable[torch.nn.Parameter], bucket_bytes: int = 8 << 20, arena=None) -> None:
         self.params = [p for p in params if p.requires_grad]
@@ -81,11 +94,106 @@ class GradAllReducer:
             size += nbytes
         if cur:
             self.buckets.append(cur)
+        # arena range [lo, hi) of each bucket: parameters are consecutive (reversed) arena slots
+        self._ranges: list[tuple[int, int]] | None = None
+        if arena is not None and [id(p) for p in arena.params] == [id(p) for p in self.params]:
+            index = {id(p): i for i, p in enumerate(arena.params)}
+            sizes = [s.numel() for s in arena.slots]
+            self._ranges = []
+            for bucket in self.buckets:
+                idx = [index[id(p)] for p in bucket]
+                lo, hi = min(idx), max(idx)
+                end = arena.offsets[hi] + (sizes[hi] + 3) // 4 * 4
+                self._ranges.append((arena.offsets[lo], min(end, arena.flat.numel())))
+        self._bucket_of = {id(p): b for b, bucket in enumerate(self.buckets) for p in bucket}
+        self._left: list[int] = []
+        self._pending: list[tuple] = []
+        self._hooks: list = []
+        self._armed = False
+        self.launched_early = 0                 # buckets whose all-reduce started inside backward (diagnostic)
 
     @property
     def grad_scale(self) -> float:
         return 1.0 / self.world
 
+    # ------------------------------------------------------------------ overlapped path
+    def attach(self) -> None:
+        """Register the per-parameter hooks (idempotent)."""
+        if self._hooks or self.world == 1:
+            return
+        for p in self.params:
+            self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
+
+    def arm(self) -> None:
+        """The next backward() completes the gradients of this step: let the hooks launch buckets."""
+        if self._hooks:
+            self._left = [len(b) for b in self.buckets]
+            self._armed = True
+
+    def detach(self) -> None:
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
+
+    def _launch(self, b: int, early: bool) -> None:
+        bucket = self.buckets[b]
+        arena = self.arena
+        if self._ranges is not None and arena is not None and all(
+                p.grad is not None and p.grad.data_ptr() == arena.slots[i].data_ptr()
+                for p, i in ((p, self._slot_index(p)) for p in bucket)):
+            lo, hi = self._ranges[b]
+            chunk = arena.flat[lo:hi]
+            self._pending.append((dist.all_reduce(chunk, op=dist.ReduceOp.SUM, async_op=True), None, None))
+        else:
+            live = [p for p in bucket if p.grad is not None]
+            if not live:
+                return
+            flat = torch.cat([p.grad.reshape(-1).float() for p in live])
+            self._pending.append((dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True), flat, live))
+        if early:
+            self.launched_early += 1
+
+    def _slot_index(self, p: torch.nn.Parameter) -> int:
+        if not hasattr(self, "_slot_idx"):
+            self._slot_idx = {id(q): i for i, q in enumerate(self.arena.params)} if self.arena is not None else {}
+        return self._slot_idx[id(p)]
+
+    def _on_grad(self, p: torch.nn.Parameter) -> None:
+        if not self._armed:
+            return
+        b = self._bucket_of[id(p)]
+        self._left[b] -= 1
+        if self._left[b] == 0:
+            with torch.no_grad():
+                self._launch(b, early=True)
+
+    @torch.no_grad()
+    def finish(self) -> None:
+        """After backward(): launch what the hooks did not (parameters without gradient this step),
+        wait for every bucket, re-point gradients at the reduced flats where a copy was made."""
+        if self.world == 1:
+            return
+        if not self._hooks or not self._armed:
+            self.reduce()
+            return
+        self._armed = False
+        for b, left in enumerate(self._left):
+            if left > 0:
+                self._launch(b, early=False)
+        self._drain()
+
+    def _drain(self) -> None:
+        for work, flat, live in self._pending:
+            work.wait()
+            if flat is not None:
+                at = 0
+                for p in live:
+                    n = p.numel()
+                    p.grad = flat[at:at + n].view_as(p)
+                    at += n
+        self._pending = []
+
+    # ------------------------------------------------------------------ one-shot path
     @torch.no_grad()
     def reduce(self) -> None:
         """Sum the gradients over ranks, in place of each parameter's .grad."""
@@ -99,20 +207,9 @@ class GradAllReducer:
             for w in works:
                 w.wait()
             return
-        pending = []
-        for bucket in self.buckets:
-            live = [p for p in bucket if p.grad is not None]
-            if not live:
-                continue
-            flat = torch.cat([p.grad.reshape(-1).float() for p in live])
-            pending.append((dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True), flat, live))
-        for work, flat, live in pending:
-            work.wait()
-            at = 0
-            for p in live:
-                n = p.numel()
-                p.grad = flat[at:at + n].view_as(p)
-                at += n
+        for b in range(len(self.buckets)):
+            self._launch(b, early=False)
+        self._drain()
 
 
 class ShardedSampler:

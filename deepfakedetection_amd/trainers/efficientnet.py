@@ -177,11 +177,13 @@ def train_one_epoch(model: nn.Module, dl: DataLoader, opt: optim.Optimizer, scal
             loss = criterion(model(inputs), targets)
             if accum_steps > 1:
                 loss = loss / accum_steps
+        if reducer is not None and pending + 1 == accum_steps:
+            reducer.arm()                   # this backward completes the step: buckets leave as they fill
         scaler.scale(loss).backward()
         pending += 1
         if pending == accum_steps:
             if reducer is not None:
-                reducer.reduce()
+                reducer.finish()
             scaler.step(opt)
             scaler.update()
             opt.zero_grad(set_to_none=True)
@@ -196,7 +198,7 @@ def train_one_epoch(model: nn.Module, dl: DataLoader, opt: optim.Optimizer, scal
         progress.update(task, advance=1, description=f"train | loss={shown:.4f} | {ips:.0f} img/s")
     if pending > 0:
         if reducer is not None:
-            reducer.reduce()
+            reducer.finish()
         scaler.step(opt)
         scaler.update()
         opt.zero_grad(set_to_none=True)
@@ -301,10 +303,14 @@ def main() -> None:  # noqa: PLR0915
             head = [p for p in model.parameters() if p.requires_grad]
             warm_opt = make_opt(head, lr=HEAD_LR, weight_decay=HEAD_WD, **opt_extra)
             reducer = GradAllReducer(head, arena=getattr(warm_opt, "arena", None)) if world > 1 else None
+            if reducer is not None:
+                reducer.attach()
             task = progress.add_task("warmup (head only)", total=len(train_dl), extra="")
             console.print("[bold]Warmup (head only)[/]")
             train_one_epoch(model, train_dl, warm_opt, scaler, criterion, device, use_cuda_amp=use_cuda, progress=progress,
                             task=task, accum_steps=1, reducer=reducer)
+            if reducer is not None:
+                reducer.detach()
             res = evaluate(model, val_dl, device, criterion)
             console.print(f"[bold cyan]warmup[/] | val_acc={res.acc:.4f} | val_loss={res.loss:.4f} ({res.correct}/{res.total})")
             best_val_acc, best_epoch, warmup_done = res.acc, 0, True
@@ -319,6 +325,8 @@ def main() -> None:  # noqa: PLR0915
                                   seed=env.seed or 0)
         opt = make_opt([p for p in model.parameters() if p.requires_grad], lr=ft_lr, weight_decay=ft_wd, **opt_extra)
         reducer = GradAllReducer(model.parameters(), arena=getattr(opt, "arena", None)) if world > 1 else None
+        if reducer is not None:
+            reducer.attach()
         scheduler = optim.lr_scheduler.CosineAnnealingLR(opt, T_max=max(1, epochs - 1))
         start_epoch = 0
         resume_state = maybe_load_checkpoint(env, model=model, optimizer=opt, scheduler=scheduler)

@@ -54,6 +54,31 @@ def _worker(rank: int, world: int, port: int, out_dir: str) -> None:
             assert torch.allclose(p.grad, torch.full_like(p, 3.0 * (i + 1))), "arena path"
         arena.release()
 
+        # path 3: hook-driven overlap — buckets are launched from inside backward() as their last
+        # gradient appears; the result must equal the sum of the two ranks' local gradients
+        torch.manual_seed(7 + rank)
+        x = torch.randn(6, 7)
+        model.zero_grad(set_to_none=True)
+        model(x).square().sum().backward()
+        local = [p.grad.clone() for p in params]
+        gathered_g = []
+        for g in local:
+            parts = [torch.zeros_like(g) for _ in range(world)]
+            dist.all_gather(parts, g)
+            gathered_g.append(parts[0] + parts[1])
+        hooked = GradAllReducer(params, bucket_bytes=64)
+        hooked.attach()
+        for _ in range(2):                                   # twice: the counters must re-arm
+            model.zero_grad(set_to_none=True)
+            model(x).square().sum().mul(0.5).backward()          # micro-batch 1 of 2: hooks stay quiet
+            hooked.arm()
+            model(x).square().sum().mul(0.5).backward()          # micro-batch 2 completes the step
+            hooked.finish()
+            for p, want in zip(params, gathered_g):
+                assert torch.allclose(p.grad, want, rtol=1e-5, atol=1e-6), "hook path"
+        assert hooked.launched_early >= len(hooked.buckets), "no bucket was launched from a hook"
+        hooked.detach()
+
         total = all_reduce_counts(float(rank + 1), 10.0)
         assert total == [3.0, 20.0]
         sampler = ShardedSampler(11, rank, world, shuffle=True, seed=4)

@@ -1,0 +1,97 @@
+"""N > 1 path on the GPU: two ranks share cuda:0 and exchange over gloo (RCCL refuses two ranks
+on one device; on a real node the same code runs one rank per GPU over RCCL).  Checks that
+  * the all-reduced gradient arena equals the sum of the two ranks' local arenas (one-shot path and
+    the hook-driven overlapped path),
+  * after AdamW steps with grad_scale = 1/world the replicas hold identical parameters."""
+
+from __future__ import annotations
+
+import datetime
+import os
+import socket
+import traceback
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank: int, world: int, port: int, mode: str) -> None:
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    from deepfakedetection_amd.dp import GradAllReducer, broadcast_module_state
+    from deepfakedetection_amd.efficientnet import HipEfficientNet
+    from deepfakedetection_amd.optim import HipAdamW, HipCrossEntropyLoss
+
+    # a failing rank must never leave its peer blocked in a collective: short timeout, hard exit
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
+    try:
+        dev = torch.device("cuda", 0)
+        torch.cuda.set_device(dev)
+        torch.manual_seed(10 + rank)                                 # different init: broadcast must fix it
+        model = HipEfficientNet("b0", "timm", 2).to(dev).train()
+        broadcast_module_state(model)
+        opt = HipAdamW(model.parameters(), lr=1e-3, weight_decay=1e-2, grad_scale=1.0 / world)
+        red = GradAllReducer(model.parameters(), bucket_bytes=2 << 20, arena=opt.arena)
+        if mode == "hooks":
+            red.attach()
+        crit = HipCrossEntropyLoss(label_smoothing=0.1)
+        g = torch.Generator().manual_seed(50 + rank)                 # each rank its own shard
+        x = torch.randn(8, 3, 64, 64, generator=g).to(dev).contiguous(memory_format=torch.channels_last)
+        y = torch.randint(0, 2, (8,), generator=g).to(dev)
+        for step in range(2):
+            opt.zero_grad(set_to_none=True)
+            torch.manual_seed(1000 + step)
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                loss = crit(model(x), y)
+            if mode == "hooks":
+                # reference: a hook-free backward of the same step (same dropout mask: same seed)
+                loss.backward()
+                torch.cuda.synchronize()
+                local = opt.arena.flat.clone()
+                opt.zero_grad(set_to_none=True)
+                torch.manual_seed(1000 + step)
+                with torch.autocast("cuda", dtype=torch.bfloat16):
+                    loss = crit(model(x), y)
+                red.arm()
+                loss.backward()
+                red.finish()
+            else:
+                loss.backward()
+                torch.cuda.synchronize()
+                local = opt.arena.flat.clone()
+                red.reduce()
+            torch.cuda.synchronize()
+            parts = [torch.zeros_like(local) for _ in range(world)]
+            dist.all_gather(parts, local)
+            want = parts[0] + parts[1]
+            got = opt.arena.flat
+            assert opt.arena.holds_all_grads()
+            err = (got - want).abs().max().item()
+            assert err <= 1e-5 * max(1.0, want.abs().max().item()), f"{mode}: reduced arena differs from the sum ({err})"
+            opt.step()
+        torch.cuda.synchronize()
+        flat = torch.cat([p.detach().flatten() for p in model.parameters()])
+        parts = [torch.zeros_like(flat) for _ in range(world)]
+        dist.all_gather(parts, flat)
+        assert torch.equal(parts[0], parts[1]), f"{mode}: replicas diverged"
+        if mode == "hooks":
+            assert red.launched_early > 0, "no bucket left from inside backward"
+    except BaseException:
+        traceback.print_exc()
+        os._exit(1)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["oneshot", "hooks"])
+def test_two_ranks_one_gpu(mode):
+    mp.spawn(_worker, args=(2, _free_port(), mode), nprocs=2, join=True)
