@@ -153,19 +153,27 @@ k_act_bn_bwd(const T* __restrict__ D, const T* __restrict__ y, const float* __re
 }
 
 // ------------------------------------------------------------------ pool kernels
-// grid = (nvc, N): one workgroup owns all HW rows of image n for its channel chunk.
+// grid = (nvc, N, splits): a workgroup owns the rows [z*rows_per .. ) of image n for its channel
+// chunk.  Large images are split over several workgroups (one per (chunk, image) leaves most of
+// the chip idle and each lane with two loads in flight); k_pool_sum then adds the partial vectors
+// in split order.  (A last-arrival reduction inside this kernel was measured 5x slower: the
+// device-scope fences it needs write back / invalidate L2 on this multi-XCD part.)
 // BWD == false: pooled[n,c] = (1/HW) sum act(scale*y+shift)
 // BWD == true : dgate[n,c]  = sum D * act(scale*y+shift)
 template <typename T, int ACT, bool BWD>
 __global__ void __launch_bounds__(DFD_THREADS)
 k_pool(const T* __restrict__ D, const T* __restrict__ y, const float* __restrict__ bnstate,
-       float* __restrict__ out, int HW, int C, float mul, ChanMap cm) {
+       float* __restrict__ out, int HW, int C, float mul, ChanMap cm, int rows_per, float* __restrict__ parts) {
     constexpr int V = Vec<T>::N;
     __shared__ float red[DFD_THREADS * V];
     const int t = threadIdx.x, vl = t % cm.cvb, rl = t / cm.cvb;
     const bool active = rl < cm.rpb;
     const int c0 = (blockIdx.x * cm.cvb + vl) * V;
     const long n = blockIdx.y;
+    const int splits = gridDim.z, N = gridDim.y;
+    const int r_beg = blockIdx.z * rows_per;
+    int r_end = r_beg + rows_per;
+    if (r_end > HW) r_end = HW;
     float sc[V], sh[V];
     load_f32<V>(bnstate + c0, sc);
     load_f32<V>(bnstate + C + c0, sh);
@@ -175,25 +183,25 @@ k_pool(const T* __restrict__ D, const T* __restrict__ y, const float* __restrict
     if (active) {
         const T* yb = y + n * HW * (long)C + c0;
         const T* db = BWD ? D + n * HW * (long)C + c0 : nullptr;
-        int r = rl;
-        // two rows in flight per lane
-        for (; r + cm.rpb < HW; r += 2 * cm.rpb) {
-            float y0[V], y1[V], d0[V], d1[V];
-            Vec<T>::load(yb + (long)r * C, y0);
-            Vec<T>::load(yb + (long)(r + cm.rpb) * C, y1);
-            if constexpr (BWD) {
-                Vec<T>::load(db + (long)r * C, d0);
-                Vec<T>::load(db + (long)(r + cm.rpb) * C, d1);
+        int r = r_beg + rl;
+        // four rows in flight per lane
+        for (; r + 3 * cm.rpb < r_end; r += 4 * cm.rpb) {
+            float yv[4][V], dv[4][V];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                Vec<T>::load(yb + (long)(r + u * cm.rpb) * C, yv[u]);
+                if constexpr (BWD) Vec<T>::load(db + (long)(r + u * cm.rpb) * C, dv[u]);
             }
 #pragma unroll
-            for (int j = 0; j < V; ++j) {
-                float a0 = round_to<T>(act_fwd<ACT>(fmaf(sc[j], y0[j], sh[j])));
-                float a1 = round_to<T>(act_fwd<ACT>(fmaf(sc[j], y1[j], sh[j])));
-                if constexpr (BWD) acc[j] += a0 * d0[j] + a1 * d1[j];
-                else acc[j] += a0 + a1;
-            }
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int j = 0; j < V; ++j) {
+                    const float a0 = round_to<T>(act_fwd<ACT>(fmaf(sc[j], yv[u][j], sh[j])));
+                    if constexpr (BWD) acc[j] += a0 * dv[u][j];
+                    else acc[j] += a0;
+                }
         }
-        for (; r < HW; r += cm.rpb) {
+        for (; r < r_end; r += cm.rpb) {
             float y0[V], d0[V];
             Vec<T>::load(yb + (long)r * C, y0);
             if constexpr (BWD) Vec<T>::load(db + (long)r * C, d0);
@@ -206,11 +214,22 @@ k_pool(const T* __restrict__ D, const T* __restrict__ y, const float* __restrict
         }
     }
     reduce_rowlanes<V>(acc, red, cm.cvb, cm.rpb, vl, rl, active);
-    if (rl == 0) {
+    if (splits == 1) {
+        if (rl == 0) {
 #pragma unroll
-        for (int j = 0; j < V; ++j) acc[j] *= mul;
-        store_f32<V>(out + n * C + c0, acc);
+            for (int j = 0; j < V; ++j) acc[j] *= mul;
+            store_f32<V>(out + n * C + c0, acc);
+        }
+        return;
     }
+    if (rl == 0) store_f32<V>(parts + ((long)blockIdx.z * N + n) * C + c0, acc);
+}
+__global__ void k_pool_sum(const float* __restrict__ parts, int splits, long NC, float mul, float* __restrict__ out) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= NC) return;
+    float s = 0.f;
+    for (int z = 0; z < splits; ++z) s += parts[(long)z * NC + i];
+    out[i] = s * mul;
 }
 
 // ------------------------------------------------------------------ finalize kernels
@@ -446,31 +465,66 @@ extern "C" int dfd_act_bn_bwd(int dtype, const void* D, const void* y, const flo
                : act_bn_bwd_t<float>(D, y, gate, dpool, bnstate, act, dz, N, HW, C, partials, pcap, nparts, st);
 }
 
+// HW rows per split so that the launch has about 2048 workgroups; one split for small images
+static void pool_plan(int N, int HW, int C, int vec, int* splits, int* rows_per) {
+    const ChanMap cm = make_chanmap(C, vec);
+    long base = (long)cm.nvc * N;
+    int s = (int)(2048 / (base > 0 ? base : 1));
+    const int max_s = HW / (cm.rpb * 8);                // at least 8 rows per lane
+    if (s > max_s) s = max_s;
+    if (s > 32) s = 32;
+    if (s < 1) s = 1;
+    int rp = (HW + s - 1) / s;
+    s = (HW + rp - 1) / rp;
+    *splits = s;
+    *rows_per = rp;
+}
+static size_t pool_ws_bytes(int N, int HW, int C, int vec) {
+    int s, rp;
+    pool_plan(N, HW, C, vec, &s, &rp);
+    if (s <= 1) return 0;
+    return (size_t)s * N * C * sizeof(float);
+}
+extern "C" size_t dfd_pool_ws(int dtype, int N, int HW, int C) {
+    if (!shape_ok(dtype, N, HW, C)) return 0;
+    return pool_ws_bytes(N, HW, C, dtype == DFD_BF16 ? Vec<bf16>::N : Vec<float>::N);
+}
+
 template <typename T, bool BWD>
 static int pool_t(const void* D, const void* y, const float* bnstate, int act, float* out, int N, int HW, int C,
-                  hipStream_t st) {
+                  void* ws, size_t ws_bytes, hipStream_t st) {
     const ChanMap cm = make_chanmap(C, Vec<T>::N);
-    dim3 grid(cm.nvc, N);
+    int splits = 1, rows_per = HW;
+    if (ws) {
+        pool_plan(N, HW, C, Vec<T>::N, &splits, &rows_per);
+        if (splits > 1 && pool_ws_bytes(N, HW, C, Vec<T>::N) > ws_bytes) return DFD_EWORKSPACE;
+    }
+    float* parts = splits > 1 ? (float*)ws : nullptr;
+    dim3 grid(cm.nvc, N, splits);
     const float mul = BWD ? 1.0f : 1.0f / (float)HW;
     DISPATCH_ACT(act, {
         hipLaunchKernelGGL((k_pool<T, ACT, BWD>), grid, dim3(DFD_THREADS), 0, st, (const T*)D, (const T*)y, bnstate, out, HW,
-                           C, mul, cm);
+                           C, mul, cm, rows_per, parts);
     });
+    if (splits > 1) {
+        const long NC = (long)N * C;
+        hipLaunchKernelGGL(k_pool_sum, dim3((unsigned)((NC + 255) / 256)), dim3(256), 0, st, parts, splits, NC, mul, out);
+    }
     return DFD_CHECK_LAUNCH();
 }
 extern "C" int dfd_pool_act(int dtype, const void* y, const float* bnstate, int act, float* pooled, int N, int HW,
-                            int C, dfd_stream stream) {
+                            int C, void* ws, size_t ws_bytes, dfd_stream stream) {
     if (!shape_ok(dtype, N, HW, C) || !y || !bnstate || !pooled) return DFD_EINVAL;
     hipStream_t st = (hipStream_t)stream;
-    return dtype == DFD_BF16 ? pool_t<bf16, false>(nullptr, y, bnstate, act, pooled, N, HW, C, st)
-                             : pool_t<float, false>(nullptr, y, bnstate, act, pooled, N, HW, C, st);
+    return dtype == DFD_BF16 ? pool_t<bf16, false>(nullptr, y, bnstate, act, pooled, N, HW, C, ws, ws_bytes, st)
+                             : pool_t<float, false>(nullptr, y, bnstate, act, pooled, N, HW, C, ws, ws_bytes, st);
 }
 extern "C" int dfd_pool_bwd_reduce(int dtype, const void* D, const void* y, const float* bnstate, int act,
-                                   float* dgate, int N, int HW, int C, dfd_stream stream) {
+                                   float* dgate, int N, int HW, int C, void* ws, size_t ws_bytes, dfd_stream stream) {
     if (!shape_ok(dtype, N, HW, C) || !D || !y || !bnstate || !dgate) return DFD_EINVAL;
     hipStream_t st = (hipStream_t)stream;
-    return dtype == DFD_BF16 ? pool_t<bf16, true>(D, y, bnstate, act, dgate, N, HW, C, st)
-                             : pool_t<float, true>(D, y, bnstate, act, dgate, N, HW, C, st);
+    return dtype == DFD_BF16 ? pool_t<bf16, true>(D, y, bnstate, act, dgate, N, HW, C, ws, ws_bytes, st)
+                             : pool_t<float, true>(D, y, bnstate, act, dgate, N, HW, C, ws, ws_bytes, st);
 }
 
 extern "C" int dfd_bn_finalize(const float* partials, int nparts, int C, double count, const float* gamma,

@@ -153,11 +153,28 @@ def act_bn_bwd(D: torch.Tensor | None, y: torch.Tensor, gate: torch.Tensor | Non
     return dz, parts, n.value
 
 
+_pool_ws: dict[int, torch.Tensor] = {}
+
+
+def _pool_workspace(y: torch.Tensor, N: int, HW: int, C: int) -> tuple[int, int]:
+    """(pointer, bytes) of the pooling workspace (partial vectors of the H*W splits), one per device."""
+    nbytes = int(_L().dfd_pool_ws(_dt(y), N, HW, C))
+    if nbytes == 0:
+        return 0, 0
+    key = y.device.index if y.device.index is not None else torch.cuda.current_device()
+    buf = _pool_ws.get(key)
+    if buf is None or buf.numel() * 4 < nbytes:
+        buf = torch.zeros((nbytes + 3) // 4, dtype=torch.float32, device=y.device)
+        _pool_ws[key] = buf
+    return buf.data_ptr(), buf.numel() * 4
+
+
 def pool_act(y: torch.Tensor, state: torch.Tensor, act: int) -> torch.Tensor:
     _chk_nhwc(y)
     N, H, W, C = y.shape
     pooled = torch.empty((N, C), dtype=torch.float32, device=y.device)
-    check(_L().dfd_pool_act(_dt(y), _p(y), _p(state), act, _p(pooled), N, H * W, C, _stream()), "dfd_pool_act")
+    ws, ws_bytes = _pool_workspace(y, N, H * W, C)
+    check(_L().dfd_pool_act(_dt(y), _p(y), _p(state), act, _p(pooled), N, H * W, C, ws, ws_bytes, _stream()), "dfd_pool_act")
     return pooled
 
 
@@ -165,7 +182,8 @@ def pool_bwd_reduce(D: torch.Tensor, y: torch.Tensor, state: torch.Tensor, act: 
     _chk_nhwc(y)
     N, H, W, C = y.shape
     dgate = torch.empty((N, C), dtype=torch.float32, device=y.device)
-    check(_L().dfd_pool_bwd_reduce(_dt(y), _p(D), _p(y), _p(state), act, _p(dgate), N, H * W, C, _stream()),
+    ws, ws_bytes = _pool_workspace(y, N, H * W, C)
+    check(_L().dfd_pool_bwd_reduce(_dt(y), _p(D), _p(y), _p(state), act, _p(dgate), N, H * W, C, ws, ws_bytes, _stream()),
           "dfd_pool_bwd_reduce")
     return dgate
 

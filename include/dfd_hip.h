@@ -99,12 +99,17 @@ int dfd_act_bn_bwd(int dtype, const void* D, const void* y, const float* gate,
                    int N, int HW, int C, float* partials, int pcap, int* nparts,
                    dfd_stream stream);
 /* pooled[n,c] = mean_hw act(scale*y+shift): SE squeeze and the classifier's
- * global average pool.                                                           */
+ * global average pool.
+ * ws (optional, may be NULL): dfd_pool_ws() bytes of scratch; lets the library split large
+ * images over several workgroups (partial vectors, summed in a fixed order by a second
+ * small kernel).  No initial contents required.                                          */
+size_t dfd_pool_ws(int dtype, int N, int HW, int C);
 int dfd_pool_act(int dtype, const void* y, const float* bnstate, int act, float* pooled,
-                 int N, int HW, int C, dfd_stream stream);
+                 int N, int HW, int C, void* ws, size_t ws_bytes, dfd_stream stream);
 /* dgate[n,c] = sum_hw D * act(scale*y+shift)                                      */
 int dfd_pool_bwd_reduce(int dtype, const void* D, const void* y, const float* bnstate,
-                        int act, float* dgate, int N, int HW, int C, dfd_stream stream);
+                        int act, float* dgate, int N, int HW, int C, void* ws, size_t ws_bytes,
+                        dfd_stream stream);
 /* out = x * row_scale[n] (drop-connect on the gradient side)                      */
 int dfd_scale_rows(int dtype, const void* x, const float* row_scale, void* out,
                    int N, int HW, int C, dfd_stream stream);

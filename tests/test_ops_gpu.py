@@ -261,6 +261,24 @@ def test_rowpass(case, rd):
     close(K.pool_bwd_reduce(dev(g), dev(y), dev(st), R.ACT_SILU), (a * g.float()).sum((1, 2)), 2e-3, "pool_bwd")
     close(K.scale_rows(dev(g), dev(rs)), R.rnd(g.float() * rs[:, None, None, None], rd), tol(rd), "scale_rows")
 
+@pytest.mark.parametrize("rd", DT)
+def test_pool_split_over_workgroups(rd):
+    """Images large enough that the pooling kernels split H*W over several workgroups (partial
+    vectors + last-arrival sum); repeated calls must leave the arrival counters re-armed."""
+    K = _k()
+    N, H, W, C = 3, 56, 56, 96
+    y, g = gen((N, H, W, C), 91, rd), gen((N, H, W, C), 92, rd)
+    st = torch.zeros((4, C))
+    st[0] = torch.rand(C, generator=torch.Generator().manual_seed(93)) + 0.5
+    st[1] = torch.randn(C, generator=torch.Generator().manual_seed(94)) * 0.1
+    st[3] = 1.0
+    assert int(K._L().dfd_pool_ws(K._dt(dev(y)), N, H * W, C)) > 0, "shape was meant to trigger the split path"
+    z = y.float() * st[0] + st[1]
+    a = R.rnd(R.act_fwd(z, 1), rd)
+    for _ in range(3):
+        close(K.pool_act(dev(y), dev(st), R.ACT_SILU), a.mean((1, 2)), 1e-3, "pool_act split")
+        close(K.pool_bwd_reduce(dev(g), dev(y), dev(st), R.ACT_SILU), (a * g.float()).sum((1, 2)), 2e-3, "pool_bwd split")
+
 
 @pytest.mark.parametrize("case", [(4, 32, 8), (3, 1152, 48), (2, 96, 4), (5, 2304, 96)])
 def test_bn_finalize_and_eval(case):
