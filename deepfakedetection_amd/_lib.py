@@ -10,7 +10,10 @@ import ctypes
 from ctypes import POINTER, Structure, c_double, c_float, c_int, c_int64, c_size_t, c_void_p
 from pathlib import Path
 
-LIB_PATH = Path(__file__).resolve().parent / "libdfd_hip.so"
+import os as _os
+
+# DFD_LIB_PATH: load another build of the same library (kernel timing experiments)
+LIB_PATH = Path(_os.environ.get("DFD_LIB_PATH") or Path(__file__).resolve().parent / "libdfd_hip.so")
 
 DFD_OK = 0
 ERRORS = {-1: "DFD_EINVAL", -2: "DFD_EUNSUPPORTED", -3: "DFD_ELAUNCH", -4: "DFD_EWORKSPACE"}

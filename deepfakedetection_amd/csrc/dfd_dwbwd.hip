@@ -84,10 +84,12 @@ k_dw_bwd_data_q(const T* __restrict__ dz, const T* __restrict__ yraw, const floa
     float* wl = reinterpret_cast<float*>(smem + tile_bytes);      // [tap][cvb*V]
     float* cf = wl + K * K * cvbV;                                // ka, kb, kc, scale, shift : [5][cvb*V]
     const int t = threadIdx.x, vl = t & (cvb - 1), lane = t >> g.cvb_log2;
-    const int vglob = blockIdx.x * cvb + vl;
+    int bx, by;
+    dwq_block(bx, by, g.remap);
+    const int vglob = bx * cvb + vl;
     const bool cvalid = vglob < g.CV;
     const int c0 = vglob * V;
-    const int chunk_c0 = blockIdx.x * cvbV;
+    const int chunk_c0 = bx * cvbV;
 
     for (int i = t; i < K * K * cvbV; i += DFD_THREADS) {
         const int tap = i / cvbV, cc = i - tap * cvbV;
@@ -109,7 +111,7 @@ k_dw_bwd_data_q(const T* __restrict__ dz, const T* __restrict__ yraw, const floa
     for (int j = 0; j < N2; ++j) { s1[j] = (f2){0.f, 0.f}; s2[j] = (f2){0.f, 0.f}; }
 
     const int tiles = g.tiles_y * g.tiles_x, TW = 4 * g.QW;
-    for (int work = blockIdx.y; work < g.nwork; work += gridDim.y) {
+    for (int work = by; work < g.nwork; work += gridDim.y) {
         const int n = work / tiles, tr = work - n * tiles;
         const int ty = tr / g.tiles_x, tx = tr - ty * g.tiles_x;
         const int h0 = ty * g.TH, w0 = tx * TW;
@@ -212,7 +214,7 @@ k_dw_bwd_data_q(const T* __restrict__ dz, const T* __restrict__ yraw, const floa
         }
         reduce_rowlanes<2 * V>(acc2, reinterpret_cast<float*>(smem), cvb, PL, vl, lane, true);
         if (lane == 0 && cvalid) {
-            float* p = partials + (long)blockIdx.y * 2 * g.C;
+            float* p = partials + (long)by * 2 * g.C;
             float a0[V], a1[V];
 #pragma unroll
             for (int j = 0; j < V; ++j) { a0[j] = acc2[j]; a1[j] = acc2[V + j]; }
@@ -231,6 +233,8 @@ static int dw_bwd_data_q_t(const void* dz, const void* y, const float* coef, con
     const int kk = s ? s->k * s->k : 0;
     if (!dfd_dwq_geom(s, V, 16, true, (size_t)(kk + 5) * 16 * V * 4, 0, 1, &g, &tile_bytes)) return DFD_EINVAL;
     const int cvb = 1 << g.cvb_log2, nchunks = (g.CV + cvb - 1) / cvb;
+    // chunk-workgroups share cache lines unless both the pixel stride and the chunk width are whole lines
+    g.remap = (s->stride == 1 && nchunks > 1 && ((s->C * (int)sizeof(T)) % 128 != 0 || (cvb * 16) % 128 != 0)) ? 1 : 0;
     const bool epi = xin != nullptr, hc = coef != nullptr;
     if (epi && (!in_bnstate || !partials || !nparts || pcap < 1)) return DFD_EINVAL;
     if (hc && !y) return DFD_EINVAL;
@@ -299,9 +303,11 @@ k_dw_bwd_weight_q(const T* __restrict__ dz, const T* __restrict__ yraw, const fl
     uint4* dyt = reinterpret_cast<uint4*>(smem + tile_bytes);                  // dy, [TH][TW][cvb]
     float* cf = reinterpret_cast<float*>(smem + tile_bytes + (size_t)g.TH * TW * cvb * 16);   // ka, kb, kc [3][cvbV]
     const int t = threadIdx.x, vl = t & (cvb - 1), lane = t >> g.cvb_log2;
-    const int vglob = blockIdx.x * cvb + vl;
+    int bx, by;
+    dwq_block(bx, by, g.remap);
+    const int vglob = bx * cvb + vl;
     const bool cvalid = vglob < g.CV;
-    const int c0 = vglob * V, chunk_c0 = blockIdx.x * cvbV;
+    const int c0 = vglob * V, chunk_c0 = bx * cvbV;
     const int NPR = PL / K;                          // quad-walking lanes per kernel row
     const int kh = lane % K, prl = lane / K;
     const bool lane_on = prl < NPR;
@@ -323,7 +329,7 @@ k_dw_bwd_weight_q(const T* __restrict__ dz, const T* __restrict__ yraw, const fl
 
     const int tiles = g.tiles_y * g.tiles_x;
     const unsigned tw_magic = ((1u << 20) + TW - 1) / TW;
-    for (int work = blockIdx.y; work < g.nwork; work += gridDim.y) {
+    for (int work = by; work < g.nwork; work += gridDim.y) {
         const int n = work / tiles, tr = work - n * tiles;
         const int ty = tr / g.tiles_x, tx = tr - ty * g.tiles_x;
         const int oy0 = ty * g.TH, ox0 = tx * TW;
@@ -381,7 +387,7 @@ k_dw_bwd_weight_q(const T* __restrict__ dz, const T* __restrict__ yraw, const fl
     }
     __syncthreads();
     if (lane_on && prl == 0 && cvalid) {
-        float* p = partials + (long)blockIdx.y * g.C * K * K;
+        float* p = partials + (long)by * g.C * K * K;
 #pragma unroll
         for (int kw = 0; kw < K; ++kw)
 #pragma unroll
@@ -395,7 +401,10 @@ k_dw_bwd_weight_q(const T* __restrict__ dz, const T* __restrict__ yraw, const fl
 
 static bool dw_wgrad_q_geom(const dfd_dwconv_shape* s, int vec, DwQGeom* g, int* tile_bytes) {
     const int max_cvb = (s && s->k == 5) ? 8 : 16;          // needs 256/cvb >= K lanes per run
-    return dfd_dwq_geom(s, vec, max_cvb, false, (size_t)5 * 16 * vec * 4, 16, s ? s->k : 1, g, tile_bytes);
+    if (!dfd_dwq_geom(s, vec, max_cvb, false, (size_t)5 * 16 * vec * 4, 16, s ? s->k : 1, g, tile_bytes)) return false;
+    const int cvb = 1 << g->cvb_log2, nchunks = (g->CV + cvb - 1) / cvb, esz = vec == 8 ? 2 : 4;
+    g->remap = (nchunks > 1 && ((s->C * esz) % 128 != 0 || (cvb * 16) % 128 != 0)) ? 1 : 0;
+    return true;
 }
 
 static int dw_wgrad_q_parts(const DwQGeom& g, int k, int nchunks) {

@@ -26,18 +26,20 @@ k_dw_fwd_q(const T* __restrict__ x, const float* __restrict__ bnstate, const flo
     float* wl = reinterpret_cast<float*>(smem + tile_bytes);      // [tap][cvb*V] f32, rounded to T
     const int cvb = 1 << g.cvb_log2, PL = DFD_THREADS >> g.cvb_log2;
     const int t = threadIdx.x, vl = t & (cvb - 1), lane = t >> g.cvb_log2;
-    const int vglob = blockIdx.x * cvb + vl;           // channel chunk is the FAST grid index:
+    int bx, by;
+    dwq_block(bx, by, g.remap);
+    const int vglob = bx * cvb + vl;           // channel chunk is the FAST grid index:
     const bool cvalid = vglob < g.CV;                  // neighbouring chunks of one tile run together
     const int c0 = vglob * V;
 
     for (int i = t; i < K * K * cvb * V; i += DFD_THREADS) {
         const int tap = i / (cvb * V), cc = i - tap * (cvb * V);
-        const int c = blockIdx.x * cvb * V + cc;
+        const int c = bx * cvb * V + cc;
         wl[i] = c < g.C ? round_to<T>(w[(long)c * K * K + tap]) : 0.f;
     }
     float* cf = wl + K * K * cvb * V;                              // scale, shift : [2][cvb*V]
     for (int i = t; i < 2 * cvb * V; i += DFD_THREADS) {
-        const int which = i / (cvb * V), cc = i - which * (cvb * V), c = blockIdx.x * cvb * V + cc;
+        const int which = i / (cvb * V), cc = i - which * (cvb * V), c = bx * cvb * V + cc;
         cf[i] = (PRO && c < g.C) ? bnstate[which * g.C + c] : (which == 0 ? 1.f : 0.f);
     }
     f2 s1[N2], s2[N2];
@@ -45,7 +47,7 @@ k_dw_fwd_q(const T* __restrict__ x, const float* __restrict__ bnstate, const flo
     for (int j = 0; j < N2; ++j) { s1[j] = (f2){0.f, 0.f}; s2[j] = (f2){0.f, 0.f}; }
 
     const int tiles = g.tiles_y * g.tiles_x, TW = 4 * g.QW;
-    for (int work = blockIdx.y; work < g.nwork; work += gridDim.y) {
+    for (int work = by; work < g.nwork; work += gridDim.y) {
         const int n = work / tiles, tr = work - n * tiles;
         const int ty = tr / g.tiles_x, tx = tr - ty * g.tiles_x;
         const int oy0 = ty * g.TH, ox0 = tx * TW;
@@ -123,7 +125,7 @@ k_dw_fwd_q(const T* __restrict__ x, const float* __restrict__ bnstate, const flo
         }
         reduce_rowlanes<2 * V>(acc2, reinterpret_cast<float*>(smem), cvb, PL, vl, lane, true);
         if (lane == 0 && cvalid) {
-            float* p = partials + (long)blockIdx.y * 2 * g.C;
+            float* p = partials + (long)by * 2 * g.C;
             float a0[V], a1[V];
 #pragma unroll
             for (int j = 0; j < V; ++j) { a0[j] = acc2[j]; a1[j] = acc2[V + j]; }
@@ -189,6 +191,7 @@ bool dfd_dwq_geom(const dfd_dwconv_shape* s, int vec, int max_cvb, bool centre_i
     g->tiles_x = (CW + 4 * bQW - 1) / (4 * bQW);
     g->nwork = s->N * g->tiles_y * g->tiles_x;
     *tile_bytes = g->IH * g->IW * cvb * 16;
+    g->remap = 0;
     return true;
 }
 
