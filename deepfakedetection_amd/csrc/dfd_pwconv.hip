@@ -317,10 +317,18 @@ k_pw_tn(const T* __restrict__ p, ProArgs pp, int Ni, const T* __restrict__ q, Pr
     constexpr int NPASS = BMK / RPP;                         // 4
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
-    const int tile_id = blockIdx.x;
+    // XCD-aware order: the output tiles of one row split read the same rows of p and q, so they
+    // go to one XCD (one L2), back to back; consecutive hardware ids are dealt over the 8 XCDs
+    int tile_id = blockIdx.x, split = blockIdx.y;
+    if (gridDim.x > 1) {
+        const int nx = gridDim.x, total = nx * gridDim.y, lin = blockIdx.y * nx + blockIdx.x;
+        const int q8 = total >> 3, r8 = total & 7, xcd = lin & 7, sl = lin >> 3;
+        const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + sl;
+        split = logical / nx;
+        tile_id = logical - split * nx;
+    }
     const int it = tile_id / j_tiles, jt = tile_id - it * j_tiles;
     const int i0 = it * TN_B, j0 = jt * TN_B;
-    const int split = blockIdx.y;
     const int mbeg = split * rows_per_split;
     int mend = mbeg + rows_per_split;
     if (mend > M) mend = M;
