@@ -235,28 +235,50 @@ k_stem_fwd(const float* __restrict__ x, const float* __restrict__ w, T* __restri
             const long tq = pix / s.Wo;
             const int oy = (int)(tq % s.Ho);
             const long n = tq / s.Ho;
-            float acc[V];
+            // packed float2 accumulators (v_pk_fma_f32); a kernel row of an interior pixel is nine
+            // contiguous floats, fetched as two 16-byte loads and one 4-byte load
+            typedef float f2v __attribute__((ext_vector_type(2)));
+            f2v acc2[V / 2];
 #pragma unroll
-            for (int j = 0; j < V; ++j) acc[j] = 0.f;
+            for (int j = 0; j < V / 2; ++j) acc2[j] = (f2v){0.f, 0.f};
+            const int ix0 = ox * s.stride - s.pad_left;
+            const bool row_inside = ix0 >= 0 && ix0 + K <= s.W && K == 3;
 #pragma unroll
             for (int kh = 0; kh < K; ++kh) {
                 const int iy = oy * s.stride - s.pad_top + kh;
                 if (iy < 0 || iy >= s.H) continue;
+                float xr[3 * K];
+                const float* prow = x + ((n * s.H + iy) * (long)s.W + ix0) * 3;
+                if (row_inside) {
+                    struct __attribute__((packed, aligned(4))) F4 { float a, b, c, d; };
+                    const F4 q0 = *reinterpret_cast<const F4*>(prow), q1 = *reinterpret_cast<const F4*>(prow + 4);
+                    xr[0] = q0.a; xr[1] = q0.b; xr[2] = q0.c; xr[3] = q0.d;
+                    xr[4] = q1.a; xr[5] = q1.b; xr[6] = q1.c; xr[7] = q1.d;
+                    xr[8] = prow[8];
+                } else {
 #pragma unroll
-                for (int kw = 0; kw < K; ++kw) {
-                    const int ix = ox * s.stride - s.pad_left + kw;
-                    if (ix < 0 || ix >= s.W) continue;
-                    const float* px = x + ((n * s.H + iy) * (long)s.W + ix) * 3;
+                    for (int kw = 0; kw < K; ++kw) {
+                        const int ix = ix0 + kw;
+                        const bool ok = ix >= 0 && ix < s.W;
 #pragma unroll
-                    for (int ci = 0; ci < 3; ++ci) {
-                        const float xv = round_to<T>(px[ci]);
-                        float wv[V];
-                        load_f32<V>(wl + ((ci * K + kh) * K + kw) * Co + c0, wv);
-#pragma unroll
-                        for (int j = 0; j < V; ++j) acc[j] = fmaf(xv, wv[j], acc[j]);
+                        for (int ci = 0; ci < 3; ++ci) xr[kw * 3 + ci] = ok ? prow[kw * 3 + ci] : 0.f;
                     }
                 }
+#pragma unroll
+                for (int kw = 0; kw < K; ++kw)
+#pragma unroll
+                    for (int ci = 0; ci < 3; ++ci) {
+                        const float xv = round_to<T>(xr[kw * 3 + ci]);
+                        const f2v xx = (f2v){xv, xv};
+                        const float* wp = wl + ((ci * K + kh) * K + kw) * Co + c0;
+#pragma unroll
+                        for (int j = 0; j < V / 2; ++j)
+                            acc2[j] = __builtin_elementwise_fma(xx, *reinterpret_cast<const f2v*>(wp + 2 * j), acc2[j]);
+                    }
             }
+            float acc[V];
+#pragma unroll
+            for (int j = 0; j < V / 2; ++j) { acc[2 * j] = acc2[j].x; acc[2 * j + 1] = acc2[j].y; }
 #pragma unroll
             for (int j = 0; j < V; ++j) {
                 const float r = round_to<T>(acc[j]);

@@ -14,8 +14,11 @@ k_bn_act_apply(const T* __restrict__ y, const float* __restrict__ bnstate, const
                const float* __restrict__ rs, T* __restrict__ out, long total_vec, int CV, int C, long vec_per_img) {
     constexpr int V = Vec<T>::N;
     const long stride = (long)gridDim.x * DFD_THREADS;
-    for (long i = (long)blockIdx.x * DFD_THREADS + threadIdx.x; i < total_vec; i += stride) {
-        const int c0 = (int)(i % CV) * V;
+    const long first = (long)blockIdx.x * DFD_THREADS + threadIdx.x;
+    int cv = (int)(first % CV);                       // channel vector of element i, kept incrementally
+    const int cstep = (int)(stride % CV);
+    for (long i = first; i < total_vec; i += stride, cv = cv + cstep >= CV ? cv + cstep - CV : cv + cstep) {
+        const int c0 = cv * V;
         float v[V], sc[V], sh[V];
         Vec<T>::load(y + i * V, v);
         load_f32<V>(bnstate + c0, sc);
@@ -69,7 +72,28 @@ k_bn_bwd_reduce(const T* __restrict__ g, const T* __restrict__ y, const float* _
     for (int j = 0; j < 2 * V; ++j) acc[j] = 0.f;
     if (active) {
         const long step = (long)gridDim.x * cm.rpb;
-        for (long r = (long)blockIdx.x * cm.rpb + rl; r < rows; r += step) {
+        long r = (long)blockIdx.x * cm.rpb + rl;
+        // four rows (eight vectors) in flight per lane
+        for (; r + 3 * step < rows; r += 4 * step) {
+            float gv[4][V], yv[4][V], sv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                Vec<T>::load(g + (r + u * step) * C + c0, gv[u]);
+                Vec<T>::load(y + (r + u * step) * C + c0, yv[u]);
+                sv[u] = 1.f;
+                if constexpr (HAS_RS) sv[u] = rs[(r + u * step) / HW];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int j = 0; j < V; ++j) {
+                    float gg = gv[u][j];
+                    if constexpr (HAS_RS) gg *= sv[u];
+                    acc[j] += gg;
+                    acc[V + j] += gg * (yv[u][j] - mean[j]) * rstd[j];
+                }
+        }
+        for (; r < rows; r += step) {
             float gv[V], yv[V];
             Vec<T>::load(g + r * C + c0, gv);
             Vec<T>::load(y + r * C + c0, yv);
