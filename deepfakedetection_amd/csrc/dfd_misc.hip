@@ -336,6 +336,10 @@ k_stem_wgrad(const float* __restrict__ x, const T* __restrict__ dz, const T* __r
     const long npix = (long)s.N * s.Ho * s.Wo;
     const int CV = Co / V;
     for (long base = (long)blockIdx.x * STEM_CHUNK; base < npix; base += (long)gridDim.x * STEM_CHUNK) {
+        const int ox_b = (int)(base % s.Wo);
+        const long tq_b = base / s.Wo;
+        const int oy_b = (int)(tq_b % s.Ho);
+        const long n_b = tq_b / s.Ho;
         __syncthreads();
         for (int i = t; i < STEM_CHUNK * CV; i += DFD_THREADS) {
             const int p = i / CV, v = i - p * CV;
@@ -364,10 +368,14 @@ k_stem_wgrad(const float* __restrict__ x, const T* __restrict__ dz, const T* __r
 #pragma unroll
             for (int j = 0; j < 3 * K; ++j) v[j] = 0.f;
             if (pix < npix) {
-                const int ox = (int)(pix % s.Wo);
-                const long tq = pix / s.Wo;
-                const int oy = (int)(tq % s.Ho);
-                const long n = tq / s.Ho;
+                // (n, oy, ox) of the chunk's first pixel are wave-uniform (scalar divisions, once per
+                // chunk); the item's offset p < 128 is folded in with small 32-bit arithmetic
+                const unsigned lin = (unsigned)ox_b + (unsigned)p;
+                const unsigned dy_ = lin / (unsigned)s.Wo;                   // 32-bit, lin < Wo + STEM_CHUNK
+                const int ox = (int)(lin - dy_ * (unsigned)s.Wo);
+                int oy = oy_b + (int)dy_;
+                long n = n_b;
+                while (oy >= s.Ho) { oy -= s.Ho; ++n; }
                 const int iy = oy * s.stride - s.pad_top + kh, ix0 = ox * s.stride - s.pad_left;
                 if (iy >= 0 && iy < s.H) {
                     const float* row = x + ((n * s.H + iy) * (long)s.W) * 3;
@@ -394,11 +402,18 @@ k_stem_wgrad(const float* __restrict__ x, const T* __restrict__ dz, const T* __r
                 const float4 xa = *reinterpret_cast<const float4*>(sx + p * STEM_TAPP + tg * 8);
                 const float4 xb = *reinterpret_cast<const float4*>(sx + p * STEM_TAPP + tg * 8 + 4);
                 const float dv[4] = {d.x, d.y, d.z, d.w};
-                const float xv[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
+                typedef float f2v __attribute__((ext_vector_type(2)));
+                const f2v xp[4] = {(f2v){xa.x, xa.y}, (f2v){xa.z, xa.w}, (f2v){xb.x, xb.y}, (f2v){xb.z, xb.w}};
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < 4; ++i) {
+                    const f2v dd = (f2v){dv[i], dv[i]};
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) acc[i][j] = fmaf(dv[i], xv[j], acc[i][j]);
+                    for (int j = 0; j < 4; ++j) {
+                        f2v a = (f2v){acc[i][2 * j], acc[i][2 * j + 1]};
+                        a = __builtin_elementwise_fma(dd, xp[j], a);
+                        acc[i][2 * j] = a.x; acc[i][2 * j + 1] = a.y;
+                    }
+                }
             }
         }
     }
