@@ -51,16 +51,43 @@ def parse() -> argparse.Namespace:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=16)
     ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--cpu-timeout", type=int, default=150, help="seconds granted to the CPU baseline child process")
+    ap.add_argument("--cpu-baseline-only", action="store_true", help="(internal) measure the CPU oracle and print its JSON")
     ap.add_argument("--profile-steps", type=int, default=2)
     return ap.parse_args()
 
 
-def cpu_baseline(args) -> dict:
-    """Oracle train step on the host cores; bounded sample, ~10-30 s."""
+def usable_cores() -> int:
+    """CPU cores this process may actually use: affinity mask and cgroup quota, not the host's count
+    (a GPU box exposes hundreds of host CPUs to os.cpu_count() while the container owns a few)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = Path(path).read_text().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                quota = int(txt[0])
+                period = int(Path("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read_text())
+                if quota > 0:
+                    n = min(n, max(1, quota // period))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return max(1, min(n, 64))
+
+
+def cpu_baseline_measure(args) -> dict:
+    """Oracle train step on the host cores; bounded sample, ~10-30 s.  Runs in a CHILD process
+    (see cpu_baseline) so that it can be time-boxed and never shares threads with the GPU run."""
+    cores = usable_cores()
+    torch.set_num_threads(cores)
     from oracle.effnet_ref import EfficientNetRef, train_step_ref
 
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
     torch.manual_seed(0)
     model = EfficientNetRef(args.variant, args.flavour, args.classes).to(memory_format=torch.channels_last)
     opt = torch.optim.AdamW(model.parameters(), lr=1e-4, weight_decay=5e-2)
@@ -79,8 +106,38 @@ def cpu_baseline(args) -> dict:
                       f"batch {args.cpu_batch} @{args.size}px, median of {args.cpu_steps} steps after 1 warm-up"}
 
 
+def cpu_baseline(args) -> dict:
+    """Time-boxed: the measurement runs as `bench.py --cpu-baseline-only` in a child process."""
+    import subprocess
+
+    cmd = [sys.executable, str(ROOT / "bench.py"), "--cpu-baseline-only", "--variant", args.variant, "--flavour", args.flavour,
+           "--classes", str(args.classes), "--size", str(args.size), "--cpu-batch", str(args.cpu_batch),
+           "--cpu-steps", str(args.cpu_steps)]
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    env["HIP_VISIBLE_DEVICES"] = ""          # the child is a pure CPU program
+    env["OMP_NUM_THREADS"] = str(usable_cores())
+    try:
+        proc = subprocess.run(cmd, capture_output=True, text=True, timeout=args.cpu_timeout, env=env)
+        for line in reversed(proc.stdout.strip().splitlines()):
+            if line.startswith("{"):
+                return json.loads(line)
+        note = f"child exited {proc.returncode}: {proc.stderr.strip()[-200:]}"
+    except subprocess.TimeoutExpired:
+        note = f"did not finish within {args.cpu_timeout} s"
+    return {"value": None, "unit": "images/sec", "cores": usable_cores(), "kind": "port", "sample": f"not measured ({note})"}
+
+
+def progress(msg: str) -> None:
+    print(f"[bench] {msg}", file=sys.stderr, flush=True)
+
+
 def main() -> None:
     args = parse()
+    if args.cpu_baseline_only:
+        print(json.dumps(cpu_baseline_measure(args)), flush=True)
+        return
     from deepfakedetection_amd import kernels as K
     from deepfakedetection_amd.dp import GradAllReducer, broadcast_module_state, init_distributed
     from deepfakedetection_amd.efficientnet import HipEfficientNet
@@ -206,6 +263,8 @@ def main() -> None:
         else:
             step_body()
 
+    if rank == 0:
+        progress(f"launch mode: {launch}; warm-up {args.warmup} steps, timing {args.steps} steps")
     for _ in range(args.warmup):
         run_step()
     torch.cuda.synchronize()
@@ -287,6 +346,7 @@ def main() -> None:
             "kernels": breakdown,
         }
         if world == 1 and not args.no_cpu_baseline:
+            progress(f"{value:.0f} images/sec measured; timing the CPU oracle on {usable_cores()} host cores (bounded)")
             line["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(line), flush=True)
     if world > 1:
