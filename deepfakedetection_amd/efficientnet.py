@@ -26,6 +26,7 @@ import warnings
 import torch
 from torch import nn
 
+from . import functions as F_
 from .arch import BlockPlan, NetPlan, efficientnet_plan
 from .functions import BNRef, HeadCtx, HeadFunction, MBConvCtx, MBConvFunction, StemCtx, StemFunction
 
@@ -208,12 +209,17 @@ class HipEfficientNet(nn.Module):
         """drop_masks / dropout_u let a test inject the stochastic-depth masks (already
         1/keep scaled, one [N] tensor or None per block) and the dropout uniforms."""
         _, _, _, head, head_bn, fc = self._parts()
-        h = self.forward_features_nhwc(x, drop_masks)
-        u = dropout_u
-        if u is None and self.training and self.drop_rate > 0 and drop_masks is None:
-            u = torch.rand((h.shape[0], head.out_channels), device=h.device, dtype=torch.float32)
-        cfg = HeadCtx(_bnref(head_bn), self.drop_rate, self.training)
-        return HeadFunction.apply(h, head.weight, head_bn.weight, head_bn.bias, fc.weight, fc.bias, u, cfg)
+        F_.begin_counter_batch()
+        try:
+            h = self.forward_features_nhwc(x, drop_masks)
+            u = dropout_u
+            if u is None and self.training and self.drop_rate > 0 and drop_masks is None:
+                u = torch.rand((h.shape[0], head.out_channels), device=h.device, dtype=torch.float32)
+            cfg = HeadCtx(_bnref(head_bn), self.drop_rate, self.training)
+            out = HeadFunction.apply(h, head.weight, head_bn.weight, head_bn.bias, fc.weight, fc.bias, u, cfg)
+        finally:
+            F_.end_counter_batch()
+        return out
 
 
 def build_efficientnet(name: str, num_classes: int) -> HipEfficientNet:

@@ -40,10 +40,30 @@ class BNRef:
         return K.BNParams(weight, bias, self.running_mean, self.running_var, self.momentum, self.eps)
 
 
+# When a whole network runs one forward pass, its 49 num_batches_tracked counters are bumped by ONE
+# multi-tensor launch at the end (HipEfficientNet.forward) instead of 49 five-microsecond kernels.
+_deferred_counters: list[torch.Tensor] | None = None
+
+
+def begin_counter_batch() -> None:
+    global _deferred_counters
+    _deferred_counters = []
+
+
+def end_counter_batch() -> None:
+    global _deferred_counters
+    pending, _deferred_counters = _deferred_counters, None
+    if pending:
+        torch._foreach_add_(pending, 1)
+
+
 def _bn_state(parts, nparts, count: int, bn: BNRef, weight, bias, training: bool) -> torch.Tensor:
     if training:
         if bn.num_batches_tracked is not None:
-            bn.num_batches_tracked.add_(1)
+            if _deferred_counters is not None:
+                _deferred_counters.append(bn.num_batches_tracked)
+            else:
+                bn.num_batches_tracked.add_(1)
         return K.bn_finalize(parts, nparts, count, bn.params(weight, bias))
     return K.bn_eval_coeffs(bn.params(weight, bias))
 
