@@ -128,7 +128,18 @@ static inline ProArgs pro_args(const dfd_prologue* p) {
 }
 
 
+// byte offset of 16-B chunk `ch` of row m in a bf16 [64][128] tile, swizzled for tr reads
+__device__ __forceinline__ int tn_off_bf16(int m, int ch) {
+    const int f = ((m & 3) | (((m >> 3) & 1) << 2)) << 1;
+    return m * 256 + ((ch ^ f) << 4);
+}
+
 // wave-autonomous NT kernel for layers whose weight panel stays resident in LDS (dfd_pwntw.hip);
 // returns DFD_EUNSUPPORTED when the shape does not qualify (the caller then uses the tiled kernel)
 int dfd_pw_ntw(int dtype, const void* a, const dfd_prologue* pro, const void* w, void* out, const void* residual, int M,
                int K, int Nout, float* partials, int pcap, int* nparts, hipStream_t st);
+
+// wave-autonomous TN (weight-gradient) kernel for large-M layers with a narrow and a wide operand
+// (dfd_pwtnw.hip, bf16 only); DFD_EUNSUPPORTED when the shape does not qualify
+int dfd_pw_tnw(const void* p, const dfd_prologue* pro_p, int Ni, const void* q, const dfd_prologue* pro_q, int Nj, int M,
+               float* dw, int accumulate, float* ws, size_t ws_bytes, hipStream_t st);

@@ -297,11 +297,6 @@ k_pw_nt(const T* __restrict__ a, ProArgs pa, const T* __restrict__ w, T* __restr
 // ===========================================================================
 #define TN_B 128   // output tile edge (channels of p and of q)
 
-// byte offset of 16-B chunk `ch` of row m in a bf16 [64][128] tile, swizzled for tr reads
-__device__ __forceinline__ int tn_off_bf16(int m, int ch) {
-    const int f = ((m & 3) | (((m >> 3) & 1) << 2)) << 1;
-    return m * 256 + ((ch ^ f) << 4);
-}
 #define TN_F32_ROW 576  // (128 + 16) floats: kq rows land on disjoint bank halves
 
 template <typename T, int PROP, int PROQ, int ACT>
@@ -671,6 +666,11 @@ extern "C" int dfd_pwconv_wgrad(int dtype, const void* p, const dfd_prologue* pr
     if (!p || !q || !dw || !ws || M < 1 || Ni < 8 || Nj < 8 || Ni % 8 || Nj % 8 || !pro_ok(pro_p) || !pro_ok(pro_q))
         return DFD_EINVAL;
     hipStream_t st = (hipStream_t)stream;
+    if (dtype == DFD_BF16) {
+        // large-M layers with a narrow operand: wave-autonomous kernel (dfd_pwtnw.hip)
+        const int rc = dfd_pw_tnw(p, pro_p, Ni, q, pro_q, Nj, M, dw, accumulate, ws, ws_bytes, st);
+        if (rc != DFD_EUNSUPPORTED) return rc;
+    }
     if (dtype == DFD_BF16) return pw_tn_t<bf16>(p, pro_p, Ni, q, pro_q, Nj, M, dw, accumulate, ws, ws_bytes, st);
     if (dtype == DFD_F32) return pw_tn_t<float>(p, pro_p, Ni, q, pro_q, Nj, M, dw, accumulate, ws, ws_bytes, st);
     return DFD_EINVAL;

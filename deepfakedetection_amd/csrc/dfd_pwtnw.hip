@@ -1,0 +1,303 @@
+// dfd_pwtnw.hip — 1x1 convolution weight gradient (TN form) for the large-M layers (bf16):
+//
+//     out[ia][jb] = sum_m A(a)[m][ia] * B(b)[m][jb]        a: narrow (<= 48 channels), b: wide (<= 144)
+//
+// EfficientNet blocks 0-3 (3.2M .. 200K rows, 16..40 x 32..144 channels).  The whole output fits a
+// wave's accumulators, so — as in the NT kernel of dfd_pwntw.hip — one wave is one independent stream:
+//   * a wave walks its own 32-row steps; per step it loads 32 rows of both operands (16-byte row
+//     chunks, everything of the NEXT step requested before the current step's MFMAs), applies the
+//     prologues (BN-backward affine map on either operand, BN + SiLU + SE gate on the wide one) and
+//     writes the rows into a wave-private LDS tile in the swizzled layout of the tiled TN kernel;
+//   * fragments are read back with ds_read_b64_tr_b16 (hardware transpose: 8 consecutive rows of one
+//     channel per lane) and fed to v_mfma_f32_16x16x32_bf16; the wide operand goes through its tile
+//     in column groups of 128 channels;
+//   * no workgroup barrier in the main loop; at the end the 4 waves add their accumulators in LDS in
+//     wave order (fixed order: reproducible) and the workgroup writes ONE partial slab, summed over
+//     workgroups by the same two-stage k_sum_partials as the tiled kernel.
+// Either operand may be the first GEMM operand: `swap` writes the slab transposed.
+#include "dfd_pw.h"
+
+// rows per wave step: 32 (v_mfma_f32_16x16x32_bf16) or, for the widest outputs where the accumulators
+// leave fewer registers for in-flight rows, 16 (v_mfma_f32_16x16x16_bf16)
+#define TNW_MIN_ROWS 16
+
+// PA: prologue of the narrow operand (NONE / AFFINE2); PB: of the wide one (NONE / AFFINE2 / BN_ACT_GATE)
+template <int ROWS, int NA, int NBT, int PA, int PB, int ACT>
+__global__ void __launch_bounds__(DFD_THREADS, 2)
+k_pw_tnw(const bf16* __restrict__ a, ProArgs pa, int Na, const bf16* __restrict__ b, ProArgs pb, int Nb, int M,
+         int rows_per_block, int swap, float* __restrict__ ws) {
+    constexpr int ITA = (ROWS * NA * 2 + 63) / 64;          // 16-byte items per lane and step
+    constexpr int ITB = (ROWS * NBT * 2 + 63) / 64;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    unsigned char* at = smem + wave * (2 * ROWS * 256);     // this wave's A tile, then its B tile
+    unsigned char* bt = at + ROWS * 256;
+    float* cl = reinterpret_cast<float*>(smem + 4 * 2 * ROWS * 256);      // coefficients: A 3*Na, B 3*Nb
+    const bf16* a2 = reinterpret_cast<const bf16*>(pa.a2);
+    const bf16* b2 = reinterpret_cast<const bf16*>(pb.a2);
+    const int ca = Na >> 3, cb = Nb >> 3;                       // 16-byte chunks per row
+
+    for (int i = t; i < 3 * Na; i += DFD_THREADS) cl[i] = (PA != DFD_PRO_NONE) ? pa.coef[i] : 0.f;
+    for (int i = t; i < 3 * Nb; i += DFD_THREADS) {
+        float v = 0.f;
+        if (PB == DFD_PRO_AFFINE2) v = pb.coef[i];
+        else if (PB != DFD_PRO_NONE && i < 2 * Nb) v = pb.coef[i];
+        cl[3 * Na + i] = v;
+    }
+    // chunks past the operand's width are never written: clear the tiles once so that partly valid
+    // 16-wide MFMA tiles read zeros there
+    for (int i = t; i < 4 * 2 * ROWS * 256 / 16; i += DFD_THREADS) reinterpret_cast<uint4*>(smem)[i] = make_uint4(0, 0, 0, 0);
+    __syncthreads();
+
+    // item -> (row, chunk) of this lane, fixed for the whole kernel
+    int ra[ITA], cha[ITA], rb[ITB], chb[ITB];
+#pragma unroll
+    for (int i = 0; i < ITA; ++i) {
+        const int idx = lane + 64 * i;
+        const bool ok = idx < ROWS * ca;
+        ra[i] = ok ? idx / ca : -1;
+        cha[i] = ok ? idx - ra[i] * ca : 0;
+    }
+#pragma unroll
+    for (int i = 0; i < ITB; ++i) {
+        const int idx = lane + 64 * i;
+        const bool ok = idx < ROWS * cb;
+        rb[i] = ok ? idx / cb : -1;
+        chb[i] = ok ? idx - rb[i] * cb : 0;
+    }
+
+    f32x4_t acc[NA][NBT];
+#pragma unroll
+    for (int x = 0; x < NA; ++x)
+#pragma unroll
+        for (int y = 0; y < NBT; ++y) acc[x][y] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    const int na = (Na + 15) >> 4, nbt = (Nb + 15) >> 4;        // valid 16-wide tiles
+
+    const int rows_per_wave = rows_per_block / 4;
+    const int mbeg = blockIdx.x * rows_per_block + wave * rows_per_wave;
+    int mend = mbeg + rows_per_wave;
+    if (mend > M) mend = M;
+
+    uint4 va[ITA], va2[ITA], vb[ITB], vb2[ITB];
+    auto g_load = [&](int m0) {
+#pragma unroll
+        for (int i = 0; i < ITA; ++i) {
+            va[i] = make_uint4(0, 0, 0, 0);
+            if (PA == DFD_PRO_AFFINE2) va2[i] = make_uint4(0, 0, 0, 0);
+            if (ra[i] >= 0 && m0 + ra[i] < mend) {
+                const long off = (long)(m0 + ra[i]) * Na + cha[i] * 8;
+                va[i] = *reinterpret_cast<const uint4*>(a + off);
+                if constexpr (PA == DFD_PRO_AFFINE2) va2[i] = *reinterpret_cast<const uint4*>(a2 + off);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < ITB; ++i) {
+            vb[i] = make_uint4(0, 0, 0, 0);
+            if (PB == DFD_PRO_AFFINE2) vb2[i] = make_uint4(0, 0, 0, 0);
+            if (rb[i] >= 0 && m0 + rb[i] < mend) {
+                const long off = (long)(m0 + rb[i]) * Nb + chb[i] * 8;
+                vb[i] = *reinterpret_cast<const uint4*>(b + off);
+                if constexpr (PB == DFD_PRO_AFFINE2) vb2[i] = *reinterpret_cast<const uint4*>(b2 + off);
+            }
+        }
+    };
+    // one operand item through its prologue
+    auto pro_item = [&](auto mode_tag, uint4 q, uint4 q2, const float* cf, int N, int ch, int m, const ProArgs& pr) -> uint4 {
+        constexpr int MODE = decltype(mode_tag)::value;
+        if constexpr (MODE == DFD_PRO_NONE) {
+            return q;
+        } else {
+            float v[8], c0[8], c1[8];
+            q_to_f(q, v);
+            load_f32<8>(cf + ch * 8, c0);
+            load_f32<8>(cf + N + ch * 8, c1);
+            if constexpr (MODE == DFD_PRO_AFFINE2) {
+                float v2[8], c2[8];
+                q_to_f(q2, v2);
+                load_f32<8>(cf + 2 * N + ch * 8, c2);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = fmaf(c0[j], v[j], fmaf(c1[j], v2[j], c2[j]));
+            } else {
+                float gt[8];
+                load_f32<8>(pr.gate + (long)pro_image(pr, m) * N + ch * 8, gt);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = round_to<bf16>(act_fwd<ACT>(fmaf(c0[j], v[j], c1[j]))) * gt[j];
+            }
+            return f_to_q(v);
+        }
+    };
+    // registers -> wave-private tiles (a whole; b one column group of 128 channels = 16 chunks)
+    auto s_store_a = [&](int m0) {
+#pragma unroll
+        for (int i = 0; i < ITA; ++i) {
+            if (ra[i] < 0) continue;
+            uint4 v = va[i];
+            if (PA != DFD_PRO_NONE && m0 + ra[i] < mend)
+                v = pro_item(std::integral_constant<int, PA>{}, va[i], va2[i], cl, Na, cha[i], m0 + ra[i], pa);
+            *reinterpret_cast<uint4*>(at + tn_off_bf16(ra[i], cha[i])) = v;
+        }
+    };
+    auto s_store_b = [&](int m0, int grp) {
+#pragma unroll
+        for (int i = 0; i < ITB; ++i) {
+            if (rb[i] < 0 || (chb[i] >> 4) != grp) continue;
+            uint4 v = vb[i];
+            if (PB != DFD_PRO_NONE && m0 + rb[i] < mend)
+                v = pro_item(std::integral_constant<int, PB>{}, vb[i], vb2[i], cl + 3 * Na, Nb, chb[i], m0 + rb[i], pb);
+            *reinterpret_cast<uint4*>(bt + tn_off_bf16(rb[i], chb[i] & 15)) = v;
+        }
+    };
+    auto wave_sync = [&]() {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    // transposed fragment of 16 channels starting at chunk `ch0` of a tile: 8 consecutive rows per lane
+    const int g = lane >> 4, li = lane & 15, qrow = li >> 2, pcol = li & 3;
+    auto frag = [&](const unsigned char* tile, int ch0) -> short8_t {
+        const int ch = ch0 + (pcol >> 1), sub = (pcol & 1) << 3;
+        if constexpr (ROWS == 32) {
+            const int m_lo = 8 * g + qrow, m_hi = m_lo + 4;
+            const short4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                (__attribute__((address_space(3))) short4_t*)(tile + tn_off_bf16(m_lo, ch) + sub));
+            const short4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                (__attribute__((address_space(3))) short4_t*)(tile + tn_off_bf16(m_hi, ch) + sub));
+            return (short8_t){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        } else {
+            const short4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                (__attribute__((address_space(3))) short4_t*)(tile + tn_off_bf16(4 * g + qrow, ch) + sub));
+            return (short8_t){lo[0], lo[1], lo[2], lo[3], 0, 0, 0, 0};
+        }
+    };
+    auto mma = [&](const short8_t& fx, const short8_t& fy, f32x4_t c) -> f32x4_t {
+        if constexpr (ROWS == 32) {
+            return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, fx), __builtin_bit_cast(bf16x8_t, fy), c, 0, 0, 0);
+        } else {
+            const short4_t x4 = (short4_t){fx[0], fx[1], fx[2], fx[3]}, y4 = (short4_t){fy[0], fy[1], fy[2], fy[3]};
+            return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(x4, y4, c, 0, 0, 0);
+        }
+    };
+
+    const int ngrp = (cb + 15) >> 4;
+    if (mbeg < mend) g_load(mbeg);
+    for (int m0 = mbeg; m0 < mend; m0 += ROWS) {
+        short8_t fa[NA];
+        s_store_a(m0);
+        s_store_b(m0, 0);
+        // group 1 (channels 128..) still sits in vb/vb2; it needs the B tile after group 0's reads
+        if (ngrp == 1 && m0 + ROWS < mend) g_load(m0 + ROWS);
+        wave_sync();
+#pragma unroll
+        for (int x = 0; x < NA; ++x)
+            if (x < na) fa[x] = frag(at, 2 * x);
+        for (int grp = 0; grp < ngrp; ++grp) {
+            if (grp > 0) {
+                wave_sync();                            // group grp-1's fragment reads are done
+                s_store_b(m0, grp);
+                if (grp == ngrp - 1 && m0 + ROWS < mend) g_load(m0 + ROWS);
+                wave_sync();
+            }
+#pragma unroll
+            for (int y = 0; y < NBT; ++y) {
+                if ((y >> 3) != grp || y >= nbt) continue;
+                const short8_t fb = frag(bt, 2 * (y & 7));
+#pragma unroll
+                for (int x = 0; x < NA; ++x)
+                    if (x < na)
+                        acc[x][y] = mma(fa[x], fb, acc[x][y]);
+            }
+        }
+        wave_sync();                                    // reads done before the next step's stores
+    }
+
+    // ---- add the four waves' accumulators in LDS in wave order, write one slab per workgroup
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);        // [NA*NBT][256] floats <= 27 KB
+    for (int w = 0; w < 4; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int x = 0; x < NA; ++x)
+#pragma unroll
+                for (int y = 0; y < NBT; ++y) {
+                    if (x >= na || y >= nbt) continue;
+                    float* r = red + ((x * NBT + y) * 64 + lane) * 4;
+                    float4 cur = w == 0 ? make_float4(0.f, 0.f, 0.f, 0.f) : *reinterpret_cast<float4*>(r);
+                    cur.x += acc[x][y][0]; cur.y += acc[x][y][1]; cur.z += acc[x][y][2]; cur.w += acc[x][y][3];
+                    *reinterpret_cast<float4*>(r) = cur;
+                }
+        }
+        __syncthreads();
+    }
+    // D layout: col (lane & 15) = wide index within the tile, rows 4*(lane>>4)+r = narrow index
+    float* o = ws + (long)blockIdx.x * Na * Nb;
+    for (int e = t; e < na * nbt * 256; e += DFD_THREADS) {
+        const int tile = e >> 8, l = (e >> 2) & 63, r = e & 3;
+        const int x = tile / nbt, y = tile - x * nbt;
+        const int ia = x * 16 + (l >> 4) * 4 + r, jb = y * 16 + (l & 15);
+        if (ia < Na && jb < Nb) {
+            const float v = red[((x * NBT + y) * 64 + l) * 4 + r];
+            if (swap) o[(long)jb * Na + ia] = v; else o[(long)ia * Nb + jb] = v;
+        }
+    }
+}
+
+// ===========================================================================
+// host dispatch
+// ===========================================================================
+static bool tnw_pro_ok(int mode_narrow, int mode_wide) {
+    return (mode_narrow == DFD_PRO_NONE || mode_narrow == DFD_PRO_AFFINE2) &&
+           (mode_wide == DFD_PRO_NONE || mode_wide == DFD_PRO_AFFINE2 || mode_wide == DFD_PRO_BN_ACT_GATE);
+}
+
+template <int ROWS, int NA, int NBT>
+static int tnw_launch(const void* a, const dfd_prologue* pro_a, int Na, const void* b, const dfd_prologue* pro_b, int Nb,
+                      int M, int swap, float* dw, int accumulate, float* ws, size_t ws_bytes, hipStream_t st) {
+    const ProArgs pa = pro_args(pro_a), pb = pro_args(pro_b);
+    const int ma = pro_a ? pro_a->mode : DFD_PRO_NONE, mb = pro_b ? pro_b->mode : DFD_PRO_NONE;
+    const int act = (mb == DFD_PRO_BN_ACT_GATE && pro_b) ? pro_b->act : DFD_ACT_NONE;
+    // 2 workgroups per CU (64 KB of tiles each); every wave should see several 32-row steps
+    int nblocks = 512;
+    int rpb = (M + nblocks - 1) / nblocks;
+    rpb = (rpb + 4 * ROWS - 1) / (4 * ROWS) * (4 * ROWS);
+    nblocks = (M + rpb - 1) / rpb;
+    if ((size_t)(nblocks + nblocks / 32 + 2) * Na * Nb * 4 > ws_bytes) return DFD_EUNSUPPORTED;
+    const int lds = 4 * 2 * ROWS * 256 + 3 * (Na + Nb) * 4;
+#define LAUNCH_TNW(PAV, PBV, ACTV)                                                                                     \
+    hipLaunchKernelGGL((k_pw_tnw<ROWS, NA, NBT, PAV, PBV, ACTV>), dim3(nblocks), dim3(DFD_THREADS), lds, st, (const bf16*)a, pa, \
+                       Na, (const bf16*)b, pb, Nb, M, rpb, swap, ws)
+    if (mb == DFD_PRO_BN_ACT_GATE) {
+        if (act != DFD_ACT_SILU) return DFD_EUNSUPPORTED;
+        if (ma == DFD_PRO_AFFINE2) LAUNCH_TNW(DFD_PRO_AFFINE2, DFD_PRO_BN_ACT_GATE, DFD_ACT_SILU);
+        else LAUNCH_TNW(DFD_PRO_NONE, DFD_PRO_BN_ACT_GATE, DFD_ACT_SILU);
+    } else if (mb == DFD_PRO_AFFINE2) {
+        if (ma == DFD_PRO_AFFINE2) return DFD_EUNSUPPORTED;
+        LAUNCH_TNW(DFD_PRO_NONE, DFD_PRO_AFFINE2, DFD_ACT_NONE);
+    } else {
+        if (ma == DFD_PRO_AFFINE2) LAUNCH_TNW(DFD_PRO_AFFINE2, DFD_PRO_NONE, DFD_ACT_NONE);
+        else LAUNCH_TNW(DFD_PRO_NONE, DFD_PRO_NONE, DFD_ACT_NONE);
+    }
+#undef LAUNCH_TNW
+    if (hipGetLastError() != hipSuccess) return DFD_ELAUNCH;
+    return dfd_launch_sum_partials(ws, nblocks, (long)Na * Nb, dw, accumulate, st);
+}
+
+int dfd_pw_tnw(const void* p, const dfd_prologue* pro_p, int Ni, const void* q, const dfd_prologue* pro_q, int Nj, int M,
+               float* dw, int accumulate, float* ws, size_t ws_bytes, hipStream_t st) {
+    // large M only: each of 2048 waves needs a few 32-row steps for the pipeline to matter
+    if (M < 2048 * 32 * 3) return DFD_EUNSUPPORTED;
+    const int mp = pro_p ? pro_p->mode : DFD_PRO_NONE, mq = pro_q ? pro_q->mode : DFD_PRO_NONE;
+    // narrow operand <= 48 channels, wide one <= 144; dw is [Ni][Nj]
+    const auto wide_ok = [](int n) { return n <= 128 || (n <= 144 && n % 16 == 0); };
+#define TNW_PICK(NARROW, WIDE, ...)                                             \
+    do {                                                                       \
+        if ((NARROW) <= 32 && (WIDE) <= 96) return tnw_launch<32, 2, 6>(__VA_ARGS__); \
+        if ((NARROW) <= 32) return tnw_launch<16, 2, 9>(__VA_ARGS__);               \
+        return DFD_EUNSUPPORTED;    /* 3 x 9 accumulator tiles spill at 2 waves per SIMD: tiled kernel */ \
+    } while (0)
+    if (Ni <= 48 && wide_ok(Nj) && Ni <= Nj && tnw_pro_ok(mp, mq))
+        TNW_PICK(Ni, Nj, p, pro_p, Ni, q, pro_q, Nj, M, 0, dw, accumulate, ws, ws_bytes, st);
+    if (Nj <= 48 && wide_ok(Ni) && tnw_pro_ok(mq, mp))
+        TNW_PICK(Nj, Ni, q, pro_q, Nj, p, pro_p, Ni, M, 1, dw, accumulate, ws, ws_bytes, st);
+#undef TNW_PICK
+    return DFD_EUNSUPPORTED;
+}

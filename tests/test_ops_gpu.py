@@ -206,6 +206,41 @@ def test_pwconv_wgrad(case, qmode, rd):
     got2 = K.pwconv_wgrad(dev(p), None, dev(q), pq)
     close(got2, want2.float(), 3e-3 if rd == torch.bfloat16 else 2e-4, "pwconv_wgrad plain p")
 
+# (N, HW, Ni, Nj): row counts above the wave-autonomous weight-gradient kernel's threshold (196,608 rows),
+# ragged so that the last 32-row steps and the last workgroup are partial
+TNW_CASES = [(4, 50000, 16, 32), (3, 70001, 24, 96), (4, 50003, 96, 16), (2, 100003, 32, 8), (3, 66001, 24, 144),
+             (3, 66003, 144, 24), (2, 99001, 8, 136)]
+
+
+@pytest.mark.parametrize("case", TNW_CASES)
+def test_pwconv_wgrad_large_m(case):
+    """bf16, M >= 196,608: the narrow x wide layers of EfficientNet blocks 0-1 run k_pw_tnw (wave-private
+    tiles, no workgroup barrier); both operand orders, every prologue the engine uses there."""
+    K = _k()
+    rd = torch.bfloat16
+    N, HW, Ni, Nj = case
+    p = gen((N, HW, 1, Ni), 61, rd, 0.5)
+    p2 = gen((N, HW, 1, Ni), 62, rd, 0.5)
+    q = gen((N, HW, 1, Nj), 63, rd, 0.5)
+    coef3 = rand_state(Ni, 64)[:3].contiguous()
+    st = rand_state(Nj, 65)
+    gate = torch.rand((N, Nj), generator=torch.Generator().manual_seed(66))
+    P = R.prologue(p.float().view(N, HW, Ni), 3, rd, coef=coef3, a2=p2.float().view(N, HW, Ni))
+    Qg = R.prologue(q.float().view(N, HW, Nj), 2, rd, R.ACT_SILU, st, gate=gate)
+    pro_p = K.pro_affine2(dev(p2), dev(coef3))
+    pro_g = K.pro_bn_act_gate(dev(st), R.ACT_SILU, dev(gate), HW)
+    # project-conv form: affine2 on p, BN + SiLU + gate on q
+    want = P.reshape(-1, Ni).t().double() @ Qg.reshape(-1, Nj).double()
+    close(K.pwconv_wgrad(dev(p), pro_p, dev(q), pro_g), want.float(), 4e-3, "wgrad affine2 x gate")
+    # expand-conv form: affine2 on p, raw q
+    want = P.reshape(-1, Ni).t().double() @ q.float().reshape(-1, Nj).double()
+    close(K.pwconv_wgrad(dev(p), pro_p, dev(q), None), want.float(), 4e-3, "wgrad affine2 x raw")
+    # no prologue at all, and repeatability (fixed-order reductions)
+    want = p.float().reshape(-1, Ni).t().double() @ q.float().reshape(-1, Nj).double()
+    got = K.pwconv_wgrad(dev(p), None, dev(q), None)
+    close(got, want.float(), 4e-3, "wgrad raw x raw")
+    assert torch.equal(got, K.pwconv_wgrad(dev(p), None, dev(q), None)), "weight gradient is not reproducible"
+
 
 ROW_CASES = [(2, 7, 7, 1152), (3, 14, 14, 40), (2, 28, 28, 144), (1, 56, 56, 24), (4, 5, 3, 672), (2, 7, 7, 1280)]
 
