@@ -24,23 +24,26 @@
 // ===========================================================================
 // LDS layout of the NT kernel: A double buffer at 0, then (past the epilogue overlay, so a
 // resident weight tile survives it) the B double buffer.
-template <typename T, int BN> struct NtLds {
-    static constexpr int A_BYTES = PW_BM * 128;
+template <typename T, int BN, int BM> struct NtLds {
+    static constexpr int A_BYTES = BM * 128;
     static constexpr int B_BYTES = BN * 128;
     static constexpr int OROW = BN * (int)sizeof(T) + 16;                   // epilogue row stride
-    static constexpr int OBYTES = PW_BM * OROW;
+    static constexpr int OBYTES = BM * OROW;
     static constexpr int BOFF = ((2 * A_BYTES > OBYTES ? 2 * A_BYTES : OBYTES) + 15) / 16 * 16;
     static constexpr int TOTAL = BOFF + 2 * B_BYTES;
 };
 
-template <typename T, int BN, int PRO, int ACT, bool RES, bool STATS>
+// BM = rows of a workgroup tile: 128, or 64 when M is so small that 128-row tiles leave CUs idle
+template <typename T, int BN, int BM, int PRO, int ACT, bool RES, bool STATS>
 __global__ void __launch_bounds__(DFD_THREADS, 2)
 k_pw_nt(const T* __restrict__ a, ProArgs pa, const T* __restrict__ w, T* __restrict__ out, const T* __restrict__ res,
         int M, int K, int Nout, int m_tiles, int n_tiles, int gx, float* __restrict__ partials) {
     constexpr int E = El<T>::EPC;
     constexpr int BK = El<T>::BK;
     constexpr int NTW = BN / 32;            // 16-wide n tiles per wave
-    using L = NtLds<T, BN>;
+    using L = NtLds<T, BN, BM>;
+    constexpr int RF = BM / 32;             // 16-row fragments per wave
+    constexpr int AI = BM / 32;             // A staging items per thread and K tile (BM rows x 8 chunks / 256)
     constexpr int OROW = L::OROW;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
@@ -82,19 +85,19 @@ k_pw_nt(const T* __restrict__ a, ProArgs pa, const T* __restrict__ w, T* __restr
 
     // two register sets: the loads of stage s+2 are issued while stage s computes and stage s+1
     // waits in the other set for its turn through the prologue into LDS
-    struct Regs { uint4 a[4], a2[4], b[BN / 32]; };
+    struct Regs { uint4 a[AI], a2[AI], b[BN / 32]; };
     Regs R0, R1;
     auto g_load = [&](Regs& R, int mt, int kt, bool with_b) {
         int kc, sh;
         tile_kc(kt, kc, sh);
         const int c = t & ((1 << sh) - 1), rb0 = t >> sh, rstep = DFD_THREADS >> sh;
-        const int m0 = mt * PW_BM, k0 = kt * BK;
+        const int m0 = mt * BM, k0 = kt * BK;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < AI; ++i) {
             const int r = rb0 + i * rstep;
             R.a[i] = make_uint4(0, 0, 0, 0);
             if (PRO == DFD_PRO_AFFINE2) R.a2[i] = make_uint4(0, 0, 0, 0);
-            if (r < PW_BM && c < kc && m0 + r < M) {
+            if (r < BM && c < kc && m0 + r < M) {
                 const long off = (long)(m0 + r) * K + k0 + c * E;
                 R.a[i] = *reinterpret_cast<const uint4*>(a + off);
                 if constexpr (PRO == DFD_PRO_AFFINE2) R.a2[i] = *reinterpret_cast<const uint4*>(a2 + off);
@@ -128,11 +131,11 @@ k_pw_nt(const T* __restrict__ a, ProArgs pa, const T* __restrict__ w, T* __restr
         const int c = t & ((1 << sh) - 1), rb0 = t >> sh, rstep = DFD_THREADS >> sh;
         unsigned char* ab = smem + buf * L::A_BYTES;
         unsigned char* bb = smem + L::BOFF + buf * L::B_BYTES;
-        const int m0 = mt * PW_BM, k0 = kt * BK;
+        const int m0 = mt * BM, k0 = kt * BK;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < AI; ++i) {
             const int r = rb0 + i * rstep;
-            if (r >= PW_BM) continue;
+            if (r >= BM) continue;
             uint4 q = R.a[i];
             if (PRO != DFD_PRO_NONE && c < kc && m0 + r < M) {
                 const float* gk = nullptr;
@@ -153,11 +156,11 @@ k_pw_nt(const T* __restrict__ a, ProArgs pa, const T* __restrict__ w, T* __restr
     // flat software pipeline over (M tile, K tile), two stages deep: while stage s runs its MFMAs
     // (and epilogue), the loads of stage s+2 are issued and stage s+1 sits in registers; its
     // prologue + LDS store follow the MFMAs, so a global load has a full stage to land
-    f32x4_t acc[NTW][4];
+    f32x4_t acc[NTW][RF];
 #pragma unroll
     for (int i = 0; i < NTW; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < RF; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
     const bool next_b = !b_resident;
     auto advance = [&](int& m_, int& k_) { if (++k_ == nk) { k_ = 0; m_ += gx; } };
     auto compute = [&](int mt, int kt, int buf) {
@@ -169,10 +172,10 @@ k_pw_nt(const T* __restrict__ a, ProArgs pa, const T* __restrict__ w, T* __restr
                     const int klim = kt * BK + ks * (BK / 2);
                     if (klim < K) {
                         const int c = ks * 4 + fk;
-                        uint4 fa[4], fw[NTW];
+                        uint4 fa[RF], fw[NTW];
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            const int r = wm * 64 + i * 16 + frow;
+                        for (int i = 0; i < RF; ++i) {
+                            const int r = wm * (BM / 2) + i * 16 + frow;
                             fa[i] = *reinterpret_cast<const uint4*>(ab + r * 128 + ((c ^ (r & 7)) << 4));
                         }
 #pragma unroll
@@ -183,7 +186,7 @@ k_pw_nt(const T* __restrict__ a, ProArgs pa, const T* __restrict__ w, T* __restr
 #pragma unroll
                         for (int i = 0; i < NTW; ++i)
 #pragma unroll
-                            for (int j = 0; j < 4; ++j) {
+                            for (int j = 0; j < RF; ++j) {
                                 if constexpr (sizeof(T) == 2) {
                                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
                                         __builtin_bit_cast(bf16x8_t, fw[i]), __builtin_bit_cast(bf16x8_t, fa[j]), acc[i][j], 0, 0, 0);
@@ -201,13 +204,13 @@ k_pw_nt(const T* __restrict__ a, ProArgs pa, const T* __restrict__ w, T* __restr
             }
             if (kt == nk - 1) {
                 // ---- tile done: accumulators -> LDS overlay [m][n] -> 16-byte row-major stores
-                const int m0 = mt * PW_BM;
+                const int m0 = mt * BM;
                 __syncthreads();            // every wave is done reading the A buffers the overlay covers
 #pragma unroll
                 for (int i = 0; i < NTW; ++i)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int m = wm * 64 + j * 16 + frow;
+                    for (int j = 0; j < RF; ++j) {
+                        const int m = wm * (BM / 2) + j * 16 + frow;
                         const int n = wn * (BN / 2) + i * 16 + fk * 4;
                         unsigned char* p = smem + m * OROW + n * (int)sizeof(T);
                         if constexpr (sizeof(T) == 2) {
@@ -224,7 +227,7 @@ k_pw_nt(const T* __restrict__ a, ProArgs pa, const T* __restrict__ w, T* __restr
                 const int n = n0 + ec * E;
                 if (n < Nout) {
 #pragma unroll 4
-                    for (int r = er; r < PW_BM; r += RL) {
+                    for (int r = er; r < BM; r += RL) {
                         const int m = m0 + r;
                         if (m >= M) break;
                         float v[E];
@@ -528,10 +531,10 @@ extern "C" int dfd_pw_prep_weights(int dtype, const float* w, void* w_nk, void* 
 // ===========================================================================
 // host dispatch
 // ===========================================================================
-template <typename T, int BN>
+template <typename T, int BN, int BM>
 static int pw_nt_launch(const void* a, const dfd_prologue* pro, const void* w, void* out, const void* residual, int M,
                         int K, int Nout, float* partials, int pcap, int* nparts, hipStream_t st) {
-    const int m_tiles = (M + PW_BM - 1) / PW_BM, n_tiles = (Nout + BN - 1) / BN;
+    const int m_tiles = (M + BM - 1) / BM, n_tiles = (Nout + BN - 1) / BN;
     int cap = partials ? (pcap < DFD_MAX_PARTIALS ? pcap : DFD_MAX_PARTIALS) : DFD_MAX_PARTIALS;
     int gx = 2048 / n_tiles;
     if (gx < 32) gx = 32;
@@ -539,7 +542,7 @@ static int pw_nt_launch(const void* a, const dfd_prologue* pro, const void* w, v
     if (gx > m_tiles) gx = m_tiles;
     if (partials) *nparts = gx;
     constexpr int RED = DFD_THREADS * 2 * El<T>::EPC * 4;
-    int lds = NtLds<T, BN>::TOTAL;
+    int lds = NtLds<T, BN, BM>::TOTAL;
     if (lds < RED) lds = RED;
     const ProArgs pa = pro_args(pro);
     const int mode = pro ? pro->mode : DFD_PRO_NONE;
@@ -547,7 +550,7 @@ static int pw_nt_launch(const void* a, const dfd_prologue* pro, const void* w, v
     const bool has_res = residual != nullptr, stats = partials != nullptr;
     dim3 grid(gx * n_tiles);
 #define LAUNCH_NT(PRO, RES, STATS)                                                                                        \
-    hipLaunchKernelGGL((k_pw_nt<T, BN, PRO, ACT, RES, STATS>), grid, dim3(DFD_THREADS), lds, st, (const T*)a, pa, (const T*)w, \
+    hipLaunchKernelGGL((k_pw_nt<T, BN, BM, PRO, ACT, RES, STATS>), grid, dim3(DFD_THREADS), lds, st, (const T*)a, pa, (const T*)w, \
                        (T*)out, (const T*)residual, M, K, Nout, m_tiles, n_tiles, gx, partials)
     // combinations used by the engine: forward = {NONE, BN_ACT, BN_ACT_GATE} x stats, no residual;
     // data gradient = AFFINE2 (+ residual), no stats; plain = NONE
@@ -576,9 +579,16 @@ static int pw_nt_launch(const void* a, const dfd_prologue* pro, const void* w, v
 template <typename T>
 static int pw_nt_t(const void* a, const dfd_prologue* pro, const void* w, void* out, const void* residual, int M, int K,
                    int Nout, float* partials, int pcap, int* nparts, hipStream_t st) {
-    if (Nout <= 32) return pw_nt_launch<T, 32>(a, pro, w, out, residual, M, K, Nout, partials, pcap, nparts, st);
-    if (Nout <= 64) return pw_nt_launch<T, 64>(a, pro, w, out, residual, M, K, Nout, partials, pcap, nparts, st);
-    return pw_nt_launch<T, 128>(a, pro, w, out, residual, M, K, Nout, partials, pcap, nparts, st);
+    // 128-row tiles unless they would leave most CUs without a workgroup (the 7x7 / 14x14 layers)
+    const long tiles128 = (long)((M + 127) / 128) * ((Nout + 127) / 128);
+    const bool small = tiles128 < 256;      // measured: a win below one tile per CU, a loss above
+#define PW_NT_GO(BNV)                                                                                                   \
+    return small ? pw_nt_launch<T, BNV, 64>(a, pro, w, out, residual, M, K, Nout, partials, pcap, nparts, st)            \
+                 : pw_nt_launch<T, BNV, 128>(a, pro, w, out, residual, M, K, Nout, partials, pcap, nparts, st)
+    if (Nout <= 32) PW_NT_GO(32);
+    if (Nout <= 64) PW_NT_GO(64);
+    PW_NT_GO(128);
+#undef PW_NT_GO
 }
 
 extern "C" int dfd_pwconv_fwd(int dtype, const void* a, const dfd_prologue* pro, const void* w, void* out,
