@@ -85,6 +85,11 @@ def load() -> ctypes.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    # torch first: its bundled HIP runtime must be the one this process uses.  If libdfd_hip.so is
+    # dlopen'ed before torch, the loader resolves libamdhip64 to the system copy, torch then brings its
+    # own, and every launch on a torch stream fails (two runtimes, foreign stream handles).
+    import torch  # noqa: F401
+
     if not LIB_PATH.exists():
         raise RuntimeError(
             f"{LIB_PATH} is missing: build it with `python -m deepfakedetection_amd.build` "
