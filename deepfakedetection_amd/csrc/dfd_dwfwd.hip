@@ -15,6 +15,7 @@
 //     (sum, sumsq) row per workgroup, BN + SiLU of the producer applied once per staged
 //     element, zero padding written in the activated domain.
 #include "dfd_dwq.h"
+#include <cstdlib>
 
 template <typename T, int K, int S, int ACT, bool PRO, bool STATS>
 __global__ void __launch_bounds__(DFD_THREADS, 4)
@@ -211,6 +212,12 @@ static int dw_fwd_q_t(const void* x, const float* in_bnstate, int in_act, const 
     DwQGeom g; int tile_bytes;
     if (!dfd_dwq_geom(s, V, 16, false, (size_t)(s ? s->k * s->k + 2 : 0) * 16 * V * 4, 0, 1, &g, &tile_bytes)) return DFD_EINVAL;
     const int cvb = 1 << g.cvb_log2, nchunks = (g.CV + cvb - 1) / cvb;
+    // XCD-aware order (dwq_block): measured per layer — helps the forward kernel when an image spans
+    // several tiles and the channel chunks share cache lines (block 2: 219 -> 201 us), hurts when one
+    // tile is one image (14x14, 7x7 layers: +8..17 %)
+    g.remap = (nchunks > 1 && g.tiles_y * g.tiles_x >= 2 &&
+               ((s->C * (int)sizeof(T)) % 128 != 0 || (cvb * 16) % 128 != 0)) ? 1 : 0;
+    if (const char* e = getenv("DFD_DW_FWD_REMAP")) g.remap = atoi(e);      // tuning experiments only
     const bool stats = partials != nullptr;
     int cap = stats ? (pcap < DFD_MAX_PARTIALS ? pcap : DFD_MAX_PARTIALS) : DFD_MAX_PARTIALS;
     int gy = 2048 / nchunks;

@@ -545,7 +545,15 @@ __global__ void k_linear_bwd_w(const float* __restrict__ dout, const float* __re
     const int j = blockIdx.y, k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k < K) {
         float s = 0.f;
-        for (int n = 0; n < N; ++n) s = fmaf(dout[(long)n * J + j], x[(long)n * K + k], s);
+        int n = 0;
+        for (; n + 8 <= N; n += 8) {           // eight rows in flight; products added in row order
+            float xv[8], dv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { xv[u] = x[(long)(n + u) * K + k]; dv[u] = dout[(long)(n + u) * J + j]; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s = fmaf(dv[u], xv[u], s);
+        }
+        for (; n < N; ++n) s = fmaf(dout[(long)n * J + j], x[(long)n * K + k], s);
         float* p = dw + (long)j * K + k;
         *p = (accumulate ? *p : 0.f) + s;
     }
@@ -565,7 +573,7 @@ extern "C" int dfd_linear_bwd(const float* dout, const float* x, const float* w,
     }
     if (dw) {
         if (!x) return DFD_EINVAL;
-        hipLaunchKernelGGL(k_linear_bwd_w, dim3((K + 255) / 256, J), dim3(256), 0, st, dout, x, dw, db, N, K, J, accumulate);
+        hipLaunchKernelGGL(k_linear_bwd_w, dim3((K + 63) / 64, J), dim3(64), 0, st, dout, x, dw, db, N, K, J, accumulate);
     }
     return DFD_CHECK_LAUNCH();
 }
