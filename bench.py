@@ -129,6 +129,22 @@ def cpu_baseline(args) -> dict:
     return {"value": None, "unit": "images/sec", "cores": usable_cores(), "kind": "port", "sample": f"not measured ({note})"}
 
 
+def pmc_traffic(family: str, args) -> int | None:
+    """HBM bytes per launch of a kernel family from the committed rocprofv3 --pmc passes (counters
+    cannot be read from inside this process): newest profiles/*pmc_traffic.json, which records GB per
+    training step of exactly this workload.  None when the file is absent or the workload differs."""
+    if (args.variant, args.flavour, args.batch, args.size) != ("b0", "timm", 256, 224):
+        return None
+    files = sorted((ROOT / "profiles").glob("*pmc_traffic.json"))
+    if not files:
+        return None
+    try:
+        fam = json.loads(files[-1].read_text())["families"][family]
+        return int((fam["ea_read_gb_per_step"] + fam["ea_write_gb_per_step"]) * 1e9 / fam["dispatches_per_step"])
+    except (KeyError, ValueError, ZeroDivisionError):
+        return None
+
+
 def progress(msg: str) -> None:
     print(f"[bench] {msg}", file=sys.stderr, flush=True)
 
@@ -326,7 +342,7 @@ def main() -> None:
         top = breakdown[0]
         t, b, f, n = agg[top["kernel"]]
         roofline = {"kernel": top["kernel"], "bound": "hbm", "achieved": round(b / t / 1e9, 1), "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(b / t / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
+                    "unit": "GB/s", "frac": round(b / t / 1e9 / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(top["kernel"], args),
                     "avg_launch_us": round(t / n * 1e6, 2), "avg_launch_bytes": int(b / n),
                     "share_of_step": top["share"], "mfma_tflops": round(f / t / 1e12, 2),
                     "mfma_frac": round(f / t / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4)}
