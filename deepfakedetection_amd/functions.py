@@ -211,7 +211,8 @@ class MBConvFunction(torch.autograd.Function):
         dw_proj = None
         if need[11]:
             pro_q = K.pro_bn_act_gate(st2, ACT_SILU, gate, Ho * Wo)
-            dw_proj = K.pwconv_wgrad(gb, pro_dy3, y2, pro_q, _dest(ctx, 11, (Cout, Cmid))).view(Cout, Cmid, 1, 1)
+            with K.side_stream():
+                dw_proj = K.pwconv_wgrad(gb, pro_dy3, y2, pro_q, _dest(ctx, 11, (Cout, Cmid))).view(Cout, Cmid, 1, 1)
         # ---- squeeze-excite backward
         dgate = K.pool_bwd_reduce(D, y2, st2, ACT_SILU)
         want_se = need[7] or need[8] or need[9] or need[10]
@@ -230,23 +231,26 @@ class MBConvFunction(torch.autograd.Function):
                                               geom.stride, geom.pad_lead, geom.pad_lead)
             coef1, dg_exp, db_exp = K.bn_bwd_finalize(parts, n, N * H * W, g_exp, st1, tr, need[2] or need[3],
                                                       _dest(ctx, 2, (Cmid,)), _dest(ctx, 3, (Cmid,)))
-            if need[4]:
-                dw_dw = K.dwconv_bwd_weight(dz2, y2, coef2, y1, st1, ACT_SILU, geom.kernel, geom.stride,
-                                            geom.pad_lead, geom.pad_lead, _dest(ctx, 4, (Cmid, 1, kk, kk)))
             pro_dy1 = K.pro_affine2(y1, coef1)
+            with K.side_stream():
+                if need[4]:
+                    dw_dw = K.dwconv_bwd_weight(dz2, y2, coef2, y1, st1, ACT_SILU, geom.kernel, geom.stride,
+                                                geom.pad_lead, geom.pad_lead, _dest(ctx, 4, (Cmid, 1, kk, kk)))
+                if need[1]:
+                    dw_exp = K.pwconv_wgrad(dz1, pro_dy1, x, None, _dest(ctx, 1, (Cmid, Cin))).view(Cmid, Cin, 1, 1)
             if need[0]:
                 dx, _, _ = K.pwconv(dz1, pro_dy1, wexp_kn, g if cfg.skip else None, stats=False)
-            if need[1]:
-                dw_exp = K.pwconv_wgrad(dz1, pro_dy1, x, None, _dest(ctx, 1, (Cmid, Cin))).view(Cmid, Cin, 1, 1)
         else:
             if need[4]:
-                dw_dw = K.dwconv_bwd_weight(dz2, y2, coef2, x, None, ACT_NONE, geom.kernel, geom.stride,
-                                            geom.pad_lead, geom.pad_lead, _dest(ctx, 4, (Cmid, 1, kk, kk)))
+                with K.side_stream():
+                    dw_dw = K.dwconv_bwd_weight(dz2, y2, coef2, x, None, ACT_NONE, geom.kernel, geom.stride,
+                                                geom.pad_lead, geom.pad_lead, _dest(ctx, 4, (Cmid, 1, kk, kk)))
             if need[0]:
                 dx, _, _ = K.dwconv_bwd_data(dz2, y2, coef2, w_dw, None, None, ACT_NONE, ctx.in_shape, geom.kernel,
                                              geom.stride, geom.pad_lead, geom.pad_lead)
                 if cfg.skip:
                     dx = K.bn_act_apply(dx, _identity_state(Cin, dx.device), ACT_NONE, g, None)
+        K.join_side()
         return (dx, dw_exp, dg_exp, db_exp, dw_dw, dg_dw, db_dw, dw1, db1, dw2, db2, dw_proj, dg_proj, db_proj,
                 None, None)
 
