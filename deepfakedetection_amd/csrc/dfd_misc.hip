@@ -714,3 +714,42 @@ extern "C" int dfd_adamw_step(const int64_t* table, int nchunks, const float* hp
     hipLaunchKernelGGL(k_adamw, dim3(nchunks), dim3(DFD_THREADS), 0, (hipStream_t)stream, table, hp);
     return DFD_CHECK_LAUNCH();
 }
+
+// ===========================================================================
+// input tail: uint8 NHWC batch -> [horizontal flip] -> /255 -> (x - mean) / std -> [erase box] -> f32 NHWC
+// (RandomHorizontalFlip, ToTensor, Normalize, RandomErasing(value=0) of trainers/efficientnet.py:111-234,
+//  in that order; the random decisions arrive as per-image parameters).  One thread = one pixel (3 channels).
+// ===========================================================================
+__global__ void __launch_bounds__(DFD_THREADS)
+k_image_prep(const unsigned char* __restrict__ src, float* __restrict__ dst, int N, int H, int W, float m0, float m1, float m2,
+             float s0, float s1, float s2, const unsigned char* __restrict__ flip, const int* __restrict__ erase) {
+    const long total = (long)N * H * W;
+    for (long i = (long)blockIdx.x * DFD_THREADS + threadIdx.x; i < total; i += (long)gridDim.x * DFD_THREADS) {
+        const int x = (int)(i % W);
+        const long t = i / W;
+        const int y = (int)(t % H);
+        const int n = (int)(t / H);
+        const int sx = (flip && flip[n]) ? W - 1 - x : x;
+        const unsigned char* p = src + (((long)n * H + y) * W + sx) * 3;
+        float r = ((float)p[0] / 255.0f - m0) / s0;
+        float g = ((float)p[1] / 255.0f - m1) / s1;
+        float b = ((float)p[2] / 255.0f - m2) / s2;
+        if (erase) {
+            const int* e = erase + 4 * n;                      // top, left, height, width (height 0: none)
+            if (e[2] > 0 && y >= e[0] && y < e[0] + e[2] && x >= e[1] && x < e[1] + e[3]) { r = 0.f; g = 0.f; b = 0.f; }
+        }
+        float* o = dst + i * 3;
+        o[0] = r; o[1] = g; o[2] = b;
+    }
+}
+extern "C" int dfd_image_prep(const unsigned char* src, float* dst, int N, int H, int W, const float* mean3,
+                              const float* std3, const unsigned char* flip, const int* erase, dfd_stream stream) {
+    if (!src || !dst || !mean3 || !std3 || N < 1 || H < 1 || W < 1) return DFD_EINVAL;
+    if (std3[0] == 0.f || std3[1] == 0.f || std3[2] == 0.f) return DFD_EINVAL;
+    const long total = (long)N * H * W;
+    long grid = (total + DFD_THREADS - 1) / DFD_THREADS;
+    if (grid > 65536) grid = 65536;
+    hipLaunchKernelGGL(k_image_prep, dim3((unsigned)grid), dim3(DFD_THREADS), 0, (hipStream_t)stream, src, dst, N, H, W, mean3[0],
+                       mean3[1], mean3[2], std3[0], std3[1], std3[2], flip, erase);
+    return DFD_CHECK_LAUNCH();
+}

@@ -239,6 +239,24 @@ def scale_rows(x: torch.Tensor, row_scale: torch.Tensor) -> torch.Tensor:
     return out
 
 
+# ------------------------------------------------------------------ input tail
+def image_prep(src_u8: torch.Tensor, mean, std, flip: torch.Tensor | None, erase: torch.Tensor | None) -> torch.Tensor:
+    """uint8 [N, H, W, 3] on the device -> f32, returned as an [N, 3, H, W] channels_last view of the
+    NHWC result (zero-copy: exactly what HipEfficientNet.forward turns back into NHWC)."""
+    if src_u8.dtype != torch.uint8 or src_u8.dim() != 4 or src_u8.shape[3] != 3 or not src_u8.is_contiguous():
+        raise ValueError("expected a contiguous uint8 [N, H, W, 3] tensor")
+    N, H, W, _ = src_u8.shape
+    dst = torch.empty((N, H, W, 3), dtype=torch.float32, device=src_u8.device)
+    m3 = (ctypes.c_float * 3)(*[float(v) for v in mean])
+    s3 = (ctypes.c_float * 3)(*[float(v) for v in std])
+    if flip is not None and (flip.dtype != torch.uint8 or flip.numel() != N):
+        raise ValueError("flip must be uint8 [N]")
+    if erase is not None and (erase.dtype != torch.int32 or erase.numel() != 4 * N):
+        raise ValueError("erase must be int32 [N, 4]")
+    check(_L().dfd_image_prep(_p(src_u8), _p(dst), N, H, W, m3, s3, _p(flip), _p(erase), _stream()), "dfd_image_prep")
+    return dst.permute(0, 3, 1, 2)
+
+
 # ------------------------------------------------------------------ squeeze-excite
 def se_fc_fwd(pooled: torch.Tensor, w1, b1, w2, b2, act: int):
     N, C = pooled.shape

@@ -65,8 +65,10 @@ class EvalResult:
     correct: int
 
 
-def build_transforms(img_size: int) -> tuple[D.Compose, D.Compose]:
-    """(train, val) pipelines from the toggle defaults of the reference + $TRANSFORMS."""
+def build_transforms(img_size: int, gpu_tail: bool = False):
+    """(train, val) pipelines from the toggle defaults of the reference + $TRANSFORMS.
+    gpu_tail=True: the pipelines end in uint8 HWC tensors and (train, val, train_tail, val_tail) is
+    returned, the tails being `D.GpuInputTail`s that do flip / to-float / normalise / erasing on the GPU."""
     small = img_size <= 64
     toggles = load_transform_toggles(
         {
@@ -99,22 +101,37 @@ def build_transforms(img_size: int) -> tuple[D.Compose, D.Compose]:
                 train.append(D.CenterCrop(img_size))
         if on("train_random_rotation", True):
             train.append(D.RandomRotation(10))
-    if on("train_random_horizontal_flip", True):
-        train.append(D.RandomHorizontalFlip())
-    if on("train_color_jitter", False):
-        train.append(D.ColorJitter(0.2, 0.2, 0.2, 0.05))
-    if on("train_to_tensor", True):
-        train.append(D.ToTensor())
-    if on("train_normalize", True):
-        train.append(normalize)
-    if on("train_random_erasing", False):
-        train.append(D.RandomErasing(p=0.5, scale=(0.02, 0.33), ratio=(0.3, 3.3), value=0))
+    mean, std = [0.485, 0.456, 0.406], [0.229, 0.224, 0.225]
+    if gpu_tail:
+        # flip commutes with the per-pixel colour jitter, so it can move behind it onto the device
+        if on("train_color_jitter", False):
+            train.append(D.ColorJitter(0.2, 0.2, 0.2, 0.05))
+        train.append(D.ToUint8HWC())
+        train_tail = D.GpuInputTail(mean if on("train_normalize", True) else [0.0] * 3,
+                                    std if on("train_normalize", True) else [1.0] * 3,
+                                    flip_p=0.5 if on("train_random_horizontal_flip", True) else 0.0,
+                                    erase_p=0.5 if on("train_random_erasing", False) else 0.0)
+    else:
+        if on("train_random_horizontal_flip", True):
+            train.append(D.RandomHorizontalFlip())
+        if on("train_color_jitter", False):
+            train.append(D.ColorJitter(0.2, 0.2, 0.2, 0.05))
+        if on("train_to_tensor", True):
+            train.append(D.ToTensor())
+        if on("train_normalize", True):
+            train.append(normalize)
+        if on("train_random_erasing", False):
+            train.append(D.RandomErasing(p=0.5, scale=(0.02, 0.33), ratio=(0.3, 3.3), value=0))
 
     val: list = [D.Lambda(_rgb)] if on("ensure_rgb", True) else []
     if on("val_resize", True):
         val.append(D.Resize(img_size if small else enlarged))
     if on("val_center_crop", True):
         val.append(D.CenterCrop(img_size))
+    if gpu_tail:
+        val.append(D.ToUint8HWC())
+        val_tail = D.GpuInputTail(mean if on("val_normalize", True) else [0.0] * 3, std if on("val_normalize", True) else [1.0] * 3)
+        return D.Compose(train), D.Compose(val), train_tail, val_tail
     if on("val_to_tensor", True):
         val.append(D.ToTensor())
     if on("val_normalize", True):
@@ -131,17 +148,28 @@ def make_loader(dataset, batch_size: int, num_workers: int, *, shuffle: bool, ra
 
 
 def get_loaders(data_root: Path, train_split: str, val_split: str, img_size: int, batch_size: int, num_workers: int, *,
-                expected_classes: int | None = None, rank: int = 0, world: int = 1, seed: int = 0):
-    train_t, val_t = build_transforms(img_size)
+                expected_classes: int | None = None, rank: int = 0, world: int = 1, seed: int = 0, gpu_tail: bool = False):
+    """(train loader, val loader); with gpu_tail also (train tail, val tail) to apply to each uint8 batch."""
+    tails = ()
+    if gpu_tail:
+        train_t, val_t, *tails = build_transforms(img_size, gpu_tail=True)
+    else:
+        train_t, val_t = build_transforms(img_size)
     train_ds = D.ImageFolder(data_root / train_split, transform=train_t)
     if expected_classes is not None:
         require_num_classes(train_ds, expected_classes, split=train_split)
     val_ds = D.ImageFolder(data_root / val_split, transform=val_t)
     return (make_loader(train_ds, batch_size, num_workers, shuffle=True, rank=rank, world=world, seed=seed),
-            make_loader(val_ds, batch_size, num_workers, shuffle=False, rank=rank, world=world, seed=seed))
+            make_loader(val_ds, batch_size, num_workers, shuffle=False, rank=rank, world=world, seed=seed), *tails)
 
 
-def evaluate(model: nn.Module, dl: DataLoader, device: str, criterion: nn.Module) -> EvalResult:
+def _to_device(batch_x: torch.Tensor, device: str, tail) -> torch.Tensor:
+    if tail is not None:
+        return tail(batch_x, device)                         # uint8 NHWC -> normalised f32 on the GPU
+    return batch_x.to(device, non_blocking=True).to(memory_format=torch.channels_last)
+
+
+def evaluate(model: nn.Module, dl: DataLoader, device: str, criterion: nn.Module, tail=None) -> EvalResult:
     """Top-1 accuracy and mean loss; f32, no autocast (reference :237-262).  Counters stay
     on the device and are read once at the end (and summed over ranks)."""
     model.eval()
@@ -150,7 +178,7 @@ def evaluate(model: nn.Module, dl: DataLoader, device: str, criterion: nn.Module
     total = 0
     with torch.inference_mode():
         for batch_x, batch_y in dl:
-            inputs = batch_x.to(device, non_blocking=True).to(memory_format=torch.channels_last)
+            inputs = _to_device(batch_x, device, tail)
             targets = batch_y.to(device, non_blocking=True)
             logits = model(inputs)
             loss_sum += criterion(logits, targets).double() * targets.size(0)
@@ -162,7 +190,7 @@ def evaluate(model: nn.Module, dl: DataLoader, device: str, criterion: nn.Module
 
 def train_one_epoch(model: nn.Module, dl: DataLoader, opt: optim.Optimizer, scaler, criterion: nn.Module, device: str, *,
                     use_cuda_amp: bool, progress: Progress, task: TaskID, accum_steps: int = 1,
-                    reducer: GradAllReducer | None = None) -> float:
+                    reducer: GradAllReducer | None = None, tail=None) -> float:
     """One epoch; returns the mean training loss (reference :265-333)."""
     model.train()
     start = perf_counter()
@@ -171,7 +199,7 @@ def train_one_epoch(model: nn.Module, dl: DataLoader, opt: optim.Optimizer, scal
     seen_total = pending = 0
     shown = float("nan")
     for i, (batch_x, batch_y) in enumerate(dl, 1):
-        inputs = batch_x.to(device, non_blocking=True).to(memory_format=torch.channels_last)
+        inputs = _to_device(batch_x, device, tail)
         targets = batch_y.to(device, non_blocking=True)
         with torch.autocast(device_type="cuda", dtype=torch.bfloat16, enabled=use_cuda_amp):
             loss = criterion(model(inputs), targets)
@@ -272,8 +300,13 @@ def main() -> None:  # noqa: PLR0915
         console.print(f"Expected: {data_root}/{train_split}/<class> and {data_root}/{val_split}/<class>")
         raise SystemExit(1)
     try:
-        train_dl, val_dl = get_loaders(data_root, train_split, val_split, img_size, batch_size, num_workers,
-                                       expected_classes=num_classes, rank=rank, world=world, seed=env.seed or 0)
+        # $GPU_INPUT_TAIL (YAML training.gpu_input_tail): loaders ship uint8 batches, the device does
+        # flip / to-float / normalise / erasing
+        gpu_tail = use_cuda and env_str("GPU_INPUT_TAIL", "0").lower() in {"1", "true", "yes"}
+        train_dl, val_dl, *tails = get_loaders(data_root, train_split, val_split, img_size, batch_size, num_workers,
+                                               expected_classes=num_classes, rank=rank, world=world, seed=env.seed or 0,
+                                               gpu_tail=gpu_tail)
+        train_tail, val_tail = tails if tails else (None, None)
     except ValueError as exc:
         console.print("[bold red]Class configuration mismatch[/]", f"→ {exc}")
         console.print("Update `data.num_classes` in your YAML to match the dataset. For MNIST, set it to 10.")
@@ -308,10 +341,10 @@ def main() -> None:  # noqa: PLR0915
             task = progress.add_task("warmup (head only)", total=len(train_dl), extra="")
             console.print("[bold]Warmup (head only)[/]")
             train_one_epoch(model, train_dl, warm_opt, scaler, criterion, device, use_cuda_amp=use_cuda, progress=progress,
-                            task=task, accum_steps=1, reducer=reducer)
+                            task=task, accum_steps=1, reducer=reducer, tail=train_tail)
             if reducer is not None:
                 reducer.detach()
-            res = evaluate(model, val_dl, device, criterion)
+            res = evaluate(model, val_dl, device, criterion, val_tail)
             console.print(f"[bold cyan]warmup[/] | val_acc={res.acc:.4f} | val_loss={res.loss:.4f} ({res.correct}/{res.total})")
             best_val_acc, best_epoch, warmup_done = res.acc, 0, True
             if getattr(warm_opt, "arena", None) is not None:
@@ -343,9 +376,10 @@ def main() -> None:  # noqa: PLR0915
                 train_dl_ft.sampler.set_epoch(epoch)
             task = progress.add_task(f"epoch {epoch}", total=len(train_dl_ft), extra="")
             train_loss = train_one_epoch(model, train_dl_ft, opt, scaler, criterion, device, use_cuda_amp=use_cuda,
-                                         progress=progress, task=task, accum_steps=accum_steps, reducer=reducer)
+                                         progress=progress, task=task, accum_steps=accum_steps, reducer=reducer,
+                                         tail=train_tail)
             scheduler.step()
-            res = evaluate(model, val_dl, device, criterion)
+            res = evaluate(model, val_dl, device, criterion, val_tail)
             console.print(f"[bold cyan]epoch {epoch}[/] | train_loss={train_loss:.4f} | val_loss={res.loss:.4f} | "
                           f"val_acc={res.acc:.4f} ({res.correct}/{res.total}) | lr={scheduler.get_last_lr()[0]:.2e}")
             improved = res.acc > best_val_acc + 1e-4

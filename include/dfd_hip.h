@@ -217,6 +217,13 @@ int dfd_ce_loss(const float* logits, const int64_t* targets, int N, int J,
                 float* dlogits, dfd_stream stream);
 int dfd_softmax_argmax(const float* logits, int N, int J, float* probs, int64_t* preds,
                        dfd_stream stream);
+/* Input tail on the device (trainers/efficientnet.py:111-234): a uint8 NHWC
+ * batch [N][H][W][3] -> RandomHorizontalFlip -> ToTensor (/255) -> Normalize((x-mean)/std) ->
+ * RandomErasing(value 0) -> f32 NHWC, which is the stem kernel's input layout.  The random decisions
+ * are made by the caller: flip[n] != 0 mirrors image n; erase[4n..] = {top, left, height, width},
+ * height 0 = none; either pointer may be NULL.  mean3 / std3 are HOST arrays of 3 floats.      */
+int dfd_image_prep(const unsigned char* src, float* dst, int N, int H, int W, const float* mean3,
+                   const float* std3, const unsigned char* flip, const int* erase, dfd_stream stream);
 /* torch.optim.AdamW step over a chunk table: int64 rows {param, grad, exp_avg,
  * exp_avg_sq, count}; hp = {lr, beta1, beta2, eps, weight_decay, 1-beta1^t,
  * 1-beta2^t, grad_scale} in device memory (so a captured graph sees new values).   */

@@ -442,3 +442,37 @@ def test_adamw_matches_torch():
         torch.cuda.synchronize()
     for p, r in zip(dparams, ref):
         close(p, r.detach(), 1e-5, "adamw")
+
+
+def test_image_prep_matches_cpu_transforms_bit_for_bit():
+    """dfd_image_prep = RandomHorizontalFlip -> ToTensor -> Normalize -> RandomErasing(value=0) with the random
+    decisions given: identical bits to the CPU transforms of deepfakedetection_amd.data."""
+    from deepfakedetection_amd import data as D
+
+    K = _k()
+    N, H, W = 5, 37, 29
+    g = torch.Generator().manual_seed(71)
+    src = torch.randint(0, 256, (N, H, W, 3), generator=g, dtype=torch.uint8)
+    flip = torch.tensor([1, 0, 1, 0, 1], dtype=torch.uint8)
+    erase = torch.tensor([[3, 4, 10, 7], [0, 0, 0, 0], [30, 20, 7, 9], [0, 0, 36, 28], [5, 5, 0, 3]], dtype=torch.int32)
+    mean, std = [0.485, 0.456, 0.406], [0.229, 0.224, 0.225]
+    norm = D.Normalize(mean, std)
+    want = []
+    for n in range(N):
+        img = src[n]
+        if flip[n]:
+            img = img.flip(1)
+        t = norm(img.permute(2, 0, 1).to(torch.float32).div_(255.0))
+        top, left, eh, ew = (int(v) for v in erase[n])
+        if eh > 0:
+            t = t.clone()
+            t[:, top:top + eh, left:left + ew] = 0.0
+        want.append(t)
+    want = torch.stack(want)
+    got = K.image_prep(src.cuda(), mean, std, flip.cuda(), erase.cuda())
+    assert got.shape == (N, 3, H, W) and got.is_contiguous(memory_format=torch.channels_last)
+    assert torch.equal(got.cpu(), want), float((got.cpu() - want).abs().max())
+    # no flip / erase: plain ToTensor + Normalize
+    got2 = K.image_prep(src.cuda(), mean, std, None, None)
+    want2 = torch.stack([norm(src[n].permute(2, 0, 1).to(torch.float32).div_(255.0)) for n in range(N)])
+    assert torch.equal(got2.cpu(), want2)

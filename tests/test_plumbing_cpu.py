@@ -124,3 +124,32 @@ def test_hip_model_refuses_cpu_input():
     model = reg.get_model_spec("efficientnet_b0").builder("efficientnet_b0", 2)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         model(torch.zeros(1, 3, 32, 32))
+
+
+def test_gpu_input_tail_sampler_and_uint8_pipeline():
+    """Host side of the GPU input tail: the train/val pipelines end in uint8 HWC tensors, the tail samples
+    flips and erase boxes with RandomErasing's rules (box strictly inside the image, height 0 = none)."""
+    import torch
+    from PIL import Image
+
+    from deepfakedetection_amd import data as D
+    from deepfakedetection_amd.trainers.efficientnet import build_transforms
+
+    train_t, val_t, train_tail, val_tail = build_transforms(96, gpu_tail=True)
+    img = Image.fromarray((torch.rand(120, 100, 3) * 255).to(torch.uint8).numpy())
+    for t in (train_t, val_t):
+        out = t(img)
+        assert out.dtype == torch.uint8 and tuple(out.shape) == (96, 96, 3)
+    assert val_tail.flip_p == 0 and val_tail.erase_p == 0 and train_tail.flip_p == 0.5
+    torch.manual_seed(0)
+    tail = D.GpuInputTail([0.5] * 3, [0.25] * 3, flip_p=0.5, erase_p=0.5)
+    flip, erase = tail.sample(200, 64, 48)
+    assert flip.dtype == torch.uint8 and 60 <= int(flip.sum()) <= 140
+    assert erase.dtype == torch.int32 and tuple(erase.shape) == (200, 4)
+    on = erase[:, 2] > 0
+    assert 60 <= int(on.sum()) <= 140
+    e = erase[on]
+    assert bool(((e[:, 0] >= 0) & (e[:, 1] >= 0) & (e[:, 0] + e[:, 2] <= 64) & (e[:, 1] + e[:, 3] <= 48)).all())
+    assert bool((e[:, 2] < 64).all()) and bool((e[:, 3] < 48).all())
+    area = (e[:, 2] * e[:, 3]).float() / (64 * 48)
+    assert float(area.min()) > 0.01 and float(area.max()) < 0.40

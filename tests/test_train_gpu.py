@@ -16,8 +16,10 @@ from tests.test_plumbing_cpu import _make_dataset
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("model_name,weights_file", [("efficientnet_b0", "EfficientNetModel.pth"), ("efficientnet_b3", "EfficientNetModel.pth")])
-def test_orchestrated_training_and_inference_on_gpu(tmp_path, monkeypatch, model_name, weights_file):
+@pytest.mark.parametrize("model_name,weights_file,gpu_tail", [("efficientnet_b0", "EfficientNetModel.pth", False),
+                                                             ("efficientnet_b3", "EfficientNetModel.pth", False),
+                                                             ("efficientnet_b0", "EfficientNetModel.pth", True)])
+def test_orchestrated_training_and_inference_on_gpu(tmp_path, monkeypatch, model_name, weights_file, gpu_tail):
     from deepfakedetection_amd.orchestration.orchestrator import orchestrate
 
     monkeypatch.chdir(tmp_path)
@@ -29,7 +31,8 @@ def test_orchestrated_training_and_inference_on_gpu(tmp_path, monkeypatch, model
     }
     out_dir = str(tmp_path / "runs" / model_name)
     train_cfg = {**base, "models": {model_name: {"output_dir": out_dir, "training": {
-        "epochs": 1, "batch_size": 8, "ft_batch_size": 8, "accum_steps": 2, "num_workers": 0, "resume": "auto", "pretrained": False}}}}
+        "epochs": 1, "batch_size": 8, "ft_batch_size": 8, "accum_steps": 2, "num_workers": 0, "resume": "auto", "pretrained": False,
+        "gpu_input_tail": gpu_tail}}}}       # True: loaders ship uint8, flip / normalise / erasing run in dfd_image_prep
     path = tmp_path / "train.yaml"
     path.write_text(yaml.safe_dump(train_cfg))
     orchestrate(path, mode="training")
