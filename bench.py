@@ -351,7 +351,7 @@ def main() -> None:
         ms = elapsed / args.steps * 1e3
         value = args.batch * world * args.steps / elapsed
         line = {
-            "metric": "train images/sec @224^2 (EfficientNet-B0)", "value": round(value, 1), "unit": "images/sec",
+            "metric": f"train images/sec @{args.size}^2 (EfficientNet-{args.variant.upper()})", "value": round(value, 1), "unit": "images/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"EfficientNet-{args.variant} ({args.flavour} flavour) {args.size}x{args.size} train step: "
