@@ -54,6 +54,7 @@ def parse() -> argparse.Namespace:
     ap.add_argument("--cpu-timeout", type=int, default=150, help="seconds granted to the CPU baseline child process")
     ap.add_argument("--cpu-baseline-only", action="store_true", help="(internal) measure the CPU oracle and print its JSON")
     ap.add_argument("--profile-steps", type=int, default=2)
+    ap.add_argument("--eval-steps", type=int, default=10, help="f32 eval-mode forward passes timed after the train steps (0: skip)")
     return ap.parse_args()
 
 
@@ -300,6 +301,21 @@ def main() -> None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     final_loss = float(loss_box[0])
+
+    # evaluate()'s forward (reference trainers/efficientnet.py:237-262: eval mode, f32, no autocast), same batch
+    eval_ips = None
+    if args.eval_steps > 0:
+        model.eval()
+        with torch.inference_mode():
+            for _ in range(3):
+                model(x)
+            torch.cuda.synchronize()
+            t_e = time.perf_counter()
+            for _ in range(args.eval_steps):
+                model(x)
+            torch.cuda.synchronize()
+            eval_ips = args.batch * args.eval_steps / (time.perf_counter() - t_e)
+        model.train()
     in_sync = None
     if world > 1:
         # replicas started from rank 0's weights and applied the same averaged gradients
@@ -357,7 +373,8 @@ def main() -> None:
             "config": {"workload": f"EfficientNet-{args.variant} ({args.flavour} flavour) {args.size}x{args.size} train step: "
                                    f"bf16 fwd + label-smoothed CE + bwd + AdamW, random-init weights, {args.classes} classes",
                        "per_gpu_batch": args.batch, "global_batch": args.batch * world, "parallelism": f"dp{world}",
-                       "launch": launch, "final_loss": round(final_loss, 4), "replicas_in_sync": in_sync},
+                       "launch": launch, "final_loss": round(final_loss, 4), "replicas_in_sync": in_sync,
+                       "eval_f32_images_per_sec_per_gpu": round(eval_ips, 1) if eval_ips else None},
             "roofline": roofline,
             "kernels": breakdown,
         }
