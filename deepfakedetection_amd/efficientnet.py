@@ -28,7 +28,8 @@ from torch import nn
 
 from . import functions as F_
 from .arch import BlockPlan, NetPlan, efficientnet_plan
-from .functions import BNRef, HeadCtx, HeadFunction, MBConvCtx, MBConvFunction, StemCtx, StemFunction
+from .functions import (BNRef, HeadConvFunction, HeadCtx, HeadFunction, HeadTailEvalFunction, MBConvCtx, MBConvFunction,
+                        StemCtx, StemFunction)
 
 _LM_NAMES = dict(expand="_expand_conv", expand_bn="_bn0", dw="_depthwise_conv", dw_bn="_bn1",
                  se_reduce="_se_reduce", se_expand="_se_expand", project="_project_conv", project_bn="_bn2")
@@ -215,11 +216,38 @@ class HipEfficientNet(nn.Module):
             u = dropout_u
             if u is None and self.training and self.drop_rate > 0 and drop_masks is None:
                 u = torch.rand((h.shape[0], head.out_channels), device=h.device, dtype=torch.float32)
-            cfg = HeadCtx(_bnref(head_bn), self.drop_rate, self.training)
-            out = HeadFunction.apply(h, head.weight, head_bn.weight, head_bn.bias, fc.weight, fc.bias, u, cfg)
+            if head._forward_hooks or head._forward_pre_hooks:
+                out = self._hooked_head(h, head, head_bn, fc)
+            else:
+                cfg = HeadCtx(_bnref(head_bn), self.drop_rate, self.training)
+                out = HeadFunction.apply(h, head.weight, head_bn.weight, head_bn.bias, fc.weight, fc.bias, u, cfg)
         finally:
             F_.end_counter_batch()
         return out
+
+
+def _hooked_head(self, h, head, head_bn, fc):
+    """Forward hooks on the head convolution (Grad-CAM, web_ui.py:96-114): run the head unfused so that the
+    hooks see (module, (input,), output) as NCHW tensors wired into autograd.  Eval mode only."""
+    if self.training:
+        raise NotImplementedError("forward hooks on the head convolution are supported in eval mode only "
+                                  "(the training path keeps conv + BN + SiLU + pool + classifier in one fused stage)")
+    x_nchw = h.permute(0, 3, 1, 2)
+    for hook in head._forward_pre_hooks.values():
+        hook(head, (x_nchw,))
+    y = HeadConvFunction.apply(h, head.weight)
+    y_nchw = y.permute(0, 3, 1, 2)
+    for hook in head._forward_hooks.values():
+        r = hook(head, (x_nchw,), y_nchw)
+        if r is not None:
+            y_nchw = r
+    y2 = y_nchw.permute(0, 2, 3, 1)
+    if not y2.is_contiguous():
+        y2 = y2.contiguous()
+    return HeadTailEvalFunction.apply(y2, fc.weight, fc.bias, _bnref(head_bn), head_bn.weight, head_bn.bias)
+
+
+HipEfficientNet._hooked_head = _hooked_head
 
 
 def build_efficientnet(name: str, num_classes: int) -> HipEfficientNet:

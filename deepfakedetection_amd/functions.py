@@ -306,6 +306,57 @@ class HeadFunction(torch.autograd.Function):
                 dw_head = K.pwconv_wgrad(dz, pro, x, None, _dest(ctx, 1, (Chead, Cin))).view(Chead, Cin, 1, 1)
         return dx, dw_head, dgamma, dbeta, dw_fc, db_fc, None, None
 
+# =========================================================================== hooked head (Grad-CAM)
+class HeadConvFunction(torch.autograd.Function):
+    """The head's 1x1 convolution alone (raw output, NHWC): used when forward hooks sit on the head-conv
+    module, so that its OUTPUT exists as an autograd tensor (web_ui.py:96-114 attaches Grad-CAM there)."""
+
+    @staticmethod
+    def forward(ctx, x, w_head):
+        w_nk, w_kn = K.prep_weights(w_head, x.dtype, True, True)
+        y, _, _ = K.pwconv(x, None, w_nk, None, stats=False)
+        ctx.save_for_backward(x, w_kn)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w_kn = ctx.saved_tensors
+        g = _c(g)
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            dx, _, _ = K.pwconv(g, None, w_kn, None, stats=False)
+        if ctx.needs_input_grad[1]:
+            dw = K.pwconv_wgrad(g, None, x, None).view(g.shape[3], x.shape[3], 1, 1)
+        return dx, dw
+
+
+class HeadTailEvalFunction(torch.autograd.Function):
+    """Eval-mode BN + SiLU -> global average pool -> Linear on the raw head-conv output.  Differentiable
+    with respect to that activation only (the Grad-CAM use): parameters get no gradient here."""
+
+    @staticmethod
+    def forward(ctx, y, w_fc, b_fc, bn: BNRef, gamma, beta):
+        st = K.bn_eval_coeffs(bn.params(gamma, beta))
+        pooled = K.pool_act(y, st, ACT_SILU)
+        logits = K.linear_fwd(pooled, w_fc, b_fc)
+        ctx.save_for_backward(y, st, pooled, w_fc)
+        return logits
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        y, st, pooled, w_fc = ctx.saved_tensors
+        dy = None
+        if ctx.needs_input_grad[0]:
+            dpooled, _, _ = K.linear_bwd(_c(dlogits.float()), pooled, w_fc, True, False, False, None, None)
+            dz, _, _ = K.act_bn_bwd(None, y, None, dpooled, st, ACT_SILU)          # d loss / d (BN output)
+            C = y.shape[3]
+            chain = torch.zeros((4, C), dtype=torch.float32, device=y.device)       # eval BN: dy = scale * dz
+            chain[0].copy_(st[0])
+            chain[3].fill_(1.0)
+            dy = K.bn_act_apply(dz, chain, ACT_NONE, None, None)
+        return dy, None, None, None, None, None
+
+
 
 # =========================================================================== loss
 class CrossEntropyFunction(torch.autograd.Function):
@@ -323,5 +374,5 @@ class CrossEntropyFunction(torch.autograd.Function):
         return dlogits * gloss, None, None
 
 
-__all__ = ["BNRef", "CrossEntropyFunction", "HeadCtx", "HeadFunction", "MBConvCtx", "MBConvFunction", "StemCtx",
+__all__ = ["BNRef", "CrossEntropyFunction", "HeadConvFunction", "HeadCtx", "HeadFunction", "HeadTailEvalFunction", "MBConvCtx", "MBConvFunction", "StemCtx",
            "StemFunction"]

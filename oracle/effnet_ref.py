@@ -264,7 +264,12 @@ class EfficientNetRef(nn.Module):
         for i, blk in enumerate(self.block_list()):
             x = blk(x, None if drop_masks is None else drop_masks[i])
         head, bnh, fc = (self._conv_head, self._bn1, self._fc) if lm else (self.conv_head, self.bn2, self.classifier)
-        x = F.silu(_run_bn(_run_conv(x, head), bnh))
+        y = _run_conv(x, head)
+        for hook in head._forward_hooks.values():          # the third-party modules call conv_head as a module:
+            r = hook(head, (x,), y)                        # forward hooks (Grad-CAM, web_ui.py:96-114) see its output
+            if r is not None:
+                y = r
+        x = F.silu(_run_bn(y, bnh))
         x = x.mean((2, 3))
         if dropout_mask is not None:
             x = x * dropout_mask

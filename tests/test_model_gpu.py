@@ -248,3 +248,47 @@ def test_reproducible_bitwise():
         outs.append((logits.detach().clone(), hip.conv_stem.weight.grad.clone()))
     assert torch.equal(outs[0][0], outs[1][0])
     assert torch.equal(outs[0][1], outs[1][1])
+
+
+@pytest.mark.parametrize("variant,flavour,attr", [("b0", "timm", "conv_head"), ("b3", "lukemelas", "_conv_head")])
+def test_grad_cam_hooks_on_head_conv(variant, flavour, attr):
+    """web_ui.py:96-114 picks `_conv_head` (or the last nn.Conv2d) and pytorch_grad_cam hangs a forward hook on
+    it that keeps the output activation and registers a gradient hook on it.  With hooks present the engine runs
+    the head unfused (eval mode): activation and its gradient must match the oracle's."""
+    ref, hip = make_pair(variant, flavour, 2)
+    # calibrated running statistics (fresh ones let the signal die out in eval mode)
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(4, 3, 96, 96, generator=g)
+    bns = [m for m in ref.modules() if isinstance(m, torch.nn.BatchNorm2d)]
+    for m in bns:
+        m.momentum = 1.0
+    ref.train()
+    with torch.no_grad():
+        ref(x)
+    hip.load_state_dict(ref.state_dict())
+    ref.eval(); hip.eval()
+
+    kept = {}
+
+    def make_hook(tag):
+        def hook(module, inputs, output):
+            kept[tag + "_act"] = output
+            if output.requires_grad:
+                output.register_hook(lambda grad: kept.__setitem__(tag + "_grad", grad))
+        return hook
+
+    h1 = getattr(ref, attr).register_forward_hook(make_hook("ref"))
+    h2 = getattr(hip, attr).register_forward_hook(make_hook("hip"))
+    try:
+        ref_logits = ref(x)
+        ref_logits[:, 1].sum().backward()
+        hip_logits = hip(x.cuda())
+        hip_logits[:, 1].sum().backward()
+    finally:
+        h1.remove(); h2.remove()
+    assert rel_err(hip_logits, ref_logits) <= 1e-3
+    assert tuple(kept["hip_act"].shape) == tuple(kept["ref_act"].shape)            # NCHW, like the third-party module
+    assert rel_err(kept["hip_act"], kept["ref_act"]) <= 1e-3
+    assert rel_err(kept["hip_grad"], kept["ref_grad"]) <= 2e-3
+    # without hooks the fused path is back
+    assert rel_err(hip(x.cuda()), ref_logits) <= 1e-3
