@@ -139,10 +139,26 @@ PW_CASES = [
 ]
 
 
+# rows well above one pass of the persistent grids (wave-autonomous NT kernel: several 128/256-row tiles
+# per workgroup, two-deep register prefetch), ragged so that the last tile and the last wave are partial
+PW_LARGE_CASES = [(3, 70001, 32, 16), (2, 100003, 16, 96), (3, 66001, 144, 24), (3, 66003, 24, 144), (2, 99001, 40, 240)]
+
+
 @pytest.mark.parametrize("rd", DT)
 @pytest.mark.parametrize("mode", [0, 1, 2, 3])
 @pytest.mark.parametrize("case", PW_CASES)
 def test_pwconv_fwd(case, mode, rd):
+    _pwconv_fwd_case(case, mode, rd)
+
+
+@pytest.mark.parametrize("rd", DT)
+@pytest.mark.parametrize("mode", [0, 2, 3])
+@pytest.mark.parametrize("case", PW_LARGE_CASES)
+def test_pwconv_fwd_large_m(case, mode, rd):
+    _pwconv_fwd_case(case, mode, rd)
+
+
+def _pwconv_fwd_case(case, mode, rd):
     K = _k()
     N, HW, Kd, No = case
     a = gen((N, HW, 1, Kd), 11, rd)
