@@ -1,0 +1,110 @@
+"""Turn the rocprofv3 outputs of one round into the files under profiles/.
+
+    python scripts/make_profile_summary.py <tag> <gpurun_out/prof_TAG dir> <gpurun_out/pmc_TAG dir> <bench default json>
+
+Inputs: `rocprofv3 --kernel-trace --stats` of `bench.py --steps 10 --warmup 2 ...` (kernel stats csv),
+four `rocprofv3 --pmc` passes of `bench.py --steps 2 --warmup 1 --no-graph ...` (FETCH_SIZE | WRITE_SIZE |
+TCC_EA0_RDREQ_* | TCC_EA0_WRREQ_*), and the JSON line of a plain `python bench.py`.
+Outputs: profiles/<tag>_bench_kernel_stats.csv, _pmc_traffic.json, _bench_default_line.json, _summary.md."""
+import collections
+import csv
+import json
+import shutil
+import sys
+from pathlib import Path
+
+tag, prof_dir, pmc_dir, bench_json = sys.argv[1], Path(sys.argv[2]), Path(sys.argv[3]), Path(sys.argv[4])
+out = Path(__file__).resolve().parents[1] / "profiles"
+FAM = collections.OrderedDict([
+    ("pwconv", ("k_pw_ntw", "k_pw_nt<")), ("pwconv_wgrad", ("k_pw_tnw", "k_pw_tn<")),
+    ("dwconv_bwd_data", ("k_dw_bwd_data_q",)), ("dwconv_bwd_weight", ("k_dw_bwd_weight_q",)), ("dwconv_fwd", ("k_dw_fwd_q",)),
+    ("act_bn_bwd", ("k_act_bn_bwd",)), ("pool", ("k_pool",)), ("bn_finalize", ("k_bn_finalize", "k_bn_bwd_finalize")),
+    ("sum_partials", ("k_sum_partials",)), ("bn_bwd_reduce", ("k_bn_bwd_reduce",)), ("bn_act_apply", ("k_bn_act_apply",)),
+    ("stem", ("k_stem",)), ("se_mlp", ("k_se_", "k_transpose")), ("prep_weights", ("k_prep_weights",)), ("adamw", ("k_adamw",))])
+
+
+def family(name):
+    for f, keys in FAM.items():
+        if any(k in name for k in keys):
+            return f
+    return "other"
+
+
+stats = list(csv.DictReader(open(next(prof_dir.glob("*kernel_stats.csv")))))
+steps = int([r for r in stats if "k_stem_fwd" in r["Name"]][0]["Calls"])
+agg = collections.OrderedDict((f, [0, 0.0]) for f in list(FAM) + ["other"])
+for r in stats:
+    a = agg[family(r["Name"])]
+    a[0] += int(r["Calls"])
+    a[1] += float(r["TotalDurationNs"])
+
+
+def pmc(name, cols):
+    tot = collections.defaultdict(lambda: collections.defaultdict(float))
+    disp = collections.defaultdict(set)
+    for r in csv.DictReader(open(pmc_dir / f"{name}_counter_collection.csv")):
+        f = family(r["Kernel_Name"])
+        tot[f][r["Counter_Name"]] += float(r["Counter_Value"])
+        disp[f].add(r["Dispatch_Id"])
+    return tot, {f: len(v) for f, v in disp.items()}
+
+
+PMC_STEPS = 6          # 3 eager sizing + 1 warm-up + 2 timed, all eager
+fs, nd = pmc("FETCH_SIZE", None)
+ws, _ = pmc("WRITE_SIZE", None)
+rd, _ = pmc("TCC_EA0_RDREQ_sum", None)
+wr, _ = pmc("TCC_EA0_WRREQ_sum", None)
+traffic = {}
+for f in agg:
+    r, w = rd[f], wr[f]
+    other = max(0.0, r["TCC_EA0_RDREQ_sum"] - r["TCC_EA0_RDREQ_128B_sum"] - r["TCC_EA0_RDREQ_64B_sum"] - r["TCC_EA0_RDREQ_32B_sum"])
+    ea_rd = (r["TCC_EA0_RDREQ_128B_sum"] * 128 + r["TCC_EA0_RDREQ_64B_sum"] * 64 + r["TCC_EA0_RDREQ_32B_sum"] * 32 + other * 64) / PMC_STEPS / 1e9
+    ea_wr = (w["TCC_EA0_WRREQ_64B_sum"] * 64 + (w["TCC_EA0_WRREQ_sum"] - w["TCC_EA0_WRREQ_64B_sum"]) * 32) / PMC_STEPS / 1e9
+    traffic[f] = {"dispatches_per_step": nd.get(f, 0) / PMC_STEPS,
+                  "fetch_size_gb_per_step_raw": round(fs[f]["FETCH_SIZE"] * 1024 / PMC_STEPS / 1e9, 4),
+                  "ea_read_gb_per_step": round(ea_rd, 4),
+                  "write_size_gb_per_step": round(ws[f]["WRITE_SIZE"] * 1024 / PMC_STEPS / 1e9, 4),
+                  "ea_write_gb_per_step": round(ea_wr, 4)}
+doc = {"_about": "HBM traffic per kernel family and training step (EfficientNet-B0, batch 256, 224 px, bf16). rocprofv3 --pmc in "
+                 "SEPARATE passes (FETCH_SIZE | WRITE_SIZE | TCC_EA0_RDREQ_* | TCC_EA0_WRREQ_*) over `bench.py --steps 2 --warmup 1 "
+                 "--no-cpu-baseline --no-graph --profile-steps 0` (6 eager steps; sums divided by 6). FETCH_SIZE is the raw counter "
+                 "(KB -> bytes): on gfx950 it under-reports reads by 2x for every family here — TCC_EA0_RDREQ (128-byte requests x 128 B) "
+                 "gives twice its bytes — so read traffic = ea_read. WRITE_SIZE agrees with TCC_EA0_WRREQ.",
+       "steps": PMC_STEPS, "families": traffic}
+(out / f"{tag}_pmc_traffic.json").write_text(json.dumps(doc, indent=1))
+shutil.copy(next(prof_dir.glob("*kernel_stats.csv")), out / f"{tag}_bench_kernel_stats.csv")
+line = json.loads(bench_json.read_text().strip().splitlines()[-1])
+(out / f"{tag}_bench_default_line.json").write_text(json.dumps(line) + "\n")
+live = {k["kernel"]: k for k in line["kernels"]}
+L = [f"# Round 1, build {tag} — rocprofv3 kernel stats next to bench.py's live numbers\n",
+     "Commands (MI355X, one GPU):\n",
+     f"* `python bench.py` → `profiles/{tag}_bench_default_line.json` ({line['value']} images/sec, {line['ms_per_step']} ms/step, "
+     f"launch: {line['config']['launch']}; f32 eval forward {line['config'].get('eval_f32_images_per_sec_per_gpu')} images/sec).",
+     f"* `rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --profile-steps 0 "
+     f"--eval-steps 0` → `profiles/{tag}_bench_kernel_stats.csv` ({steps} steps executed in that process; the table divides by {steps}).",
+     f"* four `rocprofv3 --pmc` passes (one counter group each) → `profiles/{tag}_pmc_traffic.json`; `scripts/make_profile_summary.py` made this file.\n",
+     "| family | launches/step | avg launch µs (rocprofv3) | ms/step (rocprofv3) | ms/step (bench.py live) | algorithmic GB/s (live) | HBM read GB/step | HBM write GB/step | traffic ÷ algorithmic |",
+     "|---|---|---|---|---|---|---|---|---|"]
+total = 0.0
+for f, (calls, ns) in agg.items():
+    if not calls:
+        continue
+    lv = live.get(f)
+    t = traffic[f]
+    ratio = ""
+    if lv and lv["GBps"] > 100 and lv["ms_per_step"]:
+        algo = lv["GBps"] * lv["ms_per_step"] / 1e3
+        ratio = f"{(t['ea_read_gb_per_step'] + t['ea_write_gb_per_step']) / algo:.2f}"
+    total += ns / steps / 1e6
+    L.append(f"| {f} | {calls / steps:.1f} | {ns / calls / 1e3:.1f} | {ns / steps / 1e6:.3f} | {lv['ms_per_step'] if lv else ''} | "
+             f"{lv['GBps'] if lv else ''} | {t['ea_read_gb_per_step']:.2f} | {t['ea_write_gb_per_step']:.2f} | {ratio} |")
+r = line["roofline"]
+top = agg[r["kernel"]]
+L.append(f"\nSum of kernel durations: {total:.2f} ms per step (hipGraph step: {line['ms_per_step']} ms).")
+L.append(f"\nDominant family (`roofline` of the bench line): **{r['kernel']}**, bound hbm, {r['achieved']} GB/s of {r['peak']} "
+         f"(frac {r['frac']}); live average launch {r['avg_launch_us']} µs vs rocprofv3 {top[1] / top[0] / 1e3:.1f} µs; "
+         f"traffic {r['traffic'] / 1e6 if r['traffic'] else float('nan'):.1f} MB per launch against {r['avg_launch_bytes'] / 1e6:.1f} MB algorithmic.")
+cb = line.get("cpu_baseline") or {}
+L.append(f"\nCPU baseline of the same line: {cb.get('value')} images/sec on {cb.get('cores')} cores ({cb.get('kind')}; {cb.get('sample')}).")
+(out / f"{tag}_summary.md").write_text("\n".join(L) + "\n")
+print("\n".join(L))
