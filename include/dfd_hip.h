@@ -61,6 +61,8 @@ typedef void* dfd_stream;          /* a hipStream_t */
 #define DFD_BNSTATE_ROWS 4
 #define DFD_BNCOEF_ROWS  3
 
+/* ABI revision: 100 = first release; 101 = workspace arguments on the pooling entry points,
+ * dfd_pool_ws, dfd_image_prep. */
 int dfd_version(void);
 
 /* ---------------------------------------------------------------- BatchNorm ---
