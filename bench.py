@@ -251,7 +251,8 @@ def main() -> None:
                 graph_b = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(graph_b, pool=pool, capture_error_mode="thread_local"):
                     opt.step()
-                launch = "hipgraph(fwd+bwd) | rccl all-reduce | hipgraph(adamw)"
+                coll = "rccl" if dist.get_backend() == "nccl" else dist.get_backend()
+                launch = f"hipgraph(fwd+bwd) | {coll} all-reduce | hipgraph(adamw)"
         except Exception as exc:  # noqa: BLE001 - any capture failure means: measure eagerly
             if rank == 0:
                 import traceback
