@@ -1,19 +1,6 @@
-"""`python train.py --config config/train_mi355x.yaml` — training through the orchestrator
-(drop-in for the reference's train.py: same flag, same YAML schema)."""
-
-from __future__ import annotations
-
-import argparse
-from pathlib import Path
-
-from deepfakedetection_amd.orchestration.orchestrator import orchestrate
-
-
-def main() -> None:
-    cli = argparse.ArgumentParser(description="Train deepfake detectors on the MI355X engine")
-    cli.add_argument("--config", type=Path, default=Path("config/train_mi355x.yaml"))
-    orchestrate(cli.parse_args().config.resolve(), mode="training")
-
+"""Drop-in for the reference's train.py: `python train.py --config config/train_mi355x.yaml`
+(same flag, same YAML schema; single node multi-GPU: launch it with torch.distributed.run)."""
+from deepfakedetection_amd.cli import run
 
 if __name__ == "__main__":
-    main()
+    run("training", "config/train_mi355x.yaml")
