@@ -52,6 +52,7 @@ SIGNATURES: dict[str, tuple] = {
     "dfd_bn_act_apply": (c_int, [c_int, P, P, c_int, P, P, P, c_int, c_int, c_int, P]),
     "dfd_bn_bwd_reduce": (c_int, [c_int, P, P, P, P, c_int, c_int, c_int, P, c_int, _PI, P]),
     "dfd_act_bn_bwd": (c_int, [c_int, P, P, P, P, P, c_int, P, c_int, c_int, c_int, P, c_int, _PI, P]),
+    "dfd_prep_weights_multi": (c_int, [P, c_int, P]),
     "dfd_image_prep": (c_int, [P, P, c_int, c_int, c_int, POINTER(c_float), POINTER(c_float), P, P, P]),
     "dfd_pool_ws": (c_size_t, [c_int, c_int, c_int, c_int]),
     "dfd_pool_act": (c_int, [c_int, P, P, c_int, P, c_int, c_int, c_int, P, c_size_t, P]),
@@ -77,6 +78,13 @@ SIGNATURES: dict[str, tuple] = {
     "dfd_softmax_argmax": (c_int, [P, c_int, c_int, P, P, P]),
     "dfd_adamw_step": (c_int, [P, c_int, P, P]),
 }
+
+class PrepJob(Structure):
+    """struct dfd_prep_job (include/dfd_hip.h)."""
+
+    _fields_ = [("src", c_void_p), ("nk", c_void_p), ("kn", c_void_p), ("N", c_int), ("K", c_int), ("dtype", c_int),
+                ("_pad", c_int)]
+
 
 _lib: ctypes.CDLL | None = None
 

@@ -170,11 +170,12 @@ __global__ void k_transpose_f32(const float* __restrict__ in, float* __restrict_
 
 extern "C" int dfd_se_fc_fwd(const float* pooled, const float* w1, const float* b1, const float* w2, const float* b2,
                              int N, int C, int R, int act, float* hpre, float* gate, float* w2t, dfd_stream stream) {
-    if (!pooled || !w1 || !w2 || !hpre || !gate || !w2t || N < 1 || C < 1 || R < 1) return DFD_EINVAL;
+    if (!pooled || !w1 || !hpre || !gate || !w2t || N < 1 || C < 1 || R < 1) return DFD_EINVAL;
     if (C > SE_MAX_C || R > SE_MAX_R) return DFD_EUNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     // w2 is [C][R]; every use sums over r for many c (or over c for few r): keep an [R][C] copy
-    hipLaunchKernelGGL(k_transpose_f32, dim3((C * R + 255) / 256), dim3(256), 0, st, w2, w2t, C, R);
+    // (w2 == NULL: the caller has already filled w2t, e.g. with dfd_prep_weights_multi)
+    if (w2) hipLaunchKernelGGL(k_transpose_f32, dim3((C * R + 255) / 256), dim3(256), 0, st, w2, w2t, C, R);
     hipLaunchKernelGGL(k_se_hidden, dim3((R + 3) / 4, N), dim3(DFD_THREADS), 0, st, pooled, w1, b1, C, R, hpre);
     DISPATCH_ACT(act, {
         hipLaunchKernelGGL((k_se_gate<ACT>), dim3((C + DFD_THREADS - 1) / DFD_THREADS, N), dim3(DFD_THREADS), 0, st, hpre, w2t,

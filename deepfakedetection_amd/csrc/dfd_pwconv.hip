@@ -528,6 +528,51 @@ extern "C" int dfd_pw_prep_weights(int dtype, const float* w, void* w_nk, void* 
     return DFD_CHECK_LAUNCH();
 }
 
+// ---- all derived weights of a network in ONE launch per 32 jobs (instead of one k_prep_weights per layer
+// and one transpose per squeeze-excite block): job = f32 [N][K] -> `nk` (same layout, element type T or
+// f32) and / or `kn` ([K][N]).  Jobs travel by value in the kernel arguments, so a captured hipGraph needs
+// no table upload.
+#define PREP_JOBS_PER_LAUNCH 32
+struct PrepJobs { dfd_prep_job j[PREP_JOBS_PER_LAUNCH]; };
+__global__ void __launch_bounds__(256)
+k_prep_weights_multi(PrepJobs jobs) {
+    const dfd_prep_job& jb = jobs.j[blockIdx.y];
+    const long total = (long)jb.N * jb.K;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const long i = ((long)blockIdx.x * 4 + u) * 256 + threadIdx.x;
+        if (i >= total) return;
+        const int n = (int)(i / jb.K), k = (int)(i - (long)n * jb.K);
+        const float v = jb.src[i];
+        if (jb.dtype == DFD_BF16) {
+            if (jb.nk) reinterpret_cast<unsigned short*>(jb.nk)[i] = f2bf(v);
+            if (jb.kn) reinterpret_cast<unsigned short*>(jb.kn)[(long)k * jb.N + n] = f2bf(v);
+        } else {
+            if (jb.nk) reinterpret_cast<float*>(jb.nk)[i] = v;
+            if (jb.kn) reinterpret_cast<float*>(jb.kn)[(long)k * jb.N + n] = v;
+        }
+    }
+}
+extern "C" int dfd_prep_weights_multi(const dfd_prep_job* jobs, int njobs, dfd_stream stream) {
+    if (!jobs || njobs < 1) return DFD_EINVAL;
+    for (int i = 0; i < njobs; ++i) {
+        const dfd_prep_job& j = jobs[i];
+        if (!j.src || (!j.nk && !j.kn) || j.N < 1 || j.K < 1 || (j.dtype != DFD_BF16 && j.dtype != DFD_F32)) return DFD_EINVAL;
+    }
+    for (int base = 0; base < njobs; base += PREP_JOBS_PER_LAUNCH) {
+        PrepJobs pj;
+        const int cnt = njobs - base < PREP_JOBS_PER_LAUNCH ? njobs - base : PREP_JOBS_PER_LAUNCH;
+        long most = 0;
+        for (int i = 0; i < cnt; ++i) {
+            pj.j[i] = jobs[base + i];
+            const long t = (long)pj.j[i].N * pj.j[i].K;
+            if (t > most) most = t;
+        }
+        hipLaunchKernelGGL(k_prep_weights_multi, dim3((unsigned)((most + 1023) / 1024), cnt), dim3(256), 0, (hipStream_t)stream, pj);
+    }
+    return DFD_CHECK_LAUNCH();
+}
+
 // ===========================================================================
 // host dispatch
 // ===========================================================================

@@ -579,4 +579,4 @@ extern "C" int dfd_bn_bwd_finalize(const float* partials, int nparts, int C, dou
     return DFD_CHECK_LAUNCH();
 }
 
-extern "C" int dfd_version(void) { return 101; }   // 101: pool workspace arguments, dfd_pool_ws, dfd_image_prep
+extern "C" int dfd_version(void) { return 102; }   // see include/dfd_hip.h

@@ -21,6 +21,7 @@ without autocast: trainers/efficientnet.py:249-254, orchestrator.py:587-590).
 from __future__ import annotations
 
 import math
+import os
 import warnings
 
 import torch
@@ -99,15 +100,15 @@ class HipMBConv(nn.Module):
             mod = getattr(mod, piece)
         return mod
 
-    def forward(self, x: torch.Tensor) -> torch.Tensor:  # x: NHWC
+    def forward(self, x: torch.Tensor, derived: tuple | None = None) -> torch.Tensor:  # x: NHWC
         p = self.plan
         row_scale = None
         if self.training and p.skip and p.drop_connect > 0:
             keep = 1.0 - p.drop_connect
             row_scale = torch.floor(keep + torch.rand(x.shape[0], device=x.device, dtype=torch.float32)) / keep
-        return self.run(x, row_scale)
+        return self.run(x, row_scale, derived)
 
-    def run(self, x: torch.Tensor, row_scale: torch.Tensor | None) -> torch.Tensor:
+    def run(self, x: torch.Tensor, row_scale: torch.Tensor | None, derived: tuple | None = None) -> torch.Tensor:
         p = self.plan
         dw, dw_bn = self.part("dw"), self.part("dw_bn")
         ser, see = self.part("se_reduce"), self.part("se_expand")
@@ -117,7 +118,7 @@ class HipMBConv(nn.Module):
             w_exp, g_exp, b_exp, ref_exp = exp.weight, exp_bn.weight, exp_bn.bias, _bnref(exp_bn)
         else:
             w_exp = g_exp = b_exp = ref_exp = None
-        cfg = MBConvCtx(p.expand, p.dw, p.skip, ref_exp, _bnref(dw_bn), _bnref(proj_bn), self.training)
+        cfg = MBConvCtx(p.expand, p.dw, p.skip, ref_exp, _bnref(dw_bn), _bnref(proj_bn), self.training, derived)
         return MBConvFunction.apply(x, w_exp, g_exp, b_exp, dw.weight, dw_bn.weight, dw_bn.bias, ser.weight, ser.bias,
                                     see.weight, see.bias, proj.weight, proj_bn.weight, proj_bn.bias, row_scale, cfg)
 
@@ -202,9 +203,47 @@ class HipEfficientNet(nn.Module):
         xh = x.detach().float().contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1)
         h = StemFunction.apply(xh, stem.weight, stem_bn.weight, stem_bn.bias,
                                StemCtx(self.plan.stem, _bnref(stem_bn), dt, self.training))
+        derived = self._derived_weights(dt)
         for i, blk in enumerate(blocks):
-            h = blk(h) if drop_masks is None else blk.run(h, drop_masks[i])
+            h = blk(h, derived[i]) if drop_masks is None else blk.run(h, drop_masks[i], derived[i])
+        self._head_derived = derived[len(blocks)]
         return h
+
+    def _derived_weights(self, dt: torch.dtype) -> list:
+        """One batched launch per forward refreshes every derived weight of the network (1x1 conv weights in
+        the activation dtype as [N][K] and [K][N], [R][C] copies of the squeeze-excite expand weights);
+        returns, per block, ((wexp_nk, wexp_kn) | None, (wproj_nk, wproj_kn), se_w2t) and last the head's pair.
+        The buffers and the job list are rebuilt only when a parameter moved (e.g. after .to())."""
+        from . import kernels as K
+
+        _, _, blocks, head, _, _ = self._parts()
+        if os.environ.get("DFD_NO_DERIVED") == "1":            # A/B switch: per-layer preparation
+            return [None] * (len(blocks) + 1)
+        items, layout = [], []
+        for blk in blocks:
+            p = blk.plan
+            if p.expand:
+                items.append((blk.part("expand").weight, True, True, False))
+            items.append((blk.part("project").weight, True, True, False))
+            items.append((blk.part("se_expand").weight, False, True, True))
+            layout.append(p.expand)
+        items.append((head.weight, True, True, False))
+        cache = getattr(self, "_derived_cache", None)
+        if cache is None or not cache.valid_for([it[0] for it in items], dt):
+            cache = self._derived_cache = K.DerivedWeights(items, dt)
+        cache.refresh()
+        out, at = [], 0
+        for has_exp in layout:
+            exp = None
+            if has_exp:
+                exp = cache.out[at]
+                at += 1
+            proj = cache.out[at]
+            w2t = cache.out[at + 1][1]
+            at += 2
+            out.append((exp, proj, w2t))
+        out.append(cache.out[at])
+        return out
 
     def forward(self, x: torch.Tensor, drop_masks=None, dropout_u: torch.Tensor | None = None) -> torch.Tensor:
         """drop_masks / dropout_u let a test inject the stochastic-depth masks (already
@@ -219,7 +258,7 @@ class HipEfficientNet(nn.Module):
             if head._forward_hooks or head._forward_pre_hooks:
                 out = self._hooked_head(h, head, head_bn, fc)
             else:
-                cfg = HeadCtx(_bnref(head_bn), self.drop_rate, self.training)
+                cfg = HeadCtx(_bnref(head_bn), self.drop_rate, self.training, self._head_derived)
                 out = HeadFunction.apply(h, head.weight, head_bn.weight, head_bn.bias, fc.weight, fc.bias, u, cfg)
         finally:
             F_.end_counter_batch()

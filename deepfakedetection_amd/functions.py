@@ -144,6 +144,9 @@ class MBConvCtx:
     bn_dw: BNRef
     bn_project: BNRef
     training: bool
+    # derived weights prepared for the whole network in one launch (kernels.DerivedWeights):
+    # ((wexp_nk, wexp_kn) | None, (wproj_nk, wproj_kn), se_w2t); None: prepare per layer
+    derived: tuple | None = None
 
 
 class MBConvFunction(torch.autograd.Function):
@@ -163,7 +166,7 @@ class MBConvFunction(torch.autograd.Function):
         Ho, Wo = geom.out_size(H), geom.out_size(W)
         need_bwd = any(ctx.needs_input_grad)   # grad mode is off inside forward(); this is the autograd view
         if cfg.expand:
-            wexp_nk, wexp_kn = K.prep_weights(w_exp, dt, True, need_bwd)
+            wexp_nk, wexp_kn = cfg.derived[0] if cfg.derived is not None else K.prep_weights(w_exp, dt, True, need_bwd)
             y1, parts, n = K.pwconv(x, None, wexp_nk, None, stats=tr)
             st1 = _bn_state(parts, n, N * H * W, cfg.bn_expand, g_exp, b_exp, tr)
             y2, parts, n = K.dwconv_fwd(y1, st1, ACT_SILU, w_dw, geom.kernel, geom.stride, geom.pad_lead, geom.pad_lead,
@@ -175,8 +178,8 @@ class MBConvFunction(torch.autograd.Function):
         st2 = _bn_state(parts, n, N * Ho * Wo, cfg.bn_dw, g_dw, b_dw, tr)
         pooled = K.pool_act(y2, st2, ACT_SILU)
         w1, w2 = se_w1.reshape(se_w1.shape[0], -1), se_w2.reshape(se_w2.shape[0], -1)
-        hpre, gate, w2t = K.se_fc_fwd(pooled, w1, se_b1, w2, se_b2, ACT_SILU)
-        wproj_nk, wproj_kn = K.prep_weights(w_proj, dt, True, need_bwd)
+        hpre, gate, w2t = K.se_fc_fwd(pooled, w1, se_b1, w2, se_b2, ACT_SILU, cfg.derived[2] if cfg.derived is not None else None)
+        wproj_nk, wproj_kn = cfg.derived[1] if cfg.derived is not None else K.prep_weights(w_proj, dt, True, need_bwd)
         pro = K.pro_bn_act_gate(st2, ACT_SILU, gate, Ho * Wo)
         y3, parts, n = K.pwconv(y2, pro, wproj_nk, None, stats=tr)
         st3 = _bn_state(parts, n, N * Ho * Wo, cfg.bn_project, g_proj, b_proj, tr)
@@ -261,6 +264,7 @@ class HeadCtx:
     bn: BNRef
     dropout: float
     training: bool
+    derived: tuple | None = None          # (w_nk, w_kn) from kernels.DerivedWeights, or None
 
 
 class HeadFunction(torch.autograd.Function):
@@ -270,7 +274,7 @@ class HeadFunction(torch.autograd.Function):
     def forward(ctx, x, w_head, gamma, beta, w_fc, b_fc, drop_u, cfg: HeadCtx):
         N, H, W, Cin = x.shape
         need_bwd = any(ctx.needs_input_grad)
-        w_nk, w_kn = K.prep_weights(w_head, x.dtype, True, need_bwd)
+        w_nk, w_kn = cfg.derived if cfg.derived is not None else K.prep_weights(w_head, x.dtype, True, need_bwd)
         y, parts, n = K.pwconv(x, None, w_nk, None, stats=cfg.training)
         st = _bn_state(parts, n, N * H * W, cfg.bn, gamma, beta, cfg.training)
         pooled = K.pool_act(y, st, ACT_SILU)

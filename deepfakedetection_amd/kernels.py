@@ -258,14 +258,17 @@ def image_prep(src_u8: torch.Tensor, mean, std, flip: torch.Tensor | None, erase
 
 
 # ------------------------------------------------------------------ squeeze-excite
-def se_fc_fwd(pooled: torch.Tensor, w1, b1, w2, b2, act: int):
+def se_fc_fwd(pooled: torch.Tensor, w1, b1, w2, b2, act: int, w2t: torch.Tensor | None = None):
+    """w2t given: the [R, C] copy of w2 is already up to date (DerivedWeights) and the transpose is skipped."""
     N, C = pooled.shape
     R = w1.shape[0]
     hpre = torch.empty((N, R), dtype=torch.float32, device=pooled.device)
     gate = torch.empty((N, C), dtype=torch.float32, device=pooled.device)
-    w2t = torch.empty((R, C), dtype=torch.float32, device=pooled.device)
-    check(_L().dfd_se_fc_fwd(_p(pooled), _p(w1), _p(b1), _p(w2), _p(b2), N, C, R, act, _p(hpre), _p(gate), _p(w2t),
-                             _stream()), "dfd_se_fc_fwd", f"C={C} R={R}")
+    ready = w2t is not None
+    if not ready:
+        w2t = torch.empty((R, C), dtype=torch.float32, device=pooled.device)
+    check(_L().dfd_se_fc_fwd(_p(pooled), _p(w1), _p(b1), None if ready else _p(w2), _p(b2), N, C, R, act, _p(hpre), _p(gate),
+                             _p(w2t), _stream()), "dfd_se_fc_fwd", f"C={C} R={R}")
     return hpre, gate, w2t
 
 
@@ -366,6 +369,38 @@ def prep_weights(w: torch.Tensor, dtype: torch.dtype, want_nk: bool = True, want
     code = BF16 if dtype == torch.bfloat16 else F32
     check(_L().dfd_pw_prep_weights(code, _p(w), _p(w_nk), _p(w_kn), Nn, K, _stream()), "dfd_pw_prep_weights")
     return w_nk, w_kn
+
+
+class DerivedWeights:
+    """Every per-step derived weight of a network, refreshed by ONE batched launch per forward pass:
+    the activation-dtype copies [N][K] / [K][N] of the 1x1 convolution weights and the [R][C] copies of the
+    squeeze-excite expand weights.  `items`: (f32 source, want_nk, want_kn, is_se) in a fixed order; the
+    destination buffers are allocated once and handed out by index."""
+
+    def __init__(self, items: list[tuple[torch.Tensor, bool, bool, bool]], dtype: torch.dtype) -> None:
+        from ._lib import PrepJob
+
+        self.dtype = dtype
+        self.sources = [src for src, _, _, _ in items]
+        self.ptrs = [src.data_ptr() for src in self.sources]
+        self.out: list[tuple[torch.Tensor | None, torch.Tensor | None]] = []
+        jobs = (PrepJob * len(items))()
+        for i, (src, want_nk, want_kn, is_se) in enumerate(items):
+            n, kdim = src.shape[0], src.shape[1]
+            dt = torch.float32 if is_se else dtype
+            nk = torch.empty((n, kdim), dtype=dt, device=src.device) if want_nk else None
+            kn = torch.empty((kdim, n), dtype=dt, device=src.device) if want_kn else None
+            self.out.append((nk, kn))
+            jobs[i] = PrepJob(src.data_ptr(), nk.data_ptr() if nk is not None else None,
+                              kn.data_ptr() if kn is not None else None, n, kdim, BF16 if dt == torch.bfloat16 else F32, 0)
+        self._jobs = jobs
+
+    def valid_for(self, sources: list[torch.Tensor], dtype: torch.dtype) -> bool:
+        return dtype == self.dtype and len(sources) == len(self.ptrs) and all(
+            s.data_ptr() == p for s, p in zip(sources, self.ptrs))
+
+    def refresh(self) -> None:
+        check(_L().dfd_prep_weights_multi(self._jobs, len(self._jobs), _stream()), "dfd_prep_weights_multi")
 
 
 def pwconv(a: torch.Tensor, pro: Prologue | None, w_nk: torch.Tensor, residual: torch.Tensor | None = None,

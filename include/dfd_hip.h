@@ -62,7 +62,7 @@ typedef void* dfd_stream;          /* a hipStream_t */
 #define DFD_BNCOEF_ROWS  3
 
 /* ABI revision: 100 = first release; 101 = workspace arguments on the pooling entry points,
- * dfd_pool_ws, dfd_image_prep. */
+ * dfd_pool_ws, dfd_image_prep; 102 = dfd_prep_weights_multi, dfd_se_fc_fwd accepts a prepared w2t. */
 int dfd_version(void);
 
 /* ---------------------------------------------------------------- BatchNorm ---
@@ -120,7 +120,7 @@ int dfd_scale_rows(int dtype, const void* x, const float* row_scale, void* out,
  * MBConvBlock._se_reduce/_se_expand (efficientnet_pytorch), SqueezeExcite (timm):
  * gate = sigmoid(W2 * act(W1*pooled + b1) + b2).                                 */
 /* w2 is torch's [C][R]; w2t [R][C] is written by the forward (coalesced reads) and is
- * what the backward takes. */
+ * what the backward takes.  w2 == NULL: w2t was prepared by the caller (dfd_prep_weights_multi). */
 int dfd_se_fc_fwd(const float* pooled, const float* w1, const float* b1, const float* w2,
                   const float* b2, int N, int C, int R, int act, float* hpre, float* gate,
                   float* w2t, dfd_stream stream);
@@ -190,6 +190,18 @@ size_t dfd_pwconv_wgrad_ws(int M, int Ni, int Nj);
 /* f32 master [N][K] -> w_nk [N][K] and w_kn [K][N] in `dtype` (either may be NULL) */
 int dfd_pw_prep_weights(int dtype, const float* w, void* w_nk, void* w_kn, int N, int K,
                         dfd_stream stream);
+/* Every derived weight of a network in one call (launched 32 jobs at a time): src f32 [N][K] -> nk ([N][K],
+ * element type `dtype`) and / or kn ([K][N]); either destination may be NULL.  Also used for the [R][C] copy
+ * of the squeeze-excite expand weight (dtype DFD_F32, kn only).  `jobs` is a HOST array.                   */
+typedef struct dfd_prep_job {
+    const float* src;
+    void* nk;
+    void* kn;
+    int N, K;
+    int dtype;
+    int _pad;
+} dfd_prep_job;
+int dfd_prep_weights_multi(const dfd_prep_job* jobs, int njobs, dfd_stream stream);
 
 /* ------------------------------------------------------------------- stem ---
  * _conv_stem / conv_stem: k x k stride-2 convolution on the 3-channel f32 image.  */
