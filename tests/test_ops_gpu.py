@@ -492,3 +492,29 @@ def test_image_prep_matches_cpu_transforms_bit_for_bit():
     got2 = K.image_prep(src.cuda(), mean, std, None, None)
     want2 = torch.stack([norm(src[n].permute(2, 0, 1).to(torch.float32).div_(255.0)) for n in range(N)])
     assert torch.equal(got2.cpu(), want2)
+
+
+@pytest.mark.parametrize("rd", DT)
+def test_prep_weights_multi_matches_per_layer(rd):
+    """dfd_prep_weights_multi (one launch for every derived weight of a network, >32 jobs = two launches) against
+    the per-layer dfd_pw_prep_weights and a plain transpose for the squeeze-excite copies."""
+    K = _k()
+    g = torch.Generator().manual_seed(81)
+    items = []
+    for i in range(37):
+        n, k = int(torch.randint(1, 40, (1,), generator=g)) * 8, int(torch.randint(1, 30, (1,), generator=g)) * 8
+        w = torch.randn((n, k, 1, 1), generator=g).cuda()
+        items.append((w, i % 3 != 2, True, i % 5 == 4))
+    dw = K.DerivedWeights(items, rd)
+    dw.refresh()
+    for (w, want_nk, want_kn, is_se), (nk, kn) in zip(items, dw.out):
+        if is_se:
+            assert kn.dtype == torch.float32 and torch.equal(kn, w.reshape(w.shape[0], -1).t().contiguous())
+            continue
+        ref_nk, ref_kn = K.prep_weights(w, rd, True, True)
+        if want_nk:
+            assert torch.equal(nk, ref_nk)
+        else:
+            assert nk is None
+        assert torch.equal(kn, ref_kn)
+    assert dw.valid_for([w for w, *_ in items], rd) and not dw.valid_for([w for w, *_ in items][:-1], rd)
