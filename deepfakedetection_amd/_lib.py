@@ -7,7 +7,7 @@ symbol cannot be resolved, importing/using the kernels raises immediately.
 from __future__ import annotations
 
 import ctypes
-from ctypes import POINTER, Structure, c_double, c_float, c_int, c_int64, c_size_t, c_void_p
+from ctypes import POINTER, Structure, c_double, c_float, c_int, c_int64, c_long, c_size_t, c_uint32, c_void_p
 from pathlib import Path
 
 import os as _os
@@ -31,6 +31,12 @@ class DwShape(Structure):
 
 class StemShape(Structure):
     _fields_ = [(n, c_int) for n in ("N", "H", "W", "Cout", "Ho", "Wo", "k", "stride", "pad_top", "pad_left")]
+
+
+class Mat(Structure):
+    """struct dfd_mat: element (b, h, r, c) at base + b*sb + h*sh + r*sr + c*sc (element units)."""
+
+    _fields_ = [(n, c_long) for n in ("sb", "sh", "sr", "sc")]
 
 
 class Prologue(Structure):
@@ -77,6 +83,34 @@ SIGNATURES: dict[str, tuple] = {
     "dfd_ce_loss": (c_int, [P, P, c_int, c_int, c_float, c_float, P, P, P, P]),
     "dfd_softmax_argmax": (c_int, [P, c_int, c_int, P, P, P]),
     "dfd_adamw_step": (c_int, [P, c_int, P, P]),
+    # ---- ABI 110
+    "dfd_bn_finalize_ex": (c_int, [P, c_int, c_int, c_double, P, P, P, P, P, P, c_float, c_float, P, P]),
+    "dfd_bn_eval_coeffs_ex": (c_int, [P, P, P, P, P, P, c_float, c_int, P, P]),
+    "dfd_bn_bwd_finalize_ex": (c_int, [P, c_int, c_int, c_double, P, P, P, P, c_int, P, P, P, P, c_int, P, P]),
+    "dfd_affine2_apply": (c_int, [c_int, P, P, P, P, c_long, c_int, P]),
+    "dfd_bn_add_act": (c_int, [c_int, P, P, P, c_int, P, c_long, c_int, P]),
+    "dfd_bn_add_act_bwd": (c_int, [c_int, P, P, P, P, c_int, P, c_long, c_int, P, c_int, _PI, P]),
+    "dfd_channel_stats": (c_int, [c_int, P, c_long, c_int, P, c_int, _PI, P]),
+    "dfd_sum_rows": (c_int, [P, c_int, c_long, P, c_int, P]),
+    "dfd_up2_act_fwd": (c_int, [c_int, P, c_int, P, c_int, c_int, c_int, c_int, P]),
+    "dfd_up2_act_bwd": (c_int, [c_int, P, P, c_int, P, c_int, c_int, c_int, c_int, P]),
+    "dfd_subsample_add": (c_int, [c_int, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
+    "dfd_subsample_add_bwd": (c_int, [c_int, P, P, c_int, c_int, c_int, c_int, c_int, P]),
+    "dfd_bgemm": (c_int, [c_int, P, POINTER(Mat), c_int, P, POINTER(Mat), c_int, P, POINTER(Mat), P, c_float, c_int, c_int,
+                          c_int, c_int, c_int, c_int, c_int, P]),
+    "dfd_attn_softmax_fwd": (c_int, [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P]),
+    "dfd_attn_softmax_bwd": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, P]),
+    "dfd_bias_gather": (c_int, [P, P, P, c_int, c_int, c_long, P]),
+    "dfd_bias_scatter": (c_int, [P, P, P, c_int, c_int, c_long, c_int, P]),
+    "dfd_im2col": (c_int, [c_int, P, P, c_int, P, POINTER(DwShape), P]),
+    "dfd_col2im": (c_int, [c_int, P, P, POINTER(DwShape), P]),
+    "dfd_conv_weight_perm": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P]),
+    "dfd_layernorm_fwd": (c_int, [c_int, P, P, P, c_float, P, P, c_long, c_int, P]),
+    "dfd_layernorm_bwd": (c_int, [c_int, P, P, P, P, P, P, c_int, _PI, c_long, c_int, P]),
+    "dfd_axpby": (c_int, [P, P, c_float, c_float, P, P, c_long, P]),
+    "dfd_add": (c_int, [c_int, P, P, P, c_long, P]),
+    "dfd_rand": (c_int, [P, c_uint32, c_float, P, c_long, P]),
+    "dfd_step_tick": (c_int, [P, c_int, P, P]),
 }
 
 class PrepJob(Structure):
@@ -123,6 +157,6 @@ def check(code: int, op: str, detail: str = "") -> None:
 
 __all__ = [
     "ACT_GELU", "ACT_NONE", "ACT_RELU", "ACT_SILU", "ADAMW_HP_LEN", "ADAMW_TABLE_COLS", "BF16", "F32",
-    "MAX_PARTIALS", "PRO_AFFINE2", "PRO_BN_ACT", "PRO_BN_ACT_GATE", "PRO_NONE", "DwShape", "Prologue",
+    "MAX_PARTIALS", "Mat", "PRO_AFFINE2", "PRO_BN_ACT", "PRO_BN_ACT_GATE", "PRO_NONE", "DwShape", "Prologue",
     "StemShape", "SIGNATURES", "check", "load", "c_int64",
 ]

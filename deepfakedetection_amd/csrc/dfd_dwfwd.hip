@@ -15,7 +15,7 @@
 //     (sum, sumsq) row per workgroup, BN + SiLU of the producer applied once per staged
 //     element, zero padding written in the activated domain.
 #include "dfd_dwq.h"
-#include <cstdlib>
+#include <climits>
 
 template <typename T, int K, int S, int ACT, bool PRO, bool STATS>
 __global__ void __launch_bounds__(DFD_THREADS, 4)
@@ -199,7 +199,19 @@ bool dfd_dwq_geom(const dfd_dwconv_shape* s, int vec, int max_cvb, bool centre_i
     g->iw_magic = ((1u << 20) + g->IW - 1) / g->IW;
     g->tiles_y = (CH + bTH - 1) / bTH;
     g->tiles_x = (CW + 4 * bQW - 1) / (4 * bQW);
+    if ((long)s->N * g->tiles_y * g->tiles_x > INT_MAX / 2) return false;        // int work counters in the kernels
     g->nwork = s->N * g->tiles_y * g->tiles_x;
+    // the kernels divide by QW and IW with 20-bit magic numbers ((v * magic) >> 20): check them over the
+    // whole range they are used on (v < NQ and v < IH*IW, both < 4096) instead of trusting the bound
+    for (unsigned v = 0; v < (unsigned)g->NQ; ++v)
+        if (((v * g->qw_magic) >> 20) != v / (unsigned)bQW) return false;
+    for (unsigned v = 0; v < (unsigned)(g->IH * g->IW); ++v)
+        if (((v * g->iw_magic) >> 20) != v / (unsigned)g->IW) return false;
+    {   // the weight-gradient kernel stages the centre tile with a magic for TW = 4*QW
+        const unsigned TW = 4u * (unsigned)bQW, tw_magic = ((1u << 20) + TW - 1) / TW;
+        for (unsigned v = 0; v < (unsigned)bTH * TW; ++v)
+            if (((v * tw_magic) >> 20) != v / TW) return false;
+    }
     *tile_bytes = g->IH * g->IW * cvb * 16;
     g->remap = 0;
     return true;
@@ -217,7 +229,6 @@ static int dw_fwd_q_t(const void* x, const float* in_bnstate, int in_act, const 
     // tile is one image (14x14, 7x7 layers: +8..17 %)
     g.remap = (nchunks > 1 && g.tiles_y * g.tiles_x >= 2 &&
                ((s->C * (int)sizeof(T)) % 128 != 0 || (cvb * 16) % 128 != 0)) ? 1 : 0;
-    if (const char* e = getenv("DFD_DW_FWD_REMAP")) g.remap = atoi(e);      // tuning experiments only
     const bool stats = partials != nullptr;
     int cap = stats ? (pcap < DFD_MAX_PARTIALS ? pcap : DFD_MAX_PARTIALS) : DFD_MAX_PARTIALS;
     int gy = 2048 / nchunks;

@@ -97,11 +97,12 @@ __device__ __forceinline__ uint4 apply_pro_c(uint4 q, uint4 q2, const float (&c0
     }
 }
 
-// activations instantiated for the GEMM prologues (EfficientNet: SiLU)
+// activations instantiated for the GEMM prologues (EfficientNet: SiLU; EfficientFormerV2 / FasterViT: GELU)
 #define DISPATCH_ACT_PW(ACTV, ...)                                                   \
     switch (ACTV) {                                                                  \
         case DFD_ACT_NONE: { constexpr int ACT = DFD_ACT_NONE; __VA_ARGS__; } break; \
         case DFD_ACT_SILU: { constexpr int ACT = DFD_ACT_SILU; __VA_ARGS__; } break; \
+        case DFD_ACT_GELU: { constexpr int ACT = DFD_ACT_GELU; __VA_ARGS__; } break; \
         default: return DFD_EUNSUPPORTED;                                            \
     }
 static inline bool pro_ok(const dfd_prologue* p) {

@@ -297,6 +297,7 @@ __device__ __forceinline__ void fin_reduce(const float* __restrict__ partials, i
 __global__ void __launch_bounds__(FIN_CH * FIN_LANES)
 k_bn_finalize(const float* __restrict__ partials, int nparts, int C, double count,
               const float* __restrict__ gamma, const float* __restrict__ beta,
+              const float* __restrict__ conv_bias, const float* __restrict__ ls,
               float* __restrict__ rmean, float* __restrict__ rvar, float momentum, float eps,
               float* __restrict__ bnstate) {
     __shared__ double sm[FIN_CH * FIN_LANES * 2];
@@ -310,47 +311,61 @@ k_bn_finalize(const float* __restrict__ partials, int nparts, int C, double coun
         const float rstd = (float)(1.0 / sqrt(var + (double)eps));
         const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
         const float scale = g * rstd;
-        bnstate[c] = scale;
-        bnstate[C + c] = b - (float)mean * scale;
+        const float l = ls ? ls[c] : 1.f;                  // LayerScale folded into the affine map
+        bnstate[c] = l * scale;
+        bnstate[C + c] = l * (b - (float)mean * scale);
         bnstate[2 * C + c] = (float)mean;
         bnstate[3 * C + c] = rstd;
         if (rmean) {
+            // the convolution's bias never enters the kernels: a constant per channel cancels in
+            // batch-statistics BatchNorm and only shifts the running mean
             const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
-            rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)mean;
+            const float mb = (float)mean + (conv_bias ? conv_bias[c] : 0.f);
+            rmean[c] = (1.f - momentum) * rmean[c] + momentum * mb;
             rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unbiased;
         }
     }
 }
 
 __global__ void k_bn_eval_coeffs(const float* __restrict__ gamma, const float* __restrict__ beta,
+                                 const float* __restrict__ conv_bias, const float* __restrict__ ls,
                                  const float* __restrict__ rmean, const float* __restrict__ rvar, float eps, int C,
                                  float* __restrict__ bnstate) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
     const float rstd = 1.0f / sqrtf(rvar[c] + eps);
     const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+    const float m = rmean[c] - (conv_bias ? conv_bias[c] : 0.f);      // BN(y + bias) == BN'(y) with mean - bias
+    const float l = ls ? ls[c] : 1.f;
     const float scale = g * rstd;
-    bnstate[c] = scale;
-    bnstate[C + c] = b - rmean[c] * scale;
-    bnstate[2 * C + c] = rmean[c];
+    bnstate[c] = l * scale;
+    bnstate[C + c] = l * (b - m * scale);
+    bnstate[2 * C + c] = m;
     bnstate[3 * C + c] = rstd;
 }
 
 __global__ void __launch_bounds__(FIN_CH * FIN_LANES)
 k_bn_bwd_finalize(const float* __restrict__ partials, int nparts, int C, double count,
-                  const float* __restrict__ gamma, const float* __restrict__ bnstate, int train,
-                  float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate,
-                  float* __restrict__ coef) {
+                  const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ ls,
+                  const float* __restrict__ bnstate, int train,
+                  float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ dls, float* __restrict__ dbias,
+                  int accumulate, float* __restrict__ coef) {
     __shared__ double sm[FIN_CH * FIN_LANES * 2];
     const int c = blockIdx.x * FIN_CH + (threadIdx.x & (FIN_CH - 1)), q = threadIdx.x / FIN_CH;
     double s1, s2;
     fin_reduce(partials, nparts, C, c, q, sm, s1, s2);
     if (c < C && q == 0) {
-        if (dgamma) dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)s2;
-        if (dbeta) dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)s1;
-        const double g = gamma ? (double)gamma[c] : 1.0;
+        // s1 = sum dz, s2 = sum dz*xhat with dz = d loss / d (ls * BN(y)); BN(y) = gamma*xhat + beta
+        const double l = ls ? (double)ls[c] : 1.0;
+        const double g0 = gamma ? (double)gamma[c] : 1.0;
+        if (dgamma) dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)(l * s2);
+        if (dbeta) dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)(l * s1);
+        if (dls) dls[c] = (accumulate ? dls[c] : 0.f) + (float)(g0 * s2 + (beta ? (double)beta[c] : 0.0) * s1);
+        const double g = g0 * l;
         const double mean = bnstate[2 * C + c], rstd = bnstate[3 * C + c];
         const double a = g * rstd;
+        // the producing convolution's bias: d/d bias = sum dy, exactly 0 through batch statistics
+        if (dbias) dbias[c] = (accumulate ? dbias[c] : 0.f) + (train ? 0.f : (float)(a * s1));
         double b = 0.0, cc = 0.0;
         if (train) {
             b = -g * rstd * rstd * s2 / count;
@@ -551,32 +566,51 @@ extern "C" int dfd_pool_bwd_reduce(int dtype, const void* D, const void* y, cons
                              : pool_t<float, true>(D, y, bnstate, act, dgate, N, HW, C, ws, ws_bytes, st);
 }
 
-extern "C" int dfd_bn_finalize(const float* partials, int nparts, int C, double count, const float* gamma,
-                               const float* beta, float* running_mean, float* running_var, float momentum, float eps,
-                               float* bnstate, dfd_stream stream) {
+extern "C" int dfd_bn_finalize_ex(const float* partials, int nparts, int C, double count, const float* gamma,
+                                  const float* beta, const float* conv_bias, const float* ls_gamma, float* running_mean,
+                                  float* running_var, float momentum, float eps, float* bnstate, dfd_stream stream) {
     if (!partials || nparts < 1 || C < 1 || count <= 0 || !bnstate) return DFD_EINVAL;
     if ((running_mean == nullptr) != (running_var == nullptr)) return DFD_EINVAL;
     const int threads = FIN_CH * FIN_LANES, grid = (C + FIN_CH - 1) / FIN_CH;
     hipLaunchKernelGGL(k_bn_finalize, dim3(grid), dim3(threads), 0, (hipStream_t)stream, partials, nparts, C, count, gamma,
-                       beta, running_mean, running_var, momentum, eps, bnstate);
+                       beta, conv_bias, ls_gamma, running_mean, running_var, momentum, eps, bnstate);
+    return DFD_CHECK_LAUNCH();
+}
+extern "C" int dfd_bn_finalize(const float* partials, int nparts, int C, double count, const float* gamma,
+                               const float* beta, float* running_mean, float* running_var, float momentum, float eps,
+                               float* bnstate, dfd_stream stream) {
+    return dfd_bn_finalize_ex(partials, nparts, C, count, gamma, beta, nullptr, nullptr, running_mean, running_var, momentum,
+                              eps, bnstate, stream);
+}
+extern "C" int dfd_bn_eval_coeffs_ex(const float* gamma, const float* beta, const float* conv_bias, const float* ls_gamma,
+                                     const float* running_mean, const float* running_var, float eps, int C, float* bnstate,
+                                     dfd_stream stream) {
+    if (!running_mean || !running_var || C < 1 || !bnstate) return DFD_EINVAL;
+    const int threads = 256, grid = (C + threads - 1) / threads;
+    hipLaunchKernelGGL(k_bn_eval_coeffs, dim3(grid), dim3(threads), 0, (hipStream_t)stream, gamma, beta, conv_bias, ls_gamma,
+                       running_mean, running_var, eps, C, bnstate);
     return DFD_CHECK_LAUNCH();
 }
 extern "C" int dfd_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean,
                                   const float* running_var, float eps, int C, float* bnstate, dfd_stream stream) {
-    if (!running_mean || !running_var || C < 1 || !bnstate) return DFD_EINVAL;
-    const int threads = 256, grid = (C + threads - 1) / threads;
-    hipLaunchKernelGGL(k_bn_eval_coeffs, dim3(grid), dim3(threads), 0, (hipStream_t)stream, gamma, beta, running_mean,
-                       running_var, eps, C, bnstate);
+    return dfd_bn_eval_coeffs_ex(gamma, beta, nullptr, nullptr, running_mean, running_var, eps, C, bnstate, stream);
+}
+extern "C" int dfd_bn_bwd_finalize_ex(const float* partials, int nparts, int C, double count, const float* gamma,
+                                      const float* beta, const float* ls_gamma, const float* bnstate, int train,
+                                      float* dgamma, float* dbeta, float* dls, float* dbias, int accumulate, float* coef,
+                                      dfd_stream stream) {
+    if (!partials || nparts < 1 || C < 1 || count <= 0 || !bnstate || !coef) return DFD_EINVAL;
+    if (dls && (!ls_gamma || !beta)) return DFD_EINVAL;
+    const int threads = FIN_CH * FIN_LANES, grid = (C + FIN_CH - 1) / FIN_CH;
+    hipLaunchKernelGGL(k_bn_bwd_finalize, dim3(grid), dim3(threads), 0, (hipStream_t)stream, partials, nparts, C, count,
+                       gamma, beta, ls_gamma, bnstate, train, dgamma, dbeta, dls, dbias, accumulate, coef);
     return DFD_CHECK_LAUNCH();
 }
 extern "C" int dfd_bn_bwd_finalize(const float* partials, int nparts, int C, double count, const float* gamma,
                                    const float* bnstate, int train, float* dgamma, float* dbeta, int accumulate,
                                    float* coef, dfd_stream stream) {
-    if (!partials || nparts < 1 || C < 1 || count <= 0 || !bnstate || !coef) return DFD_EINVAL;
-    const int threads = FIN_CH * FIN_LANES, grid = (C + FIN_CH - 1) / FIN_CH;
-    hipLaunchKernelGGL(k_bn_bwd_finalize, dim3(grid), dim3(threads), 0, (hipStream_t)stream, partials, nparts, C, count,
-                       gamma, bnstate, train, dgamma, dbeta, accumulate, coef);
-    return DFD_CHECK_LAUNCH();
+    return dfd_bn_bwd_finalize_ex(partials, nparts, C, count, gamma, nullptr, nullptr, bnstate, train, dgamma, dbeta, nullptr,
+                                  nullptr, accumulate, coef, stream);
 }
 
-extern "C" int dfd_version(void) { return 102; }   // see include/dfd_hip.h
+extern "C" int dfd_version(void) { return 110; }   // see include/dfd_hip.h

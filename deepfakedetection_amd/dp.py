@@ -213,13 +213,20 @@ class GradAllReducer:
 
 
 class ShardedSampler:
-    """Rank-strided shard of a seeded per-epoch permutation, padded so every rank sees the
-    same number of samples (the contract of torch's DistributedSampler)."""
+    """Rank-strided shard of a seeded per-epoch permutation.  pad=True (training): padded so every rank sees the
+    same number of samples (the contract of torch's DistributedSampler — the gradient all-reduce needs equal step
+    counts).  pad=False (validation): every sample is seen exactly once over all ranks, shards may differ by one
+    (evaluate() has no collective inside its loop, so unequal lengths are fine and the metrics stay unbiased)."""
 
-    def __init__(self, length: int, rank: int, world: int, shuffle: bool = True, seed: int = 0, drop_last: bool = False) -> None:
+    def __init__(self, length: int, rank: int, world: int, shuffle: bool = True, seed: int = 0, drop_last: bool = False,
+                 pad: bool = True) -> None:
         self.length, self.rank, self.world, self.shuffle, self.seed, self.drop_last = length, rank, world, shuffle, seed, drop_last
+        self.pad = pad
         self.epoch = 0
-        self.per_rank = length // world if drop_last else math.ceil(length / world)
+        if not pad and not drop_last:
+            self.per_rank = len(range(rank, length, world))
+        else:
+            self.per_rank = length // world if drop_last else math.ceil(length / world)
 
     def set_epoch(self, epoch: int) -> None:
         self.epoch = epoch
@@ -233,6 +240,8 @@ class ShardedSampler:
             order = torch.randperm(self.length, generator=g).tolist()
         else:
             order = list(range(self.length))
+        if not self.pad and not self.drop_last:
+            return iter(order[self.rank::self.world])
         total = self.per_rank * self.world
         if self.drop_last:
             order = order[:total]

@@ -32,6 +32,22 @@ from .arch import BlockPlan, NetPlan, efficientnet_plan
 from .functions import (BNRef, HeadConvFunction, HeadCtx, HeadFunction, HeadTailEvalFunction, MBConvCtx, MBConvFunction,
                         StemCtx, StemFunction)
 
+# A/B switch for experiments, read once at import: per-layer weight preparation instead of the batched launch
+_NO_DERIVED = os.environ.get("DFD_NO_DERIVED") == "1"
+_default_rng: dict = {}
+
+
+def default_rng(device: torch.device):
+    """Process-wide Philox state per device, for stages used outside of a HipEfficientNet (tests, plug-ins)."""
+    from . import kernels as K
+
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    rng = _default_rng.get(key)
+    if rng is None:
+        rng = _default_rng[key] = K.DeviceRng(device)
+    return rng
+
+
 _LM_NAMES = dict(expand="_expand_conv", expand_bn="_bn0", dw="_depthwise_conv", dw_bn="_bn1",
                  se_reduce="_se_reduce", se_expand="_se_expand", project="_project_conv", project_bn="_bn2")
 _TIMM_IR_NAMES = dict(expand="conv_pw", expand_bn="bn1", dw="conv_dw", dw_bn="bn2",
@@ -100,15 +116,18 @@ class HipMBConv(nn.Module):
             mod = getattr(mod, piece)
         return mod
 
-    def forward(self, x: torch.Tensor, derived: tuple | None = None) -> torch.Tensor:  # x: NHWC
+    def forward(self, x: torch.Tensor, derived: tuple | None = None, rng=None, counters: list | None = None) -> torch.Tensor:
+        """x: NHWC.  Drop-connect (efficientnet_pytorch utils.drop_connect): per-sample Bernoulli(keep) / keep, drawn
+        by the Philox kernel from the owning network's device-resident state."""
         p = self.plan
         row_scale = None
         if self.training and p.skip and p.drop_connect > 0:
-            keep = 1.0 - p.drop_connect
-            row_scale = torch.floor(keep + torch.rand(x.shape[0], device=x.device, dtype=torch.float32)) / keep
-        return self.run(x, row_scale, derived)
+            rng = rng if rng is not None else default_rng(x.device)
+            row_scale = rng.drop_path_scale(x.shape[0], 1.0 - p.drop_connect, stream_id=p.index)
+        return self.run(x, row_scale, derived, counters)
 
-    def run(self, x: torch.Tensor, row_scale: torch.Tensor | None, derived: tuple | None = None) -> torch.Tensor:
+    def run(self, x: torch.Tensor, row_scale: torch.Tensor | None, derived: tuple | None = None,
+            counters: list | None = None) -> torch.Tensor:
         p = self.plan
         dw, dw_bn = self.part("dw"), self.part("dw_bn")
         ser, see = self.part("se_reduce"), self.part("se_expand")
@@ -118,7 +137,7 @@ class HipMBConv(nn.Module):
             w_exp, g_exp, b_exp, ref_exp = exp.weight, exp_bn.weight, exp_bn.bias, _bnref(exp_bn)
         else:
             w_exp = g_exp = b_exp = ref_exp = None
-        cfg = MBConvCtx(p.expand, p.dw, p.skip, ref_exp, _bnref(dw_bn), _bnref(proj_bn), self.training, derived)
+        cfg = MBConvCtx(p.expand, p.dw, p.skip, ref_exp, _bnref(dw_bn), _bnref(proj_bn), self.training, derived, counters)
         return MBConvFunction.apply(x, w_exp, g_exp, b_exp, dw.weight, dw_bn.weight, dw_bn.bias, ser.weight, ser.bias,
                                     see.weight, see.bias, proj.weight, proj_bn.weight, proj_bn.bias, row_scale, cfg)
 
@@ -195,17 +214,27 @@ class HipEfficientNet(nn.Module):
     def block_list(self) -> list[HipMBConv]:
         return self._parts()[2]
 
-    def forward_features_nhwc(self, x: torch.Tensor, drop_masks=None) -> torch.Tensor:
+    def rng(self, device: torch.device):
+        """This network's Philox state on `device` (created on first use, seeded from torch.initial_seed())."""
+        from . import kernels as K
+
+        cur = self.__dict__.get("_rng_obj")
+        if cur is None or cur.state.device != device:
+            cur = self.__dict__["_rng_obj"] = K.DeviceRng(device)
+        return cur
+
+    def forward_features_nhwc(self, x: torch.Tensor, drop_masks=None, counters: list | None = None) -> torch.Tensor:
         stem, stem_bn, blocks, _, _, _ = self._parts()
         if not x.is_cuda:
             raise RuntimeError("HipEfficientNet runs on a HIP device only (no CPU fallback); move the input with .to('cuda')")
         dt = compute_dtype()
         xh = x.detach().float().contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1)
         h = StemFunction.apply(xh, stem.weight, stem_bn.weight, stem_bn.bias,
-                               StemCtx(self.plan.stem, _bnref(stem_bn), dt, self.training))
+                               StemCtx(self.plan.stem, _bnref(stem_bn), dt, self.training, counters))
         derived = self._derived_weights(dt)
+        rng = self.rng(x.device) if self.training else None
         for i, blk in enumerate(blocks):
-            h = blk(h, derived[i]) if drop_masks is None else blk.run(h, drop_masks[i], derived[i])
+            h = blk(h, derived[i], rng, counters) if drop_masks is None else blk.run(h, drop_masks[i], derived[i], counters)
         self._head_derived = derived[len(blocks)]
         return h
 
@@ -217,7 +246,7 @@ class HipEfficientNet(nn.Module):
         from . import kernels as K
 
         _, _, blocks, head, _, _ = self._parts()
-        if os.environ.get("DFD_NO_DERIVED") == "1":            # A/B switch: per-layer preparation
+        if _NO_DERIVED:                                        # A/B switch: per-layer preparation
             return [None] * (len(blocks) + 1)
         items, layout = [], []
         for blk in blocks:
@@ -228,9 +257,14 @@ class HipEfficientNet(nn.Module):
             items.append((blk.part("se_expand").weight, False, True, True))
             layout.append(p.expand)
         items.append((head.weight, True, True, False))
-        cache = getattr(self, "_derived_cache", None)
+        # one cache entry PER DTYPE: the trainer alternates bf16 training and f32 evaluation, and a captured
+        # hipGraph holds raw pointers into its entry, so an entry is never freed by a train/eval switch; the
+        # buffers are ordinary (non-inference) tensors even when first built under torch.inference_mode()
+        caches = self.__dict__.setdefault("_derived_caches", {})
+        cache = caches.get(dt)
         if cache is None or not cache.valid_for([it[0] for it in items], dt):
-            cache = self._derived_cache = K.DerivedWeights(items, dt)
+            with torch.inference_mode(False):
+                cache = caches[dt] = K.DerivedWeights(items, dt)
         cache.refresh()
         out, at = [], 0
         for has_exp in layout:
@@ -249,19 +283,18 @@ class HipEfficientNet(nn.Module):
         """drop_masks / dropout_u let a test inject the stochastic-depth masks (already
         1/keep scaled, one [N] tensor or None per block) and the dropout uniforms."""
         _, _, _, head, head_bn, fc = self._parts()
-        F_.begin_counter_batch()
-        try:
-            h = self.forward_features_nhwc(x, drop_masks)
-            u = dropout_u
-            if u is None and self.training and self.drop_rate > 0 and drop_masks is None:
-                u = torch.rand((h.shape[0], head.out_channels), device=h.device, dtype=torch.float32)
-            if head._forward_hooks or head._forward_pre_hooks:
-                out = self._hooked_head(h, head, head_bn, fc)
-            else:
-                cfg = HeadCtx(_bnref(head_bn), self.drop_rate, self.training, self._head_derived)
-                out = HeadFunction.apply(h, head.weight, head_bn.weight, head_bn.bias, fc.weight, fc.bias, u, cfg)
-        finally:
-            F_.end_counter_batch()
+        counters: list = []                 # owned by this call: num_batches_tracked of every BatchNorm that ran
+        h = self.forward_features_nhwc(x, drop_masks, counters)
+        u = dropout_u
+        if u is None and self.training and self.drop_rate > 0 and drop_masks is None:
+            u = self.rng(h.device).uniform(h.shape[0] * head.out_channels, stream_id=1 << 20).view(h.shape[0], head.out_channels)
+        if head._forward_hooks or head._forward_pre_hooks:
+            out = self._hooked_head(h, head, head_bn, fc)
+        else:
+            cfg = HeadCtx(_bnref(head_bn), self.drop_rate, self.training, self._head_derived, counters)
+            out = HeadFunction.apply(h, head.weight, head_bn.weight, head_bn.bias, fc.weight, fc.bias, u, cfg)
+        if self.training:
+            self.rng(h.device).tick(counters)       # one launch: every counter += 1, Philox offset += 1
         return out
 
 

@@ -40,39 +40,21 @@ class BNRef:
         return K.BNParams(weight, bias, self.running_mean, self.running_var, self.momentum, self.eps)
 
 
-# When a whole network runs one forward pass, its 49 num_batches_tracked counters are bumped by ONE
-# multi-tensor launch at the end (HipEfficientNet.forward) instead of 49 five-microsecond kernels.
-_deferred_counters: list[torch.Tensor] | None = None
-
-
-def begin_counter_batch() -> None:
-    global _deferred_counters
-    _deferred_counters = []
-
-
-def end_counter_batch() -> None:
-    global _deferred_counters
-    pending, _deferred_counters = _deferred_counters, None
-    if pending:
-        torch._foreach_add_(pending, 1)
-
-
-def _bn_state(parts, nparts, count: int, bn: BNRef, weight, bias, training: bool) -> torch.Tensor:
+def _bn_state(parts, nparts, count: int, bn: BNRef, weight, bias, training: bool, counters: list | None = None,
+              conv_bias=None, ls=None) -> torch.Tensor:
+    """BatchNorm coefficients of one layer.  `counters`: the list owned by the calling network's forward pass; the
+    layer's num_batches_tracked is appended and the network bumps all of them with ONE launch at the end
+    (kernels.DeviceRng.tick).  A stage used on its own (counters None) bumps its counter itself."""
+    params = bn.params(weight, bias)
+    params.conv_bias, params.ls = conv_bias, ls
     if training:
         if bn.num_batches_tracked is not None:
-            if _deferred_counters is not None:
-                _deferred_counters.append(bn.num_batches_tracked)
+            if counters is not None:
+                counters.append(bn.num_batches_tracked)
             else:
                 bn.num_batches_tracked.add_(1)
-        return K.bn_finalize(parts, nparts, count, bn.params(weight, bias))
-    return K.bn_eval_coeffs(bn.params(weight, bias))
-
-
-def _identity_state(C: int, device) -> torch.Tensor:
-    st = torch.zeros((4, C), dtype=torch.float32, device=device)
-    st[0].fill_(1.0)
-    st[3].fill_(1.0)
-    return st
+        return K.bn_finalize(parts, nparts, count, params)
+    return K.bn_eval_coeffs(params)
 
 
 def _c(t: torch.Tensor) -> torch.Tensor:
@@ -98,6 +80,7 @@ class StemCtx:
     bn: BNRef
     dtype: torch.dtype
     training: bool
+    counters: list | None = None          # see _bn_state
 
 
 class StemFunction(torch.autograd.Function):
@@ -109,7 +92,7 @@ class StemFunction(torch.autograd.Function):
         N, H, W, _ = x.shape
         Ho, Wo = g.out_size(H), g.out_size(W)
         y, parts, n = K.stem_conv_fwd(x, weight, cfg.dtype, g.stride, g.pad_lead, g.pad_lead, Ho, Wo, stats=cfg.training)
-        st = _bn_state(parts, n, N * Ho * Wo, cfg.bn, gamma, beta, cfg.training)
+        st = _bn_state(parts, n, N * Ho * Wo, cfg.bn, gamma, beta, cfg.training, cfg.counters)
         out = K.bn_act_apply(y, st, ACT_SILU)
         ctx.cfg = cfg
         ctx.pptr = _ptrs(x, weight, gamma, beta)
@@ -147,6 +130,7 @@ class MBConvCtx:
     # derived weights prepared for the whole network in one launch (kernels.DerivedWeights):
     # ((wexp_nk, wexp_kn) | None, (wproj_nk, wproj_kn), se_w2t); None: prepare per layer
     derived: tuple | None = None
+    counters: list | None = None          # see _bn_state
 
 
 class MBConvFunction(torch.autograd.Function):
@@ -168,21 +152,21 @@ class MBConvFunction(torch.autograd.Function):
         if cfg.expand:
             wexp_nk, wexp_kn = cfg.derived[0] if cfg.derived is not None else K.prep_weights(w_exp, dt, True, need_bwd)
             y1, parts, n = K.pwconv(x, None, wexp_nk, None, stats=tr)
-            st1 = _bn_state(parts, n, N * H * W, cfg.bn_expand, g_exp, b_exp, tr)
+            st1 = _bn_state(parts, n, N * H * W, cfg.bn_expand, g_exp, b_exp, tr, cfg.counters)
             y2, parts, n = K.dwconv_fwd(y1, st1, ACT_SILU, w_dw, geom.kernel, geom.stride, geom.pad_lead, geom.pad_lead,
                                         Ho, Wo, stats=tr)
         else:
             wexp_kn, y1, st1 = None, None, None
             y2, parts, n = K.dwconv_fwd(x, None, ACT_NONE, w_dw, geom.kernel, geom.stride, geom.pad_lead, geom.pad_lead,
                                         Ho, Wo, stats=tr)
-        st2 = _bn_state(parts, n, N * Ho * Wo, cfg.bn_dw, g_dw, b_dw, tr)
+        st2 = _bn_state(parts, n, N * Ho * Wo, cfg.bn_dw, g_dw, b_dw, tr, cfg.counters)
         pooled = K.pool_act(y2, st2, ACT_SILU)
         w1, w2 = se_w1.reshape(se_w1.shape[0], -1), se_w2.reshape(se_w2.shape[0], -1)
         hpre, gate, w2t = K.se_fc_fwd(pooled, w1, se_b1, w2, se_b2, ACT_SILU, cfg.derived[2] if cfg.derived is not None else None)
         wproj_nk, wproj_kn = cfg.derived[1] if cfg.derived is not None else K.prep_weights(w_proj, dt, True, need_bwd)
         pro = K.pro_bn_act_gate(st2, ACT_SILU, gate, Ho * Wo)
         y3, parts, n = K.pwconv(y2, pro, wproj_nk, None, stats=tr)
-        st3 = _bn_state(parts, n, N * Ho * Wo, cfg.bn_project, g_proj, b_proj, tr)
+        st3 = _bn_state(parts, n, N * Ho * Wo, cfg.bn_project, g_proj, b_proj, tr, cfg.counters)
         out = K.bn_act_apply(y3, st3, ACT_NONE, x if cfg.skip else None, row_scale if cfg.skip else None)
         ctx.cfg = cfg
         ctx.pptr = _ptrs(x, w_exp, g_exp, b_exp, w_dw, g_dw, b_dw, se_w1, se_b1, se_w2, se_b2, w_proj, g_proj, b_proj)
@@ -252,7 +236,7 @@ class MBConvFunction(torch.autograd.Function):
                 dx, _, _ = K.dwconv_bwd_data(dz2, y2, coef2, w_dw, None, None, ACT_NONE, ctx.in_shape, geom.kernel,
                                              geom.stride, geom.pad_lead, geom.pad_lead)
                 if cfg.skip:
-                    dx = K.bn_act_apply(dx, _identity_state(Cin, dx.device), ACT_NONE, g, None)
+                    dx = K.add(dx, g)
         K.join_side()
         return (dx, dw_exp, dg_exp, db_exp, dw_dw, dg_dw, db_dw, dw1, db1, dw2, db2, dw_proj, dg_proj, db_proj,
                 None, None)
@@ -265,6 +249,7 @@ class HeadCtx:
     dropout: float
     training: bool
     derived: tuple | None = None          # (w_nk, w_kn) from kernels.DerivedWeights, or None
+    counters: list | None = None          # see _bn_state
 
 
 class HeadFunction(torch.autograd.Function):
@@ -276,7 +261,7 @@ class HeadFunction(torch.autograd.Function):
         need_bwd = any(ctx.needs_input_grad)
         w_nk, w_kn = cfg.derived if cfg.derived is not None else K.prep_weights(w_head, x.dtype, True, need_bwd)
         y, parts, n = K.pwconv(x, None, w_nk, None, stats=cfg.training)
-        st = _bn_state(parts, n, N * H * W, cfg.bn, gamma, beta, cfg.training)
+        st = _bn_state(parts, n, N * H * W, cfg.bn, gamma, beta, cfg.training, cfg.counters)
         pooled = K.pool_act(y, st, ACT_SILU)
         feat = K.dropout(pooled, drop_u, cfg.dropout) if drop_u is not None else pooled
         logits = K.linear_fwd(feat, w_fc, b_fc)
@@ -354,10 +339,10 @@ class HeadTailEvalFunction(torch.autograd.Function):
             dpooled, _, _ = K.linear_bwd(_c(dlogits.float()), pooled, w_fc, True, False, False, None, None)
             dz, _, _ = K.act_bn_bwd(None, y, None, dpooled, st, ACT_SILU)          # d loss / d (BN output)
             C = y.shape[3]
-            chain = torch.zeros((4, C), dtype=torch.float32, device=y.device)       # eval BN: dy = scale * dz
-            chain[0].copy_(st[0])
-            chain[3].fill_(1.0)
-            dy = K.bn_act_apply(dz, chain, ACT_NONE, None, None)
+            coef = torch.empty((3, C), dtype=torch.float32, device=y.device)        # eval BN: dy = scale * dz
+            coef[0].copy_(st[0])
+            coef[1:].zero_()
+            dy = K.affine2_apply(dz, y, coef)
         return dy, None, None, None, None, None
 
 
@@ -375,7 +360,7 @@ class CrossEntropyFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gloss):
         (dlogits,) = ctx.saved_tensors
-        return dlogits * gloss, None, None
+        return K.axpby(dlogits, None, 1.0, 0.0, a_dev=gloss.reshape(1).float()), None, None
 
 
 __all__ = ["BNRef", "CrossEntropyFunction", "HeadConvFunction", "HeadCtx", "HeadFunction", "HeadTailEvalFunction", "MBConvCtx", "MBConvFunction", "StemCtx",

@@ -21,7 +21,7 @@ from ._lib import (
     DwShape, Prologue, StemShape, check,
 )
 
-_scratch: dict[tuple[int, str], torch.Tensor] = {}
+_scratch: dict[tuple[int, int, str], torch.Tensor] = {}
 
 
 def _L():
@@ -97,8 +97,9 @@ def _chk_nhwc(t: torch.Tensor) -> None:
 
 
 def scratch(device: torch.device, name: str, nbytes: int) -> torch.Tensor:
-    """A grow-only f32 scratch buffer per (device, purpose); reuse is stream-ordered."""
-    key = (device.index if device.index is not None else torch.cuda.current_device(), name)
+    """A grow-only f32 scratch buffer per (device, stream, purpose): reuse is ordered by the stream it belongs to,
+    so two models / threads on different streams never share a buffer (the C ABI itself is re-entrant)."""
+    key = (device.index if device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream, name)
     buf = _scratch.get(key)
     need = (nbytes + 3) // 4
     if buf is None or buf.numel() < need:
@@ -117,7 +118,8 @@ def _dst(out: torch.Tensor | None, shape, device) -> torch.Tensor:
 
 
 def partials_buf(device: torch.device, C: int) -> torch.Tensor:
-    return scratch(device, "partials", MAX_PARTIALS * 2 * C * 4)
+    # + 40 rows: room for the second stage of dfd_sum_rows when a slab is summed in place
+    return scratch(device, "partials", (MAX_PARTIALS + 40) * 2 * C * 4)
 
 
 @dataclass
@@ -130,6 +132,8 @@ class BNParams:
     running_var: torch.Tensor
     momentum: float
     eps: float
+    conv_bias: torch.Tensor | None = None      # bias of the producing convolution (timm ConvNorm), folded into the BN
+    ls: torch.Tensor | None = None             # LayerScale gamma applied to the BN output, folded into (scale, shift)
 
 
 # ------------------------------------------------------------------ BatchNorm
@@ -138,17 +142,34 @@ def bn_finalize(partials: torch.Tensor, nparts: int, count: int, bn: BNParams, u
     state = torch.empty((4, C), dtype=torch.float32, device=partials.device)
     rm = bn.running_mean if update_running else None
     rv = bn.running_var if update_running else None
-    check(_L().dfd_bn_finalize(_p(partials), nparts, C, float(count), _p(bn.weight), _p(bn.bias), _p(rm), _p(rv),
-                               bn.momentum, bn.eps, _p(state), _stream()), "dfd_bn_finalize")
+    check(_L().dfd_bn_finalize_ex(_p(partials), nparts, C, float(count), _p(bn.weight), _p(bn.bias), _p(bn.conv_bias),
+                                  _p(bn.ls), _p(rm), _p(rv), bn.momentum, bn.eps, _p(state), _stream()), "dfd_bn_finalize_ex")
     return state
 
 
 def bn_eval_coeffs(bn: BNParams) -> torch.Tensor:
     C = bn.weight.numel()
     state = torch.empty((4, C), dtype=torch.float32, device=bn.weight.device)
-    check(_L().dfd_bn_eval_coeffs(_p(bn.weight), _p(bn.bias), _p(bn.running_mean), _p(bn.running_var), bn.eps, C,
-                                  _p(state), _stream()), "dfd_bn_eval_coeffs")
+    check(_L().dfd_bn_eval_coeffs_ex(_p(bn.weight), _p(bn.bias), _p(bn.conv_bias), _p(bn.ls), _p(bn.running_mean),
+                                     _p(bn.running_var), bn.eps, C, _p(state), _stream()), "dfd_bn_eval_coeffs_ex")
     return state
+
+
+def bn_bwd_finalize_ex(partials: torch.Tensor, nparts: int, count: int, gamma: torch.Tensor, beta: torch.Tensor | None,
+                       ls: torch.Tensor | None, state: torch.Tensor, train: bool, want_bn: bool = True, want_ls: bool = False,
+                       want_bias: bool = False, outs=(None, None, None, None)):
+    """BatchNorm backward coefficients with LayerScale / convolution-bias gradients.
+    Returns (coef, dgamma, dbeta, dls, dbias); outs: optional gradient-arena slots in that order."""
+    C = gamma.numel()
+    dev = gamma.device
+    coef = torch.empty((3, C), dtype=torch.float32, device=dev)
+    dgamma = _dst(outs[0], (C,), dev) if want_bn else None
+    dbeta = _dst(outs[1], (C,), dev) if want_bn else None
+    dls = _dst(outs[2], (C,), dev) if (want_ls and ls is not None) else None
+    dbias = _dst(outs[3], (C,), dev) if want_bias else None
+    check(_L().dfd_bn_bwd_finalize_ex(_p(partials), nparts, C, float(count), _p(gamma), _p(beta), _p(ls), _p(state), int(train),
+                                      _p(dgamma), _p(dbeta), _p(dls), _p(dbias), 0, _p(coef), _stream()), "dfd_bn_bwd_finalize_ex")
+    return coef, dgamma, dbeta, dls, dbias
 
 
 def bn_bwd_finalize(partials: torch.Tensor, nparts: int, count: int, gamma: torch.Tensor, state: torch.Tensor,
@@ -196,7 +217,7 @@ def act_bn_bwd(D: torch.Tensor | None, y: torch.Tensor, gate: torch.Tensor | Non
     return dz, parts, n.value
 
 
-_pool_ws: dict[int, torch.Tensor] = {}
+_pool_ws: dict[tuple[int, int], torch.Tensor] = {}
 
 
 def _pool_workspace(y: torch.Tensor, N: int, HW: int, C: int) -> tuple[int, int]:
@@ -204,7 +225,7 @@ def _pool_workspace(y: torch.Tensor, N: int, HW: int, C: int) -> tuple[int, int]
     nbytes = int(_L().dfd_pool_ws(_dt(y), N, HW, C))
     if nbytes == 0:
         return 0, 0
-    key = y.device.index if y.device.index is not None else torch.cuda.current_device()
+    key = (y.device.index if y.device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream)
     buf = _pool_ws.get(key)
     if buf is None or buf.numel() * 4 < nbytes:
         buf = torch.zeros((nbytes + 3) // 4, dtype=torch.float32, device=y.device)
@@ -517,6 +538,243 @@ def adamw_step(table: torch.Tensor, hp: torch.Tensor) -> None:
     check(_L().dfd_adamw_step(_p(table), table.shape[0], _p(hp), _stream()), "dfd_adamw_step")
 
 
+# ------------------------------------------------------------------ token-mixer set (ABI 110)
+def _rows_c(t: torch.Tensor) -> tuple[int, int]:
+    C = t.shape[-1]
+    return t.numel() // C, C
+
+
+def affine2_apply(dz: torch.Tensor, y: torch.Tensor, coef: torch.Tensor) -> torch.Tensor:
+    rows, C = _rows_c(y)
+    out = torch.empty_like(y)
+    check(_L().dfd_affine2_apply(_dt(y), _p(dz), _p(y), _p(coef), _p(out), rows, C, _stream()), "dfd_affine2_apply")
+    return out
+
+
+def bn_add_act(y: torch.Tensor, state: torch.Tensor | None, other: torch.Tensor | None, act: int) -> torch.Tensor:
+    rows, C = _rows_c(y)
+    out = torch.empty_like(y)
+    check(_L().dfd_bn_add_act(_dt(y), _p(y), _p(state), _p(other), act, _p(out), rows, C, _stream()), "dfd_bn_add_act")
+    return out
+
+
+def bn_add_act_bwd(g: torch.Tensor, y: torch.Tensor, state: torch.Tensor | None, other: torch.Tensor | None, act: int,
+                   stats: bool = True):
+    rows, C = _rows_c(y)
+    d = torch.empty_like(y)
+    parts = partials_buf(y.device, C) if (stats and state is not None) else None
+    n = ctypes.c_int(0)
+    check(_L().dfd_bn_add_act_bwd(_dt(y), _p(g), _p(y), _p(state), _p(other), act, _p(d), rows, C, _p(parts), MAX_PARTIALS,
+                                  ctypes.byref(n), _stream()), "dfd_bn_add_act_bwd")
+    return d, parts, n.value
+
+
+def channel_stats(x: torch.Tensor):
+    rows, C = _rows_c(x)
+    parts = partials_buf(x.device, C)
+    n = ctypes.c_int(0)
+    check(_L().dfd_channel_stats(_dt(x), _p(x), rows, C, _p(parts), MAX_PARTIALS, ctypes.byref(n), _stream()), "dfd_channel_stats")
+    return parts, n.value
+
+
+def sum_rows(partials: torch.Tensor, P: int, L: int, out: torch.Tensor, accumulate: bool = False) -> torch.Tensor:
+    """out[i] = sum_p partials[p][i]; `partials` (flat f32) must hold P + ceil(P/32) rows of L floats."""
+    if partials.numel() < (P + (P + 31) // 32) * L:
+        raise ValueError("sum_rows: partial slab too small for the two-stage reduction")
+    check(_L().dfd_sum_rows(_p(partials), P, L, _p(out), int(accumulate), _stream()), "dfd_sum_rows")
+    return out
+
+
+def up2_act_fwd(s: torch.Tensor, act: int) -> torch.Tensor:
+    _chk_nhwc(s)
+    N, h, w, C = s.shape
+    out = torch.empty((N, 2 * h, 2 * w, C), dtype=s.dtype, device=s.device)
+    check(_L().dfd_up2_act_fwd(_dt(s), _p(s), act, _p(out), N, h, w, C, _stream()), "dfd_up2_act_fwd")
+    return out
+
+
+def up2_act_bwd(g: torch.Tensor, s: torch.Tensor, act: int) -> torch.Tensor:
+    N, h, w, C = s.shape
+    ds = torch.empty_like(s)
+    check(_L().dfd_up2_act_bwd(_dt(s), _p(g), _p(s), act, _p(ds), N, h, w, C, _stream()), "dfd_up2_act_bwd")
+    return ds
+
+
+def subsample_add(a: torch.Tensor, bias: torch.Tensor | None, x: torch.Tensor, stride: int) -> torch.Tensor:
+    N, H, W, C = x.shape
+    out = torch.empty_like(a)
+    check(_L().dfd_subsample_add(_dt(x), _p(a), _p(bias), _p(x), _p(out), N, H, W, stride, C, _stream()), "dfd_subsample_add")
+    return out
+
+
+def subsample_add_bwd(g: torch.Tensor, dx: torch.Tensor, stride: int) -> torch.Tensor:
+    """dx[:, ::stride, ::stride] += g, in place."""
+    N, H, W, C = dx.shape
+    check(_L().dfd_subsample_add_bwd(_dt(dx), _p(g), _p(dx), N, H, W, stride, C, _stream()), "dfd_subsample_add_bwd")
+    return dx
+
+
+def _code(dtype: torch.dtype) -> int:
+    if dtype == torch.float32:
+        return F32
+    if dtype == torch.bfloat16:
+        return BF16
+    raise TypeError(f"unsupported dtype {dtype}")
+
+
+def bgemm(A: torch.Tensor, sa: tuple, B: torch.Tensor, sb: tuple, C: torch.Tensor, sc: tuple, nb: int, nh: int, M: int, N: int,
+          Kd: int, alpha: float = 1.0, bias: torch.Tensor | None = None, round_a: bool = False, round_b: bool = False) -> None:
+    """C[b,h,m,n] = alpha * sum_k A[b,h,m,k] B[b,h,k,n] (+ bias[h,m,n]); s* = (sb, sh, sr, sc) element strides."""
+    from ._lib import Mat
+
+    ma, mb, mc = Mat(*sa), Mat(*sb), Mat(*sc)
+    check(_L().dfd_bgemm(_code(A.dtype), A.data_ptr(), ctypes.byref(ma), _code(B.dtype), B.data_ptr(), ctypes.byref(mb),
+                         _code(C.dtype), C.data_ptr(), ctypes.byref(mc), _p(bias), alpha, nb, nh, M, N, Kd, int(round_a),
+                         int(round_b), _stream()), "dfd_bgemm", f"nb={nb} nh={nh} M={M} N={N} K={Kd}")
+
+
+def attn_softmax_fwd(S: torch.Tensor, th: tuple | None):
+    """S [B,H,Nq,Nk] f32 -> (P, T2); th = (w1 [H,H], b1 [H], w2 [H,H], b2 [H]) or None (then T2 is P)."""
+    B, H, Nq, Nk = S.shape
+    P = torch.empty_like(S)
+    if th is None:
+        check(_L().dfd_attn_softmax_fwd(_p(S), None, None, None, None, _p(P), None, B, H, Nq, Nk, _stream()), "dfd_attn_softmax_fwd")
+        return P, P
+    T2 = torch.empty_like(S)
+    w1, b1, w2, b2 = th
+    check(_L().dfd_attn_softmax_fwd(_p(S), _p(w1), _p(b1), _p(w2), _p(b2), _p(P), _p(T2), B, H, Nq, Nk, _stream()),
+          "dfd_attn_softmax_fwd")
+    return P, T2
+
+
+def attn_softmax_bwd(dT2: torch.Tensor, P: torch.Tensor, th: tuple | None):
+    """-> (dT1 | None, dS)"""
+    B, H, Nq, Nk = P.shape
+    dS = torch.empty_like(P)
+    if th is None:
+        check(_L().dfd_attn_softmax_bwd(_p(dT2), _p(P), None, None, None, _p(dS), B, H, Nq, Nk, _stream()), "dfd_attn_softmax_bwd")
+        return None, dS
+    dT1 = torch.empty_like(P)
+    check(_L().dfd_attn_softmax_bwd(_p(dT2), _p(P), _p(th[0]), _p(th[2]), _p(dT1), _p(dS), B, H, Nq, Nk, _stream()),
+          "dfd_attn_softmax_bwd")
+    return dT1, dS
+
+
+def bias_gather(table: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
+    H, T = table.shape
+    L = idx.numel()
+    full = torch.empty((H, L), dtype=torch.float32, device=table.device)
+    check(_L().dfd_bias_gather(_p(table), _p(idx), _p(full), H, T, L, _stream()), "dfd_bias_gather")
+    return full
+
+
+def bias_scatter(dfull: torch.Tensor, idx: torch.Tensor, T: int, out: torch.Tensor | None = None) -> torch.Tensor:
+    H = dfull.shape[0]
+    L = idx.numel()
+    dtable = _dst(out, (H, T), dfull.device)
+    check(_L().dfd_bias_scatter(_p(dfull), _p(idx), _p(dtable), H, T, L, 0, _stream()), "dfd_bias_scatter")
+    return dtable
+
+
+def im2col(x: torch.Tensor, in_state: torch.Tensor | None, in_act: int, k: int, stride: int, pad: int, Ho: int, Wo: int) -> torch.Tensor:
+    _chk_nhwc(x)
+    N, H, W, C = x.shape
+    col = torch.empty((N, Ho, Wo, k * k * C), dtype=x.dtype, device=x.device)
+    shp = _dw_shape(x.shape, Ho, Wo, k, stride, pad, pad)
+    check(_L().dfd_im2col(_dt(x), _p(x), _p(in_state), in_act, _p(col), ctypes.byref(shp), _stream()), "dfd_im2col")
+    return col
+
+
+def col2im(dcol: torch.Tensor, in_shape, k: int, stride: int, pad: int) -> torch.Tensor:
+    N, H, W, C = in_shape
+    Ho, Wo = dcol.shape[1], dcol.shape[2]
+    dx = torch.empty((N, H, W, C), dtype=dcol.dtype, device=dcol.device)
+    shp = _dw_shape(in_shape, Ho, Wo, k, stride, pad, pad)
+    check(_L().dfd_col2im(_dt(dcol), _p(dcol), _p(dx), ctypes.byref(shp), _stream()), "dfd_col2im")
+    return dx
+
+
+def conv_weight_to_gemm(w: torch.Tensor) -> torch.Tensor:
+    """torch [O, I, k, k] f32 -> [O, k*k*I] f32 with column (kh*k + kw)*I + i."""
+    O, I, k, _ = w.shape
+    out = torch.empty((O, k * k * I), dtype=torch.float32, device=w.device)
+    check(_L().dfd_conv_weight_perm(_p(w), _p(out), O, I, k, 1, 0, _stream()), "dfd_conv_weight_perm")
+    return out
+
+
+def conv_wgrad_from_gemm(dw_gemm: torch.Tensor, shape, out: torch.Tensor | None = None) -> torch.Tensor:
+    O, I, k, _ = shape
+    dw = _dst(out, (O, I, k, k), dw_gemm.device)
+    check(_L().dfd_conv_weight_perm(_p(dw_gemm), _p(dw), O, I, k, 0, 0, _stream()), "dfd_conv_weight_perm")
+    return dw
+
+
+def layernorm_fwd(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float, want_stats: bool = True):
+    rows, C = _rows_c(x)
+    y = torch.empty_like(x)
+    stats = torch.empty((rows, 2), dtype=torch.float32, device=x.device) if want_stats else None
+    check(_L().dfd_layernorm_fwd(_dt(x), _p(x), _p(gamma), _p(beta), eps, _p(y), _p(stats), rows, C, _stream()), "dfd_layernorm_fwd")
+    return y, stats
+
+
+def layernorm_bwd(g: torch.Tensor, x: torch.Tensor, gamma: torch.Tensor, stats: torch.Tensor, out_dgamma=None, out_dbeta=None):
+    rows, C = _rows_c(x)
+    dx = torch.empty_like(x)
+    parts = partials_buf(x.device, C)
+    n = ctypes.c_int(0)
+    check(_L().dfd_layernorm_bwd(_dt(x), _p(g), _p(x), _p(gamma), _p(stats), _p(dx), _p(parts), MAX_PARTIALS, ctypes.byref(n),
+                                 rows, C, _stream()), "dfd_layernorm_bwd")
+    both = torch.empty((2, C), dtype=torch.float32, device=x.device)
+    sum_rows(parts, n.value, 2 * C, both)
+    return dx, both[0], both[1]
+
+
+def axpby(x: torch.Tensor, y: torch.Tensor | None, a: float = 1.0, b: float = 1.0, a_dev: torch.Tensor | None = None) -> torch.Tensor:
+    """(a * a_dev[0]) * x + b * y on f32 tensors."""
+    out = torch.empty_like(x)
+    check(_L().dfd_axpby(_p(x), _p(y), a, b, _p(a_dev), _p(out), x.numel(), _stream()), "dfd_axpby")
+    return out
+
+
+def add(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    out = torch.empty_like(a)
+    check(_L().dfd_add(_dt(a), _p(a), _p(b), _p(out), a.numel(), _stream()), "dfd_add")
+    return out
+
+
+class DeviceRng:
+    """Philox state {seed, offset} in device memory: every random tensor of a forward pass is a pure function of
+    (seed, offset, stream id, index), and `tick()` advances the offset with a kernel — so a captured hipGraph
+    draws fresh numbers on every replay (a host-side offset would be frozen into the graph)."""
+
+    def __init__(self, device: torch.device, seed: int | None = None) -> None:
+        seed = torch.initial_seed() if seed is None else seed
+        host = torch.tensor([seed & 0x7FFFFFFFFFFFFFFF, 0], dtype=torch.int64)
+        with torch.inference_mode(False):
+            self.state = host.to(device)
+        self._counter_key: tuple = ()
+        self._counter_table: torch.Tensor | None = None
+
+    def uniform(self, n: int, stream_id: int) -> torch.Tensor:
+        out = torch.empty(n, dtype=torch.float32, device=self.state.device)
+        check(_L().dfd_rand(_p(self.state), stream_id, 0.0, _p(out), n, _stream()), "dfd_rand")
+        return out
+
+    def drop_path_scale(self, n: int, keep: float, stream_id: int) -> torch.Tensor:
+        out = torch.empty(n, dtype=torch.float32, device=self.state.device)
+        check(_L().dfd_rand(_p(self.state), stream_id, keep, _p(out), n, _stream()), "dfd_rand")
+        return out
+
+    def tick(self, counters: list[torch.Tensor]) -> None:
+        """One launch: every int64 counter += 1 (BatchNorm.num_batches_tracked) and the Philox offset += 1."""
+        key = tuple(c.data_ptr() for c in counters)
+        if key != self._counter_key:
+            self._counter_key = key
+            with torch.inference_mode(False):
+                self._counter_table = torch.tensor(list(key), dtype=torch.int64).to(self.state.device) if key else None
+        check(_L().dfd_step_tick(_p(self._counter_table), len(key), _p(self.state), _stream()), "dfd_step_tick")
+
+
 # ------------------------------------------------------------------ measurement hook
 # bench.py installs a list here; each front-end call then appends
 # (name, algorithmic_bytes, flops, start_event, end_event).  Algorithmic bytes = every
@@ -526,7 +784,9 @@ _profile_sink: list | None = None
 _TIMED = ("bn_act_apply", "bn_bwd_reduce", "act_bn_bwd", "pool_act", "pool_bwd_reduce", "scale_rows", "dwconv_fwd",
           "dwconv_bwd_data", "dwconv_bwd_weight", "pwconv", "pwconv_wgrad", "stem_conv_fwd", "stem_conv_wgrad",
           "se_fc_fwd", "se_fc_bwd", "linear_fwd", "linear_bwd", "ce_loss", "adamw_step", "prep_weights", "bn_finalize",
-          "bn_bwd_finalize", "dropout")
+          "bn_bwd_finalize", "bn_bwd_finalize_ex", "dropout", "bgemm", "attn_softmax_fwd", "attn_softmax_bwd", "im2col", "col2im",
+          "bn_add_act", "bn_add_act_bwd", "affine2_apply", "up2_act_fwd", "up2_act_bwd", "layernorm_fwd", "layernorm_bwd",
+          "channel_stats", "subsample_add")
 
 
 def set_profile_sink(sink: list | None) -> None:

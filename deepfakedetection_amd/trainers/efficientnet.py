@@ -142,7 +142,8 @@ def build_transforms(img_size: int, gpu_tail: bool = False):
 def make_loader(dataset, batch_size: int, num_workers: int, *, shuffle: bool, rank: int = 0, world: int = 1,
                 seed: int = 0) -> DataLoader:
     extra = {"prefetch_factor": 2} if num_workers > 0 else {}
-    sampler = ShardedSampler(len(dataset), rank, world, shuffle=shuffle, seed=seed) if world > 1 else None
+    # training shards are padded to equal length (equal step counts for the all-reduce); validation shards are not
+    sampler = ShardedSampler(len(dataset), rank, world, shuffle=shuffle, seed=seed, pad=shuffle) if world > 1 else None
     return DataLoader(dataset, batch_size=batch_size, shuffle=shuffle and sampler is None, sampler=sampler,
                       num_workers=num_workers, pin_memory=True, persistent_workers=num_workers > 0, **extra)
 
@@ -221,7 +222,7 @@ def train_one_epoch(model: nn.Module, dl: DataLoader, opt: optim.Optimizer, scal
         loss_sum += loss.detach().double() * (bsz * max(1, accum_steps))
         if i % LOG_EVERY == 0 or i == len(dl):
             shown = float(loss.detach()) * max(1, accum_steps)          # the only host sync of the loop
-        seen = min(i * (dl.batch_size or bsz), len(dl.dataset))
+        seen = min(i * (dl.batch_size or bsz), len(dl.sampler) if dl.sampler is not None else len(dl.dataset))
         ips = seen / max(1e-6, perf_counter() - start)
         progress.update(task, advance=1, description=f"train | loss={shown:.4f} | {ips:.0f} img/s")
     if pending > 0:

@@ -62,7 +62,10 @@ typedef void* dfd_stream;          /* a hipStream_t */
 #define DFD_BNCOEF_ROWS  3
 
 /* ABI revision: 100 = first release; 101 = workspace arguments on the pooling entry points,
- * dfd_pool_ws, dfd_image_prep; 102 = dfd_prep_weights_multi, dfd_se_fc_fwd accepts a prepared w2t. */
+ * dfd_pool_ws, dfd_image_prep; 102 = dfd_prep_weights_multi, dfd_se_fc_fwd accepts a prepared w2t;
+ * 110 = the EfficientFormerV2 / FasterViT set (section "token mixers" below), the *_ex BatchNorm entry
+ * points (convolution bias and LayerScale folded into the BatchNorm coefficients), GELU in every
+ * prologue, and the bookkeeping kernels (dfd_rand, dfd_step_tick, dfd_axpby, dfd_add). */
 int dfd_version(void);
 
 /* ---------------------------------------------------------------- BatchNorm ---
@@ -84,6 +87,24 @@ int dfd_bn_bwd_finalize(const float* partials, int nparts, int C, double count,
                         const float* gamma, const float* bnstate, int train,
                         float* dgamma, float* dbeta, int accumulate, float* coef,
                         dfd_stream stream);
+
+/* The same three with the two per-channel vectors timm's ConvNorm / LayerScale2d add around a BatchNorm
+ * (timm efficientformer_v2.py ConvNorm: conv(bias=True) -> BatchNorm2d; LayerScale2d: x * gamma):
+ *   conv_bias [C] (optional): bias of the producing convolution.  It never enters the conv kernels: under
+ *     batch statistics it cancels, so it only shifts the running mean (training) / the mean used (eval);
+ *   ls_gamma  [C] (optional): LayerScale applied to the BatchNorm output, folded into (scale, shift).
+ * Backward: partial sums are of dz = d loss / d (ls * BN(y)); dls / dbias are optional outputs.      */
+int dfd_bn_finalize_ex(const float* partials, int nparts, int C, double count, const float* gamma,
+                       const float* beta, const float* conv_bias, const float* ls_gamma,
+                       float* running_mean, float* running_var, float momentum, float eps,
+                       float* bnstate, dfd_stream stream);
+int dfd_bn_eval_coeffs_ex(const float* gamma, const float* beta, const float* conv_bias,
+                          const float* ls_gamma, const float* running_mean, const float* running_var,
+                          float eps, int C, float* bnstate, dfd_stream stream);
+int dfd_bn_bwd_finalize_ex(const float* partials, int nparts, int C, double count, const float* gamma,
+                           const float* beta, const float* ls_gamma, const float* bnstate, int train,
+                           float* dgamma, float* dbeta, float* dls, float* dbias, int accumulate,
+                           float* coef, dfd_stream stream);
 
 /* out = act(scale*y + shift) [* row_scale[n]] [+ residual]; all [N][HW][C].     */
 int dfd_bn_act_apply(int dtype, const void* y, const float* bnstate, int act,
@@ -244,6 +265,90 @@ int dfd_image_prep(const unsigned char* src, float* dst, int N, int H, int W, co
 #define DFD_ADAMW_TABLE_COLS 5
 #define DFD_ADAMW_HP_LEN 8
 int dfd_adamw_step(const int64_t* table, int nchunks, const float* hp, dfd_stream stream);
+
+/* ------------------------------------------------------------ token mixers ---
+ * What the EfficientFormerV2 (timm 1.0.20 efficientformer_v2.py: Attention2d, Attention2dDownsample,
+ * LocalGlobalQuery, Downsample, Stem4) and FasterViT (fastervit 1.0.0 faster_vit.py: WindowAttention,
+ * HAT, ConvBlock, PatchEmbed, LayerNorm) modules need beyond the MBConv kernels.  Reference call sites:
+ * trainers/efficientformer_v2.py:244,215,369 and trainers/fastervit.py:271,235 (`model(inputs)`).       */
+
+/* out = a[c]*dz + b[c]*y + c[c]  (BatchNorm input gradient, materialised)                                */
+int dfd_affine2_apply(int dtype, const void* dz, const void* y, const float* coef, void* out, long rows,
+                      int C, dfd_stream stream);
+/* out = act(scale*y + shift + other); bnstate == NULL: y as is; other == NULL: no addend                 */
+int dfd_bn_add_act(int dtype, const void* y, const float* bnstate, const void* other, int act, void* out,
+                   long rows, int C, dfd_stream stream);
+/* d = g * act'(scale*y + shift + other); partials (optional, needs bnstate): sums of (d, d*xhat)          */
+int dfd_bn_add_act_bwd(int dtype, const void* g, const void* y, const float* bnstate, const void* other,
+                       int act, void* d, long rows, int C, float* partials, int pcap, int* nparts,
+                       dfd_stream stream);
+/* per-channel (sum, sumsq) partial slabs [nparts][2][C] of a plain [rows][C] tensor                        */
+int dfd_channel_stats(int dtype, const void* x, long rows, int C, float* partials, int pcap, int* nparts,
+                      dfd_stream stream);
+/* out[i] (+)= sum_p partials[p][i], fixed order; `partials` needs room for P + ceil(P/32) rows of L floats  */
+int dfd_sum_rows(float* partials, int P, long L, float* out, int accumulate, dfd_stream stream);
+/* out [N][2h][2w][C] = act(bilinear_x2(s [N][h][w][C])), align_corners = False (nn.Upsample in Attention2d) */
+int dfd_up2_act_fwd(int dtype, const void* s, int act, void* out, int N, int h, int w, int C, dfd_stream stream);
+int dfd_up2_act_bwd(int dtype, const void* g, const void* s, int act, void* ds, int N, int h, int w, int C,
+                    dfd_stream stream);
+/* LocalGlobalQuery: out[n,i,j,:] = a[n,i,j,:] + bias[:] + x[n, i*stride, j*stride, :]  (AvgPool2d(1, stride))
+ * and its gradient into x: dx[n, i*stride, j*stride, :] += g[n,i,j,:]                                        */
+int dfd_subsample_add(int dtype, const void* a, const float* bias, const void* x, void* out, int N, int H,
+                      int W, int stride, int C, dfd_stream stream);
+int dfd_subsample_add_bwd(int dtype, const void* g, void* dx, int N, int H, int W, int stride, int C,
+                          dfd_stream stream);
+
+/* Small strided batched GEMM  C[b,h,m,n] = alpha * sum_k A[b,h,m,k] * B[b,h,k,n] (+ bias[h,m,n]).
+ * Element (b, h, r, c) of an operand is at base + b*sb + h*sh + r*sr + c*sc (element units), so q / k / v
+ * are read in place from the NHWC projection outputs and the result lands in NHWC.  dt_*: DFD_F32 / DFD_BF16.
+ * round_a / round_b: round that operand to bf16 after loading (an f32 intermediate standing in for a tensor
+ * a bf16 pipeline would have stored).  (M*(K+1) + K*N) * 4 bytes must fit in 150 KiB of LDS.               */
+typedef struct { long sb, sh, sr, sc; } dfd_mat;
+int dfd_bgemm(int dt_a, const void* A, const dfd_mat* sa, int dt_b, const void* B, const dfd_mat* sb,
+              int dt_c, void* C, const dfd_mat* sc, const float* bias, float alpha, int nb, int nh, int M,
+              int N, int K, int round_a, int round_b, dfd_stream stream);
+/* Attention rows on S [B][H][Nq][Nk] f32:  [T1 = W1*S + b1 over heads ->] P = softmax_k(T1) [-> T2 = W2*P + b2]
+ * th_w1 == NULL: no talking heads (T2 unused).  H <= 16, Nk <= 256.                                          */
+int dfd_attn_softmax_fwd(const float* S, const float* th_w1, const float* th_b1, const float* th_w2,
+                         const float* th_b2, float* P, float* T2, int B, int H, int Nq, int Nk,
+                         dfd_stream stream);
+/* dT2 -> dS (and dT1, the gradient at the softmax input, when talking heads are on)                           */
+int dfd_attn_softmax_bwd(const float* dT2, const float* P, const float* th_w1, const float* th_w2,
+                         float* dT1, float* dS, int B, int H, int Nq, int Nk, dfd_stream stream);
+/* learned attention bias table [H][T] <-> full [H][L] through idx [L] (int32)                                 */
+int dfd_bias_gather(const float* table, const int* idx, float* full, int H, int T, long L, dfd_stream stream);
+int dfd_bias_scatter(const float* dfull, const int* idx, float* dtable, int H, int T, long L, int accumulate,
+                     dfd_stream stream);
+
+/* Dense k x k convolution = im2col + the 1x1 GEMM entry points.  Shapes use dfd_dwconv_shape (C = input
+ * channels).  col [N*Ho*Wo][k*k*C] with column index (kh*k + kw)*C + c; zero padding in the activated domain. */
+int dfd_im2col(int dtype, const void* x, const float* in_bnstate, int in_act, void* col,
+               const dfd_dwconv_shape* s, dfd_stream stream);
+int dfd_col2im(int dtype, const void* dcol, void* dx, const dfd_dwconv_shape* s, dfd_stream stream);
+/* torch's [O][I][k][k] f32 <-> the GEMM's [O][(kh,kw,i)]; to_gemm = 0 maps a weight gradient back            */
+int dfd_conv_weight_perm(const float* src, float* dst, int O, int I, int k, int to_gemm, int accumulate,
+                         dfd_stream stream);
+
+/* LayerNorm over C of [rows][C]; stats [rows][2] = (mean, rstd).  Backward partials [nparts][2][C]
+ * (row 0: dgamma, row 1: dbeta), summed by dfd_sum_rows.                                                      */
+int dfd_layernorm_fwd(int dtype, const void* x, const float* gamma, const float* beta, float eps, void* y,
+                      float* stats, long rows, int C, dfd_stream stream);
+int dfd_layernorm_bwd(int dtype, const void* g, const void* x, const float* gamma, const float* stats,
+                      void* dx, float* partials, int pcap, int* nparts, long rows, int C, dfd_stream stream);
+
+/* ---------------------------------------------------------------- bookkeeping ---
+ * Small kernels that keep ATen off the model path (drop-connect / dropout randoms, counters, scaling).        */
+/* out = (a_dev ? a*a_dev[0] : a) * x + b * y   (y may be NULL), f32                                           */
+int dfd_axpby(const float* x, const float* y, float a, float b, const float* a_dev, float* out, long n,
+              dfd_stream stream);
+/* out = a + b, n elements of `dtype`, n % 8 == 0                                                               */
+int dfd_add(int dtype, const void* a, const void* b, void* out, long n, dfd_stream stream);
+/* Philox4x32-10 uniforms.  rng_state (device): {seed, offset}; counter = (offset, stream_id, index/4).
+ * keep <= 0: out = U[0,1);  keep in (0,1]: out = floor(keep + u) / keep  (per-sample drop-path scale)          */
+int dfd_rand(const uint64_t* rng_state, uint32_t stream_id, float keep, float* out, long n, dfd_stream stream);
+/* once per forward pass: *counter_ptrs[i] += 1 (BatchNorm num_batches_tracked, int64) and rng offset += 1.
+ * counter_ptrs is a DEVICE array of ncounters addresses.                                                       */
+int dfd_step_tick(const int64_t* counter_ptrs, int ncounters, uint64_t* rng_state, dfd_stream stream);
 
 #ifdef __cplusplus
 }

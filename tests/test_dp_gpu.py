@@ -50,18 +50,19 @@ def _worker(rank: int, world: int, port: int, mode: str) -> None:
         y = torch.randint(0, 2, (8,), generator=g).to(dev)
         for step in range(2):
             opt.zero_grad(set_to_none=True)
-            torch.manual_seed(1000 + step)
+            # the engine draws its dropout uniforms from a device-resident Philox state that advances every
+            # forward pass; the two forwards compared below take the same explicit uniforms instead
+            u = torch.rand(8, 1280, generator=torch.Generator().manual_seed(1000 + step)).to(dev)
             with torch.autocast("cuda", dtype=torch.bfloat16):
-                loss = crit(model(x), y)
+                loss = crit(model(x, dropout_u=u), y)
             if mode == "hooks":
-                # reference: a hook-free backward of the same step (same dropout mask: same seed)
+                # reference: a hook-free backward of the same step (same dropout mask)
                 loss.backward()
                 torch.cuda.synchronize()
                 local = opt.arena.flat.clone()
                 opt.zero_grad(set_to_none=True)
-                torch.manual_seed(1000 + step)
                 with torch.autocast("cuda", dtype=torch.bfloat16):
-                    loss = crit(model(x), y)
+                    loss = crit(model(x, dropout_u=u), y)
                 red.arm()
                 loss.backward()
                 red.finish()
