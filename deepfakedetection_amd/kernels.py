@@ -729,9 +729,10 @@ def layernorm_bwd(g: torch.Tensor, x: torch.Tensor, gamma: torch.Tensor, stats: 
     return dx, both[0], both[1]
 
 
-def axpby(x: torch.Tensor, y: torch.Tensor | None, a: float = 1.0, b: float = 1.0, a_dev: torch.Tensor | None = None) -> torch.Tensor:
-    """(a * a_dev[0]) * x + b * y on f32 tensors."""
-    out = torch.empty_like(x)
+def axpby(x: torch.Tensor, y: torch.Tensor | None, a: float = 1.0, b: float = 1.0, a_dev: torch.Tensor | None = None,
+          out: torch.Tensor | None = None) -> torch.Tensor:
+    """(a * a_dev[0]) * x + b * y on f32 tensors (into `out`, e.g. a gradient-arena slot, when given)."""
+    out = torch.empty_like(x) if out is None else out
     check(_L().dfd_axpby(_p(x), _p(y), a, b, _p(a_dev), _p(out), x.numel(), _stream()), "dfd_axpby")
     return out
 

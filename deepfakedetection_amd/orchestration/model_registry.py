@@ -8,8 +8,11 @@ the builders return the HIP-backed modules of this package:
   efficientnet_b3   efficientnet_pytorch-compatible B3 (state-dict keys, static SAME padding) —
                     the reference's own key (model_registry.py:50-58)
   efficientnet_b0   timm-compatible B0 — the BASELINE.json configuration (new key)
-  efficientformer*  / faster_vit*  — registered with the reference's metadata; their HIP
-                    engines are not built yet and the builder says so loudly.
+  efficientformer*  timm-compatible EfficientFormerV2-{S0,S1,S2,L} on the HIP kernels (the reference's
+                    prefix entry, model_registry.py:60-66); the builder takes an optional img_size like
+                    timm.create_model does in trainers/efficientformer_v2.py:327
+  faster_vit*       registered with the reference's metadata and a real trainer module; the HIP engine is
+                    not built yet and the builder says so loudly (no ATen fallback).
 """
 
 from __future__ import annotations
@@ -40,11 +43,17 @@ def _effnet(variant: str, flavour: str) -> Callable[[str, int], nn.Module]:
     return build
 
 
+def _efformer(model_name: str, num_classes: int, img_size: int = 224) -> nn.Module:
+    from ..efficientformer_v2 import build_efficientformer_v2
+
+    return build_efficientformer_v2(model_name, num_classes, img_size)
+
+
 def _not_built(family: str) -> Callable[[str, int], nn.Module]:
     def build(model_name: str, num_classes: int) -> nn.Module:
         raise NotImplementedError(
             f"{family} ('{model_name}') is registered but its MI355X engine is not built yet; "
-            "only the EfficientNet family runs on the HIP kernels in this round (there is no ATen fallback)."
+            "the EfficientNet and EfficientFormerV2 families run on the HIP kernels (there is no ATen fallback)."
         )
 
     return build
@@ -57,7 +66,7 @@ _exact: dict[str, ModelSpec] = {
 
 _by_prefix: dict[str, ModelSpec] = {
     "efficientformer": ModelSpec("efficientformerv2_s1", "deepfakedetection_amd.trainers.efficientformer_v2",
-                                 "efficientformerv2_s1", 224, _not_built("EfficientFormerV2")),
+                                 "efficientformerv2_s1", 224, _efformer),
     "faster_vit": ModelSpec("faster_vit_2_224", "deepfakedetection_amd.trainers.fastervit", "faster_vit_2_224", 224,
                             _not_built("FasterViT")),
 }

@@ -65,16 +65,22 @@ class EvalResult:
     correct: int
 
 
-def build_transforms(img_size: int, gpu_tail: bool = False):
+def build_transforms(img_size: int, gpu_tail: bool = False, *, rotation_default: bool | None = None,
+                     erasing_default: bool | None = None, jitter=(0.2, 0.2, 0.2, 0.05), rotation_after_flip: bool = False):
     """(train, val) pipelines from the toggle defaults of the reference + $TRANSFORMS.
     gpu_tail=True: the pipelines end in uint8 HWC tensors and (train, val, train_tail, val_tail) is
-    returned, the tails being `D.GpuInputTail`s that do flip / to-float / normalise / erasing on the GPU."""
+    returned, the tails being `D.GpuInputTail`s that do flip / to-float / normalise / erasing on the GPU.
+    The keyword arguments carry what differs between the reference's three trainers (efficientnet.py:128-187 vs
+    efficientformer_v2.py:105-165 / fastervit.py:119-180): rotation / erasing off by default, ColorJitter 0.1,
+    rotation placed after the horizontal flip."""
     small = img_size <= 64
     toggles = load_transform_toggles(
         {
             "ensure_rgb": True, "train_resize": True, "train_random_crop": small, "train_center_crop": False,
             "train_random_resized_crop": not small, "train_random_horizontal_flip": True,
-            "train_random_rotation": not small, "train_color_jitter": not small, "train_random_erasing": not small,
+            "train_random_rotation": (not small) if rotation_default is None else rotation_default,
+            "train_color_jitter": not small,
+            "train_random_erasing": (not small) if erasing_default is None else erasing_default,
             "train_to_tensor": True, "train_normalize": True, "val_resize": True, "val_center_crop": True,
             "val_to_tensor": True, "val_normalize": True,
         },
@@ -99,23 +105,31 @@ def build_transforms(img_size: int, gpu_tail: bool = False):
                 train.append(D.Resize(enlarged))
             if on("train_center_crop", True):
                 train.append(D.CenterCrop(img_size))
-        if on("train_random_rotation", True):
+        if not rotation_after_flip and on("train_random_rotation", True):
             train.append(D.RandomRotation(10))
     mean, std = [0.485, 0.456, 0.406], [0.229, 0.224, 0.225]
+    if rotation_after_flip and not gpu_tail:
+        # efficientformer_v2.py:157-160 / fastervit.py:166-170: flip, then rotation (also for small images)
+        if on("train_random_horizontal_flip", True):
+            train.append(D.RandomHorizontalFlip())
+        if on("train_random_rotation", False):
+            train.append(D.RandomRotation(10))
     if gpu_tail:
+        if rotation_after_flip and on("train_random_rotation", False):
+            train.append(D.RandomRotation(10))      # rotation by a random angle commutes in distribution with the flip
         # flip commutes with the per-pixel colour jitter, so it can move behind it onto the device
         if on("train_color_jitter", False):
-            train.append(D.ColorJitter(0.2, 0.2, 0.2, 0.05))
+            train.append(D.ColorJitter(*jitter))
         train.append(D.ToUint8HWC())
         train_tail = D.GpuInputTail(mean if on("train_normalize", True) else [0.0] * 3,
                                     std if on("train_normalize", True) else [1.0] * 3,
                                     flip_p=0.5 if on("train_random_horizontal_flip", True) else 0.0,
                                     erase_p=0.5 if on("train_random_erasing", False) else 0.0)
     else:
-        if on("train_random_horizontal_flip", True):
+        if not rotation_after_flip and on("train_random_horizontal_flip", True):
             train.append(D.RandomHorizontalFlip())
         if on("train_color_jitter", False):
-            train.append(D.ColorJitter(0.2, 0.2, 0.2, 0.05))
+            train.append(D.ColorJitter(*jitter))
         if on("train_to_tensor", True):
             train.append(D.ToTensor())
         if on("train_normalize", True):
@@ -149,13 +163,15 @@ def make_loader(dataset, batch_size: int, num_workers: int, *, shuffle: bool, ra
 
 
 def get_loaders(data_root: Path, train_split: str, val_split: str, img_size: int, batch_size: int, num_workers: int, *,
-                expected_classes: int | None = None, rank: int = 0, world: int = 1, seed: int = 0, gpu_tail: bool = False):
+                expected_classes: int | None = None, rank: int = 0, world: int = 1, seed: int = 0, gpu_tail: bool = False,
+                transform_kwargs: dict | None = None):
     """(train loader, val loader); with gpu_tail also (train tail, val tail) to apply to each uint8 batch."""
     tails = ()
+    tk = transform_kwargs or {}
     if gpu_tail:
-        train_t, val_t, *tails = build_transforms(img_size, gpu_tail=True)
+        train_t, val_t, *tails = build_transforms(img_size, gpu_tail=True, **tk)
     else:
-        train_t, val_t = build_transforms(img_size)
+        train_t, val_t = build_transforms(img_size, **tk)
     train_ds = D.ImageFolder(data_root / train_split, transform=train_t)
     if expected_classes is not None:
         require_num_classes(train_ds, expected_classes, split=train_split)

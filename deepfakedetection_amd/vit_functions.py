@@ -139,8 +139,9 @@ def _partial_rows(B: int) -> int:
     return B + (B + 31) // 32 + 1
 
 
-def attn_core_bwd(gO, q, k, v, S, P, T2, table, idx, th, geo: AttnGeom, need_table: bool, need_th: bool):
-    """Returns (dQ, dK, dV, dtable, (dw1, db1, dw2, db2) | None)."""
+def attn_core_bwd(gO, q, k, v, S, P, T2, table, idx, th, geo: AttnGeom, need_table: bool, need_th: bool, th_params=None):
+    """Returns (dQ, dK, dV, dtable, (dw1, db1, dw2, db2) | None).  th_params: the talking-head parameter tensors
+    (weight1, bias1, weight2, bias2) whose gradient-arena slots receive the results."""
     B = q.shape[0]
     H, dk, dv, Nq, Nk = geo.heads, geo.dk, geo.dv, geo.Nq, geo.Nk
     L = Nq * Nk
@@ -171,19 +172,25 @@ def attn_core_bwd(gO, q, k, v, S, P, T2, table, idx, th, geo: AttnGeom, need_tab
     dth = None
     if th is not None and need_th:
         w1, b1, w2, b2 = th
+        pw1, pb1, pw2, pb2 = th_params if th_params is not None else (None, None, None, None)
+
+        def dst(param, n):
+            slot = _slot(param, param is not None, tuple(param.shape)) if param is not None else None
+            return slot.view(-1) if slot is not None else torch.empty(n, dtype=torch.float32, device=dev)
+
         part = torch.empty((_partial_rows(B), H * H), dtype=torch.float32, device=dev)
         # dW2[g][h] = sum_{b,l} dT2[b,g,l] * P[b,h,l]   (per-image partials, then a fixed-order row sum)
         K.bgemm(dT2, (H * L, 0, L, 1), P, (H * L, 0, 1, L), part, (H * H, 0, H, 1), B, 1, H, H, L)
-        dw2 = K.sum_rows(part.view(-1), B, H * H, torch.empty(H * H, dtype=torch.float32, device=dev)).view(H, H, 1, 1)
+        dw2 = K.sum_rows(part.view(-1), B, H * H, dst(pw2, H * H)).view(H, H, 1, 1)
         part1 = torch.empty((_partial_rows(B), H * H), dtype=torch.float32, device=dev)
         K.bgemm(dT1, (H * L, 0, L, 1), S, (H * L, 0, 1, L), part1, (H * H, 0, H, 1), B, 1, H, H, L)
-        dw1 = K.sum_rows(part1.view(-1), B, H * H, torch.empty(H * H, dtype=torch.float32, device=dev)).view(H, H, 1, 1)
+        dw1 = K.sum_rows(part1.view(-1), B, H * H, dst(pw1, H * H)).view(H, H, 1, 1)
         # db2[g] = sum dT2[b,g,:]: the same contraction against a column of ones (all strides 0)
         ones = _ones(dev)
         partb = torch.empty((_partial_rows(B), H), dtype=torch.float32, device=dev)
         K.bgemm(dT2, (H * L, 0, L, 1), ones, (0, 0, 0, 0), partb, (H, 0, 1, 1), B, 1, H, 1, L)
-        db2 = K.sum_rows(partb.view(-1), B, H, torch.empty(H, dtype=torch.float32, device=dev))
-        db1 = K.axpby(b1, None, 0.0, 0.0)           # softmax is invariant to a per-head shift: exactly zero
+        db2 = K.sum_rows(partb.view(-1), B, H, dst(pb2, H))
+        db1 = K.axpby(b1, None, 0.0, 0.0, out=dst(pb1, H))      # softmax is invariant to a per-head shift: exactly zero
         dth = (dw1, db1, dw2, db2)
     dtable = None
     if need_table:
@@ -505,7 +512,8 @@ class AttentionFunction(torch.autograd.Function):
             dv_loc, dw, db, dgm, dbe = dwbn_bwd(d, parts, n, v, yl, stl, w, b, gm, be, tr, 3, 1, True, nv[0], nv[2] or nv[3])
             grads["v_local"] = (dw, db if nv[1] else None, dgm, dbe)
             # ---- attention core
-            dQ, dK, dV, dtable, dth = attn_core_bwd(d, q, k, v, S, P, T2, table, cfg.idx, th, geo, n_table, any(n_th))
+            dQ, dK, dV, dtable, dth = attn_core_bwd(d, q, k, v, S, P, T2, table, cfg.idx, th, geo, n_table, any(n_th),
+                                                    (th_w1, th_b1, th_w2, th_b2))
             dVt = K.add(dV, dv_loc)
             # ---- q, k, v projections: the gradient of their common input accumulates through `residual`
             need_xs = need[0] or (cfg.stride is not None and any(nt["stride_conv"]))
@@ -673,7 +681,8 @@ class DownsampleFunction(torch.autograd.Function):
                 parts, n = K.channel_stats(dqin)
                 both = torch.empty(2 * C, dtype=torch.float32, device=x.device)
                 K.sum_rows(parts, n, 2 * C, both)
-                dbl = both[:C]
+                slot = _slot(bl, True, (C,))
+                dbl = K.axpby(both[:C], None, 1.0, 0.0, out=slot) if slot is not None else both[:C]
         flat = [dwc if need[2] else None, dbc if need[3] else None, dgc, dbec, dwl, dbl]
         for nm in _DS_ORDER:
             flat.extend(grads[nm])
