@@ -42,6 +42,9 @@ def parse() -> argparse.Namespace:
     ap.add_argument("--batch", type=int, default=256, help="per-GPU batch (BASELINE config: 256)")
     ap.add_argument("--size", type=int, default=224)
     ap.add_argument("--classes", type=int, default=2)
+    ap.add_argument("--model", default="efficientnet",
+                    help="'efficientnet' (BASELINE config 2; see --variant / --flavour) or an EfficientFormerV2 name "
+                         "such as efficientformerv2_s1 (BASELINE config 3)")
     ap.add_argument("--variant", default="b0")
     ap.add_argument("--flavour", default="timm")
     ap.add_argument("--no-graph", action="store_true")
@@ -82,15 +85,26 @@ def usable_cores() -> int:
     return max(1, min(n, 64))
 
 
+def model_label(args) -> str:
+    if args.model.startswith("efficientformer"):
+        return "EfficientFormerV2-" + args.model.rsplit("_", 1)[-1].upper()
+    return f"EfficientNet-{args.variant.upper()}"
+
+
 def cpu_baseline_measure(args) -> dict:
     """Oracle train step on the host cores; bounded sample, ~10-30 s.  Runs in a CHILD process
     (see cpu_baseline) so that it can be time-boxed and never shares threads with the GPU run."""
     cores = usable_cores()
     torch.set_num_threads(cores)
-    from oracle.effnet_ref import EfficientNetRef, train_step_ref
-
     torch.manual_seed(0)
-    model = EfficientNetRef(args.variant, args.flavour, args.classes).to(memory_format=torch.channels_last)
+    if args.model.startswith("efficientformer"):
+        from oracle.efformer_ref import EfficientFormerV2Ref, train_step_ref, variant_of
+
+        model = EfficientFormerV2Ref(variant_of(args.model), args.classes, args.size).to(memory_format=torch.channels_last)
+    else:
+        from oracle.effnet_ref import EfficientNetRef, train_step_ref
+
+        model = EfficientNetRef(args.variant, args.flavour, args.classes).to(memory_format=torch.channels_last)
     opt = torch.optim.AdamW(model.parameters(), lr=1e-4, weight_decay=5e-2)
     g = torch.Generator().manual_seed(1)
     x = torch.randn(args.cpu_batch, 3, args.size, args.size, generator=g).contiguous(memory_format=torch.channels_last)
@@ -103,7 +117,7 @@ def cpu_baseline_measure(args) -> dict:
         times.append(time.perf_counter() - t0)
     med = sorted(times)[len(times) // 2]
     return {"value": round(args.cpu_batch / med, 2), "unit": "images/sec", "cores": cores, "kind": "port",
-            "sample": f"oracle EfficientNet-{args.variant} f32 channels_last train step (fwd+CE+bwd+AdamW), "
+            "sample": f"oracle {model_label(args)} f32 channels_last train step (fwd+CE+bwd+AdamW), "
                       f"batch {args.cpu_batch} @{args.size}px, median of {args.cpu_steps} steps after 1 warm-up"}
 
 
@@ -111,7 +125,8 @@ def cpu_baseline(args) -> dict:
     """Time-boxed: the measurement runs as `bench.py --cpu-baseline-only` in a child process."""
     import subprocess
 
-    cmd = [sys.executable, str(ROOT / "bench.py"), "--cpu-baseline-only", "--variant", args.variant, "--flavour", args.flavour,
+    cmd = [sys.executable, str(ROOT / "bench.py"), "--cpu-baseline-only", "--model", args.model, "--variant", args.variant,
+           "--flavour", args.flavour,
            "--classes", str(args.classes), "--size", str(args.size), "--cpu-batch", str(args.cpu_batch),
            "--cpu-steps", str(args.cpu_steps)]
     env = dict(os.environ)
@@ -134,7 +149,7 @@ def pmc_traffic(family: str, args) -> int | None:
     """HBM bytes per launch of a kernel family from the committed rocprofv3 --pmc passes (counters
     cannot be read from inside this process): newest profiles/*pmc_traffic.json, which records GB per
     training step of exactly this workload.  None when the file is absent or the workload differs."""
-    if (args.variant, args.flavour, args.batch, args.size) != ("b0", "timm", 256, 224):
+    if (args.model, args.variant, args.flavour, args.batch, args.size) != ("efficientnet", "b0", "timm", 256, 224):
         return None
     files = sorted((ROOT / "profiles").glob("*pmc_traffic.json"))
     if not files:
@@ -169,7 +184,14 @@ def main() -> None:
     torch.cuda.set_device(device)
 
     torch.manual_seed(1)
-    model = HipEfficientNet(args.variant, args.flavour, args.classes).to(device).train()
+    if args.model.startswith("efficientformer"):
+        from deepfakedetection_amd.efficientformer_v2 import build_efficientformer_v2
+
+        model = build_efficientformer_v2(args.model, args.classes, args.size).to(device).train()
+        workload = f"{model_label(args)} (timm 1.0.20 architecture)"
+    else:
+        model = HipEfficientNet(args.variant, args.flavour, args.classes).to(device).train()
+        workload = f"EfficientNet-{args.variant} ({args.flavour} flavour)"
     broadcast_module_state(model)
     opt = HipAdamW(model.parameters(), lr=1e-4, weight_decay=5e-2, grad_scale=1.0 / world)
     reducer = GradAllReducer(model.parameters(), arena=opt.arena) if world > 1 else None
@@ -368,10 +390,10 @@ def main() -> None:
         ms = elapsed / args.steps * 1e3
         value = args.batch * world * args.steps / elapsed
         line = {
-            "metric": f"train images/sec @{args.size}^2 (EfficientNet-{args.variant.upper()})", "value": round(value, 1), "unit": "images/sec",
+            "metric": f"train images/sec @{args.size}^2 ({model_label(args)})", "value": round(value, 1), "unit": "images/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": f"EfficientNet-{args.variant} ({args.flavour} flavour) {args.size}x{args.size} train step: "
+            "config": {"workload": f"{workload} {args.size}x{args.size} train step: "
                                    f"bf16 fwd + label-smoothed CE + bwd + AdamW, random-init weights, {args.classes} classes",
                        "per_gpu_batch": args.batch, "global_batch": args.batch * world, "parallelism": f"dp{world}",
                        "launch": launch, "final_loss": round(final_loss, 4), "replicas_in_sync": in_sync,

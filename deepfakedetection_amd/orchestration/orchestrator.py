@@ -253,8 +253,18 @@ def build_eval_transforms(image_size: int, *, toggles: dict[str, Any] | None = N
     return D.Compose(ops)
 
 
-def load_model(model_name: str, num_classes: int, weights_path: Path | None, device: torch.device) -> nn.Module:
-    model = get_model_spec(model_name).builder(model_name, num_classes)
+def load_model(model_name: str, num_classes: int, weights_path: Path | None, device: torch.device,
+               img_size: int | None = None) -> nn.Module:
+    """Reference orchestrator.py:350-377.  One addition: a builder that takes `img_size` (EfficientFormerV2: its
+    attention-bias tables depend on the resolution; the reference's registry builder omits it, model_registry.py:40,
+    and so only works at the default 224) receives the job's image size."""
+    import inspect
+
+    builder = get_model_spec(model_name).builder
+    if img_size is not None and "img_size" in inspect.signature(builder).parameters:
+        model = builder(model_name, num_classes, img_size)
+    else:
+        model = builder(model_name, num_classes)
     model.to(device)
     model.eval()
     if weights_path is not None:
@@ -398,7 +408,7 @@ def _run_inference_job(*, config_path: Path, config: dict[str, Any], model_cfg: 
         device_name = "cpu"
     device = torch.device(device_name)
 
-    model = load_model(name, num_classes, _resolve_weights(infer_cfg, name, out), device)
+    model = load_model(name, num_classes, _resolve_weights(infer_cfg, name, out), device, image_size)
     transform = build_eval_transforms(image_size, toggles=resolve_transform_mapping(model_cfg, phase="eval"))
     root = Path(data_cfg.get("root")).expanduser()
     if not root.is_absolute():

@@ -100,6 +100,80 @@ def test_training_then_inference_end_to_end(workspace):
     assert (run2 / "logs" / "inference.log").exists()
 
 
+class TinyHeadNet(nn.Module):
+    """Stub with the names the EfficientFormerV2 / FasterViT freeze masks look for (`head`, `stages.3`)."""
+
+    def __init__(self, num_classes: int) -> None:
+        super().__init__()
+        self.stem = nn.Conv2d(3, 8, 3, stride=2, padding=1)
+        self.stages = nn.Sequential(*[nn.Conv2d(8, 8, 1) for _ in range(4)])
+        self.norm = nn.BatchNorm2d(8)
+        self.head = nn.Linear(8, num_classes)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return self.head(self.norm(torch.relu(self.stages(self.stem(x)))).mean((2, 3)))
+
+
+@pytest.mark.parametrize("trainer,weights,img_arg", [("efficientformer_v2", "EfficientFormerV2_S1.pth", True),
+                                                     ("fastervit", "FasterVitModel.pth", False)])
+def test_other_two_trainers_end_to_end_on_cpu(workspace, trainer, weights, img_arg):
+    """trainers/efficientformer_v2.py and trainers/fastervit.py counterparts (shared engine) through the orchestrator:
+    warm-up on the head, the reference's fine-tune subsets, file names, throughput.jsonl."""
+    built = {}
+
+    def builder(_name, nc, img_size=None):
+        built["img_size"] = img_size
+        return TinyHeadNet(nc)
+
+    if not img_arg:
+        two_arg = builder
+        builder = lambda name, nc: two_arg(name, nc)  # noqa: E731  (FasterViT's builder takes no img_size)
+    name = f"stub_{trainer}"
+    reg.register_model_spec(reg.ModelSpec(name, f"deepfakedetection_amd.trainers.{trainer}", name, 32, builder))
+    cfg = yaml.safe_load(_config(workspace, training={"epochs": 1, "batch_size": 6, "num_workers": 0, "pretrained": False}).read_text())
+    cfg["models"] = {name: {**cfg["models"]["tinynet_stub"], "output_dir": str(workspace / "runs" / name)}}
+    cfg["selection"] = [name]
+    path = workspace / f"{trainer}.yaml"
+    path.write_text(yaml.safe_dump(cfg))
+    orchestrate(path, mode="training")
+    run = sorted((workspace / "runs" / name).iterdir())[0]
+    ckpt = torch.load(run / "checkpoints" / "latest.ckpt")
+    assert ckpt["epoch"] == 1 and ckpt["warmup_done"] is True
+    log = (run / "logs" / "train.log").read_text()
+    assert "Warmup (head only)" in log and "val_acc=" in log
+    rows = [json.loads(line) for line in (run / "logs" / "throughput.jsonl").read_text().splitlines()]
+    assert [r["phase"] for r in rows] == ["warmup", "fine-tune"] and rows[0]["images"] == 18
+    n_state = len(ckpt["optimizer"]["state"])
+    if trainer == "efficientformer_v2":
+        assert built["img_size"] == 32                        # timm.create_model(..., img_size=img_size) in the reference
+        assert n_state == 4                                   # stages.3.{weight,bias} + head.{weight,bias}
+        assert "Fine-tune" not in log                         # BATCH_SIZE batches, no accumulation
+    else:
+        assert n_state == len(list(TinyHeadNet(3).parameters())) and rows[1]["batch_size"] == 32 and rows[1]["accum_steps"] == 4
+        assert "Fine-tune" in log and "accum_steps=4" in log
+    assert (run / "checkpoints" / "best.ckpt").exists() == (run / weights).exists()
+
+
+def test_reference_train_yaml_fails_loudly_for_the_engine_that_is_not_built(workspace):
+    """config/train.yaml of the reference selects all three models.  A registered model without a HIP engine must
+    stop with the registry's message — not with ModuleNotFoundError from a dangling trainer path (round-1 review)."""
+    import importlib
+
+    for key in ("efficientnet_b3", "efficientformerv2_s1", "faster_vit_2_224"):
+        spec = reg.get_model_spec(key)
+        assert hasattr(importlib.import_module(spec.train_module), "main")
+    cfg = yaml.safe_load(_config(workspace, training={"epochs": 1, "batch_size": 6, "num_workers": 0, "pretrained": False}).read_text())
+    cfg["models"] = {"faster_vit_2_224": dict(cfg["models"]["tinynet_stub"])}
+    cfg["selection"] = ["faster_vit_2_224"]
+    path = workspace / "fv.yaml"
+    path.write_text(yaml.safe_dump(cfg))
+    try:
+        reg.get_model_spec("faster_vit_2_224").builder("faster_vit_2_224", 3)
+    except NotImplementedError:
+        with pytest.raises(NotImplementedError, match="registered but its MI355X engine is not built"):
+            orchestrate(path, mode="training")
+
+
 def test_class_count_mismatch_exits(workspace):
     cfg = yaml.safe_load(_config(workspace, training={"epochs": 1, "batch_size": 4, "num_workers": 0}).read_text())
     cfg["data"]["num_classes"] = 2
