@@ -101,6 +101,90 @@ def test_logits_match_independent_hf_implementation():
     assert torch.allclose(a, b, rtol=1e-4, atol=1e-5), float((a - b).abs().max())
 
 
+def _hf_pair(variant: str, classes: int, **cfg_kw):
+    """(oracle in the lukemelas flavour, HF model holding the oracle's weights)."""
+    transformers = pytest.importorskip("transformers")
+    cfg = transformers.EfficientNetConfig(num_labels=classes, **cfg_kw)
+    hf = transformers.EfficientNetForImageClassification(cfg)
+    torch.manual_seed(7)
+    ours = EfficientNetRef(variant, "lukemelas", classes)
+    with torch.no_grad():
+        for m in ours.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.running_mean.normal_(0, 0.1)
+                m.running_var.uniform_(0.5, 1.5)
+                m.weight.uniform_(0.5, 1.5)
+                m.bias.normal_(0, 0.1)
+    src, dst = ours.state_dict(), hf.state_dict()
+    assert len(src) == len(dst)
+    mapped = {}
+    for (ks, vs), (kd, vd) in zip(src.items(), dst.items()):
+        assert vs.shape == vd.shape, (ks, kd, vs.shape, vd.shape)
+        mapped[kd] = vs.clone()
+    hf.load_state_dict(mapped)
+    return ours, hf
+
+
+def test_b3_static_same_padding_at_224_matches_independent_hf_implementation():
+    """The reference's own model: EfficientNet-B3 (efficientnet_pytorch), whose TF-"SAME" padding is frozen at the
+    NOMINAL 300 px and then evaluated on 224 px inputs (trainers/efficientnet.py:405, img_size 224).  HF's model has the
+    same static rule built differently: ZeroPad2d((k//2 - 1, k//2)) in front of every stride-2 depthwise convolution
+    except the block indices in `depthwise_padding` (HF's published b3 config: [5, 18] — the two k5 s2 layers that
+    see an ODD nominal resolution, 75 and 19 px), which pad symmetrically."""
+    ours, hf = _hf_pair("b3", 7, width_coefficient=1.2, depth_coefficient=1.4, image_size=300, hidden_dim=1536,
+                        dropout_rate=0.3, depthwise_padding=[5, 18])
+    assert sum(p.numel() for p in hf.parameters()) == sum(p.numel() for p in ours.parameters())
+    ours.eval(); hf.eval()
+    x = torch.randn(2, 3, 224, 224, generator=torch.Generator().manual_seed(2))
+    with torch.no_grad():
+        a, b = ours(x), hf(pixel_values=x).logits
+    assert torch.allclose(a, b, rtol=1e-4, atol=2e-5), float((a - b).abs().max())
+    # and the rule matters: with TF-SAME computed for the 224 px input instead, those layers would pad differently
+    _, _, blocks, _, _ = build_cfg("b3", "lukemelas")
+    assert blocks[5].pad_dw[:2] == (2, 2) and blocks[18].pad_dw[:2] == (2, 2)
+
+
+def test_training_mode_matches_independent_hf_implementation():
+    """Batch-statistics BatchNorm, running-statistics update (momentum 0.01 in torch's convention, eps 1e-3) and the
+    gradient of every parameter, B0 at 96 px.  Stochastic parts off on both sides (HF applies elementwise dropout
+    where efficientnet_pytorch applies per-sample drop-connect: not comparable, and not what is pinned here)."""
+    ours, hf = _hf_pair("b0", 5, width_coefficient=1.0, depth_coefficient=1.0, image_size=224, hidden_dim=1280, dropout_rate=0.0,
+                        drop_connect_rate=0.0, batch_norm_momentum=0.01)
+    ours.train(); hf.train()
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(6, 3, 96, 96, generator=g)
+    y = torch.randint(0, 5, (6,), generator=g)
+    bns_o = [m for m in ours.modules() if isinstance(m, torch.nn.BatchNorm2d)]
+    bns_h = [m for m in hf.modules() if isinstance(m, torch.nn.BatchNorm2d)]
+    before = [(m.running_mean.clone(), m.running_var.clone()) for m in bns_o]
+    a = ours(x)
+    b = hf(pixel_values=x).logits
+    assert torch.allclose(a, b, rtol=1e-4, atol=2e-5), float((a - b).abs().max())
+    torch.nn.functional.cross_entropy(a, y, label_smoothing=0.1).backward()
+    torch.nn.functional.cross_entropy(b, y, label_smoothing=0.1).backward()
+    mine = dict(ours.named_parameters())
+    for (n1, p1), (n2, p2) in zip(ours.named_parameters(), hf.named_parameters()):
+        assert p1.shape == p2.shape, (n1, n2)
+        scale = max(float(p1.grad.abs().max()), 1e-8)
+        # a BN bias in front of another batch-statistics BN (block without skip) has a structurally zero gradient:
+        # both sides hold cancellation noise, so a bias is judged on the scale of its layer's (weight, bias) gradient
+        sib = n1[:-4] + "weight"
+        if n1.endswith("bias") and sib in mine:
+            scale = max(scale, float(mine[sib].grad.abs().max()))
+        assert float((p1.grad - p2.grad).abs().max()) <= 2e-3 * scale + 1e-7, (n1, n2)
+    # running statistics: new = (1 - m) * old + m * batch statistic.  efficientnet_pytorch uses m = 0.01 everywhere;
+    # HF forgets the momentum argument on its expansion BatchNorms (torch default 0.1), so the batch statistic each
+    # side folded in is compared, with each module's own momentum
+    assert len(bns_o) == len(bns_h) == 49
+    for mo, mh, (m0, v0) in zip(bns_o, bns_h, before):
+        assert mo.momentum == 0.01 and mo.eps == mh.eps == 1e-3
+        for new_o, new_h, old in ((mo.running_mean, mh.running_mean, m0), (mo.running_var, mh.running_var, v0)):
+            stat_o = (new_o - (1 - mo.momentum) * old) / mo.momentum
+            stat_h = (new_h - (1 - mh.momentum) * old) / mh.momentum
+            assert torch.allclose(stat_o, stat_h, rtol=2e-3, atol=2e-4), float((stat_o - stat_h).abs().max())
+        assert int(mo.num_batches_tracked) == int(mh.num_batches_tracked) == 1
+
+
 def test_golden_logits_fixture():
     path = GOLDEN / "effnet_logits.json"
     data = json.loads(path.read_text())
