@@ -43,8 +43,8 @@ def parse() -> argparse.Namespace:
     ap.add_argument("--size", type=int, default=224)
     ap.add_argument("--classes", type=int, default=2)
     ap.add_argument("--model", default="efficientnet",
-                    help="'efficientnet' (BASELINE config 2; see --variant / --flavour) or an EfficientFormerV2 name "
-                         "such as efficientformerv2_s1 (BASELINE config 3)")
+                    help="'efficientnet' (BASELINE config 2; see --variant / --flavour), an EfficientFormerV2 name such as "
+                         "efficientformerv2_s1 (BASELINE config 3) or a FasterViT name such as faster_vit_0_224 (config 5)")
     ap.add_argument("--variant", default="b0")
     ap.add_argument("--flavour", default="timm")
     ap.add_argument("--no-graph", action="store_true")
@@ -88,6 +88,8 @@ def usable_cores() -> int:
 def model_label(args) -> str:
     if args.model.startswith("efficientformer"):
         return "EfficientFormerV2-" + args.model.rsplit("_", 1)[-1].upper()
+    if args.model.startswith("faster_vit"):
+        return "FasterViT-" + args.model.split("_")[2]
     return f"EfficientNet-{args.variant.upper()}"
 
 
@@ -101,6 +103,10 @@ def cpu_baseline_measure(args) -> dict:
         from oracle.efformer_ref import EfficientFormerV2Ref, train_step_ref, variant_of
 
         model = EfficientFormerV2Ref(variant_of(args.model), args.classes, args.size).to(memory_format=torch.channels_last)
+    elif args.model.startswith("faster_vit"):
+        from oracle.fastervit_ref import FasterViTRef, train_step_ref, variant_of
+
+        model = FasterViTRef(variant_of(args.model), args.classes, args.size).to(memory_format=torch.channels_last)
     else:
         from oracle.effnet_ref import EfficientNetRef, train_step_ref
 
@@ -189,6 +195,11 @@ def main() -> None:
 
         model = build_efficientformer_v2(args.model, args.classes, args.size).to(device).train()
         workload = f"{model_label(args)} (timm 1.0.20 architecture)"
+    elif args.model.startswith("faster_vit"):
+        from deepfakedetection_amd.fastervit import build_fastervit
+
+        model = build_fastervit(args.model, args.classes).to(device).train()
+        workload = f"{model_label(args)} (fastervit 1.0.0 architecture, DropPath 0.2)"
     else:
         model = HipEfficientNet(args.variant, args.flavour, args.classes).to(device).train()
         workload = f"EfficientNet-{args.variant} ({args.flavour} flavour)"

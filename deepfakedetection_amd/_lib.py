@@ -107,6 +107,13 @@ SIGNATURES: dict[str, tuple] = {
     "dfd_conv_weight_perm": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P]),
     "dfd_layernorm_fwd": (c_int, [c_int, P, P, P, c_float, P, P, c_long, c_int, P]),
     "dfd_layernorm_bwd": (c_int, [c_int, P, P, P, P, P, P, c_int, _PI, c_long, c_int, P]),
+    "dfd_copy_rows": (c_int, [c_int, P, P, P, P, c_long, c_int, P]),
+    "dfd_add_rowtable": (c_int, [c_int, P, P, P, c_long, c_int, c_int, P]),
+    "dfd_rowtable_grad": (c_int, [c_int, P, P, c_long, c_int, c_int, c_int, P]),
+    "dfd_avgpool_fwd": (c_int, [c_int, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    "dfd_avgpool_bwd": (c_int, [c_int, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    "dfd_relpos_bias_fwd": (c_int, [P, P, P, c_int, c_int, c_int, P]),
+    "dfd_relpos_bias_bwd": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, P]),
     "dfd_axpby": (c_int, [P, P, c_float, c_float, P, P, c_long, P]),
     "dfd_add": (c_int, [c_int, P, P, P, c_long, P]),
     "dfd_rand": (c_int, [P, c_uint32, c_float, P, c_long, P]),

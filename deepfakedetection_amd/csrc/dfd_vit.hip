@@ -1103,3 +1103,205 @@ extern "C" int dfd_layernorm_bwd(int dtype, const void* g, const void* x, const 
     else return DFD_EINVAL;
     return DFD_CHECK_LAUNCH();
 }
+
+// ===========================================================================
+// token bookkeeping for windowed attention (fastervit faster_vit.py: window_partition / window_reverse,
+// ct_dewindow / ct_window, torch.cat of carrier and window tokens and its split): every one of them is a row
+// copy  dst[didx[r]] = src[sidx[r]]  over [rows][C] matrices (NULL index array = identity).  When each
+// destination row is written once and each source row read at most once — true for all of the above — the
+// backward pass is the same kernel with the index arrays swapped.
+// ===========================================================================
+template <typename T>
+__global__ void __launch_bounds__(DFD_THREADS)
+k_copy_rows(const T* __restrict__ src, const int* __restrict__ sidx, T* __restrict__ dst, const int* __restrict__ didx, long n, int C) {
+    constexpr int V = Vec<T>::N;
+    const int CV = C / V;
+    const long total = n * CV;
+    for (long i = (long)blockIdx.x * DFD_THREADS + threadIdx.x; i < total; i += (long)gridDim.x * DFD_THREADS) {
+        const long r = i / CV;
+        const int cv = (int)(i - r * CV);
+        const long s = sidx ? sidx[r] : r, d = didx ? didx[r] : r;
+        *reinterpret_cast<uint4*>(dst + d * C + cv * V) = *reinterpret_cast<const uint4*>(src + s * C + cv * V);
+    }
+}
+extern "C" int dfd_copy_rows(int dtype, const void* src, const int* sidx, void* dst, const int* didx, long n, int C, dfd_stream stream) {
+    if (!src || !dst || n < 1 || C < 8 || C % 8) return DFD_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == DFD_BF16) {
+        long grid = (n * (C / 8) + 255) / 256; if (grid > 16384) grid = 16384;
+        hipLaunchKernelGGL((k_copy_rows<bf16>), dim3((unsigned)grid), dim3(DFD_THREADS), 0, st, (const bf16*)src, sidx, (bf16*)dst, didx, n, C);
+    } else if (dtype == DFD_F32) {
+        long grid = (n * (C / 4) + 255) / 256; if (grid > 16384) grid = 16384;
+        hipLaunchKernelGGL((k_copy_rows<float>), dim3((unsigned)grid), dim3(DFD_THREADS), 0, st, (const float*)src, sidx, (float*)dst, didx, n, C);
+    } else return DFD_EINVAL;
+    return DFD_CHECK_LAUNCH();
+}
+
+// out[r][:] = x[r][:] + table[r % T][:]   (PosEmbMLPSwinv1D: one learned vector per token position, f32 table)
+template <typename T>
+__global__ void __launch_bounds__(DFD_THREADS)
+k_add_rowtable(const T* __restrict__ x, const float* __restrict__ table, T* __restrict__ out, long rows, int Tn, int C) {
+    constexpr int V = Vec<T>::N;
+    const int CV = C / V;
+    const long total = rows * CV;
+    for (long i = (long)blockIdx.x * DFD_THREADS + threadIdx.x; i < total; i += (long)gridDim.x * DFD_THREADS) {
+        const long r = i / CV;
+        const int cv = (int)(i - r * CV);
+        float v[V], t[V];
+        Vec<T>::load(x + i * V, v);
+        load_f32<V>(table + (r % Tn) * C + cv * V, t);
+#pragma unroll
+        for (int j = 0; j < V; ++j) v[j] += t[j];
+        Vec<T>::store(out + i * V, v);
+    }
+}
+extern "C" int dfd_add_rowtable(int dtype, const void* x, const float* table, void* out, long rows, int T, int C, dfd_stream stream) {
+    if (!x || !table || !out || rows < 1 || T < 1 || C < 8 || C % 8) return DFD_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == DFD_BF16) {
+        long grid = (rows * (C / 8) + 255) / 256; if (grid > 16384) grid = 16384;
+        hipLaunchKernelGGL((k_add_rowtable<bf16>), dim3((unsigned)grid), dim3(DFD_THREADS), 0, st, (const bf16*)x, table, (bf16*)out, rows, T, C);
+    } else if (dtype == DFD_F32) {
+        long grid = (rows * (C / 4) + 255) / 256; if (grid > 16384) grid = 16384;
+        hipLaunchKernelGGL((k_add_rowtable<float>), dim3((unsigned)grid), dim3(DFD_THREADS), 0, st, (const float*)x, table, (float*)out, rows, T, C);
+    } else return DFD_EINVAL;
+    return DFD_CHECK_LAUNCH();
+}
+// dtable[t][c] = sum_w g[w*T + t][c]   (f32 output; a workgroup per (t, channel chunk), fixed order over w)
+template <typename T>
+__global__ void __launch_bounds__(DFD_THREADS)
+k_rowtable_grad(const T* __restrict__ g, float* __restrict__ dtable, long nw, int Tn, int C, int accumulate) {
+    const int t = blockIdx.x;
+    for (int c = blockIdx.y * DFD_THREADS + threadIdx.x; c < C; c += gridDim.y * DFD_THREADS) {
+        float s = 0.f;
+        for (long w = 0; w < nw; ++w) {
+            const T* p = g + (w * Tn + t) * C + c;
+            if constexpr (sizeof(T) == 2) s += bf2f(reinterpret_cast<const unsigned short*>(p)[0]);
+            else s += reinterpret_cast<const float*>(p)[0];
+        }
+        float* o = dtable + (long)t * C + c;
+        *o = (accumulate ? *o : 0.f) + s;
+    }
+}
+extern "C" int dfd_rowtable_grad(int dtype, const void* g, float* dtable, long rows, int T, int C, int accumulate, dfd_stream stream) {
+    if (!g || !dtable || rows < 1 || T < 1 || rows % T || C < 1) return DFD_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid(T, (C + DFD_THREADS - 1) / DFD_THREADS);
+    if (dtype == DFD_BF16) hipLaunchKernelGGL((k_rowtable_grad<bf16>), grid, dim3(DFD_THREADS), 0, st, (const bf16*)g, dtable, rows / T, T, C, accumulate);
+    else if (dtype == DFD_F32) hipLaunchKernelGGL((k_rowtable_grad<float>), grid, dim3(DFD_THREADS), 0, st, (const float*)g, dtable, rows / T, T, C, accumulate);
+    else return DFD_EINVAL;
+    return DFD_CHECK_LAUNCH();
+}
+
+// average pooling k x k, stride s, no padding (TokenInitializer's AvgPool2d(5, 3)) and its gradient
+template <typename T, bool BWD>
+__global__ void __launch_bounds__(DFD_THREADS)
+k_avgpool(const T* __restrict__ in, T* __restrict__ out, int N, int H, int W, int Ho, int Wo, int k, int s, int C) {
+    constexpr int V = Vec<T>::N;
+    const int CV = C / V;
+    const float inv = 1.0f / (float)(k * k);
+    const long total = BWD ? (long)N * H * W * CV : (long)N * Ho * Wo * CV;
+    for (long i = (long)blockIdx.x * DFD_THREADS + threadIdx.x; i < total; i += (long)gridDim.x * DFD_THREADS) {
+        const int cv = (int)(i % CV);
+        long tq = i / CV;
+        float acc[V];
+#pragma unroll
+        for (int j = 0; j < V; ++j) acc[j] = 0.f;
+        if constexpr (!BWD) {
+            const int ox = (int)(tq % Wo); tq /= Wo;
+            const int oy = (int)(tq % Ho);
+            const long n = tq / Ho;
+            for (int dy = 0; dy < k; ++dy)
+                for (int dx = 0; dx < k; ++dx) {
+                    float v[V];
+                    Vec<T>::load(in + ((n * H + oy * s + dy) * (long)W + ox * s + dx) * C + cv * V, v);
+#pragma unroll
+                    for (int j = 0; j < V; ++j) acc[j] += v[j];
+                }
+        } else {
+            const int x = (int)(tq % W); tq /= W;
+            const int y = (int)(tq % H);
+            const long n = tq / H;
+            for (int oy = 0; oy < Ho; ++oy) {
+                if (y < oy * s || y >= oy * s + k) continue;
+                for (int ox = 0; ox < Wo; ++ox) {
+                    if (x < ox * s || x >= ox * s + k) continue;
+                    float v[V];
+                    Vec<T>::load(in + ((n * Ho + oy) * (long)Wo + ox) * C + cv * V, v);
+#pragma unroll
+                    for (int j = 0; j < V; ++j) acc[j] += v[j];
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < V; ++j) acc[j] *= inv;
+        Vec<T>::store(out + i * V, acc);
+    }
+}
+static int avgpool_go(int dtype, bool bwd, const void* in, void* out, int N, int H, int W, int k, int s, int C, hipStream_t st) {
+    if (!in || !out || N < 1 || H < k || W < k || k < 1 || s < 1 || C < 8 || C % 8) return DFD_EINVAL;
+    const int Ho = (H - k) / s + 1, Wo = (W - k) / s + 1;
+    const long items = (bwd ? (long)N * H * W : (long)N * Ho * Wo);
+    if (dtype == DFD_BF16) {
+        long grid = (items * (C / 8) + 255) / 256; if (grid > 16384) grid = 16384;
+        if (bwd) hipLaunchKernelGGL((k_avgpool<bf16, true>), dim3((unsigned)grid), dim3(DFD_THREADS), 0, st, (const bf16*)in, (bf16*)out, N, H, W, Ho, Wo, k, s, C);
+        else hipLaunchKernelGGL((k_avgpool<bf16, false>), dim3((unsigned)grid), dim3(DFD_THREADS), 0, st, (const bf16*)in, (bf16*)out, N, H, W, Ho, Wo, k, s, C);
+    } else if (dtype == DFD_F32) {
+        long grid = (items * (C / 4) + 255) / 256; if (grid > 16384) grid = 16384;
+        if (bwd) hipLaunchKernelGGL((k_avgpool<float, true>), dim3((unsigned)grid), dim3(DFD_THREADS), 0, st, (const float*)in, (float*)out, N, H, W, Ho, Wo, k, s, C);
+        else hipLaunchKernelGGL((k_avgpool<float, false>), dim3((unsigned)grid), dim3(DFD_THREADS), 0, st, (const float*)in, (float*)out, N, H, W, Ho, Wo, k, s, C);
+    } else return DFD_EINVAL;
+    return DFD_CHECK_LAUNCH();
+}
+extern "C" int dfd_avgpool_fwd(int dtype, const void* x, void* out, int N, int H, int W, int k, int stride, int C, dfd_stream stream) {
+    return avgpool_go(dtype, false, x, out, N, H, W, k, stride, C, (hipStream_t)stream);
+}
+extern "C" int dfd_avgpool_bwd(int dtype, const void* g, void* dx, int N, int H, int W, int k, int stride, int C, dfd_stream stream) {
+    return avgpool_go(dtype, true, g, dx, N, H, W, k, stride, C, (hipStream_t)stream);
+}
+
+// relative-position attention bias of PosEmbMLPSwinv2D:
+//   full[h][ng + i][ng + j] = 16 * sigmoid(table[idx[i*nl + j]][h]),  zero in the first ng rows / columns (carrier tokens)
+__global__ void k_relpos_bias_fwd(const float* __restrict__ table, const int* __restrict__ idx, float* __restrict__ full, int H, int nl, int ng) {
+    const int S = nl + ng;
+    const long total = (long)H * S * S;
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= total) return;
+    const int j = (int)(e % S), i = (int)((e / S) % S), h = (int)(e / ((long)S * S));
+    float v = 0.f;
+    if (i >= ng && j >= ng) v = 16.0f * sigmoid_f(table[(long)idx[(i - ng) * nl + (j - ng)] * H + h]);
+    full[e] = v;
+}
+// dtable[t][h] = sum_{(i,j): idx == t} dfull[h][ng+i][ng+j] * 16 * s * (1 - s),  s = sigmoid(table[t][h]); one wave per (t, h)
+__global__ void k_relpos_bias_bwd(const float* __restrict__ dfull, const float* __restrict__ table, const int* __restrict__ idx,
+                                  float* __restrict__ dtable, int H, int Tn, int nl, int ng) {
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (wave >= Tn * H) return;
+    const int t = wave / H, h = wave - t * H;
+    const int S = nl + ng;
+    float s = 0.f;
+    for (int l = lane; l < nl * nl; l += 64) {
+        if (idx[l] != t) continue;
+        const int i = l / nl, j = l - i * nl;
+        s += dfull[((long)h * S + ng + i) * S + ng + j];
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) {
+        const float sg = sigmoid_f(table[(long)t * H + h]);
+        dtable[(long)t * H + h] = s * 16.0f * sg * (1.0f - sg);
+    }
+}
+extern "C" int dfd_relpos_bias_fwd(const float* table, const int* idx, float* full, int H, int n_local, int n_global, dfd_stream stream) {
+    if (!table || !idx || !full || H < 1 || n_local < 1 || n_global < 0) return DFD_EINVAL;
+    const long S = n_local + n_global, total = (long)H * S * S;
+    hipLaunchKernelGGL(k_relpos_bias_fwd, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, table, idx, full, H, n_local, n_global);
+    return DFD_CHECK_LAUNCH();
+}
+extern "C" int dfd_relpos_bias_bwd(const float* dfull, const float* table, const int* idx, float* dtable, int H, int T, int n_local,
+                                   int n_global, dfd_stream stream) {
+    if (!dfull || !table || !idx || !dtable || H < 1 || T < 1 || n_local < 1 || n_global < 0) return DFD_EINVAL;
+    const long waves = (long)T * H;
+    hipLaunchKernelGGL(k_relpos_bias_bwd, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, (hipStream_t)stream, dfull, table, idx, dtable, H, T, n_local, n_global);
+    return DFD_CHECK_LAUNCH();
+}

@@ -1,0 +1,532 @@
+"""Fused autograd functions of the FasterViT engine.
+
+  ConvBlockFunction        conv3x3 (+bias) BN GELU conv3x3 (+bias) BN [* gamma] + x          faster_vit.py ConvBlock
+  FVDownsampleFunction     LayerNorm2d -> conv3x3 s2                                          Downsample
+  TokenInitFunction        dw3x3 (+bias) -> AvgPool2d(k, s)  -> carrier tokens                TokenInitializer
+  HATFunction              hierarchical attention block: carrier-token attention + MLP, window attention + MLP
+                           over [carrier ; window] tokens, split                              HAT
+(the stem uses vit_functions.ConvStemFunction / DenseConvBNFunction with ReLU, the tail TailFunction with one head).
+
+Dense 3x3 convolutions run as im2col + the MFMA GEMM kernels; Linear layers run on the same GEMM kernels with the
+bias (and LayerScale, residual, DropPath scale) applied by the BatchNorm-apply pass under an identity statistic
+(mean 0, variance 1, eps 0), so `Linear + bias` needs no kernel of its own and its bias gradient is the BN-beta
+gradient.  Window bookkeeping (partition, carrier-token concatenation and split) is `dfd_copy_rows` with index
+maps built once per batch size.  Reference call sites: trainers/fastervit.py:271 (train), :235 (evaluate),
+orchestration/orchestrator.py:529,590; arithmetic per fastervit 1.0.0 faster_vit.py (restated in
+oracle/fastervit_ref.py).
+"""
+
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+import torch
+
+from . import kernels as K
+from ._lib import ACT_GELU, ACT_NONE, ACT_RELU
+from .functions import BNRef, _bn_state, _c
+from .vit_functions import _gemm_weight, _partial_rows, _rows, _slot, pwbn_bwd, pwbn_fwd
+
+_ident_cache: dict = {}
+
+
+def ident(device: torch.device, C: int):
+    """(ones [C], BNRef with mean 0 / variance 1 / eps 0): the identity statistic that turns the BN-apply kernels into
+    `+ bias`."""
+    key = (device.type, device.index, C)
+    hit = _ident_cache.get(key)
+    if hit is None:
+        with torch.inference_mode(False):
+            ones = torch.ones(C, dtype=torch.float32, device=device)
+            zeros = torch.zeros(C, dtype=torch.float32, device=device)
+        hit = _ident_cache[key] = (ones, BNRef(zeros, ones, None, 0.0, 0.0))
+    return hit
+
+
+def tok4(t: torch.Tensor) -> torch.Tensor:
+    """[n, T, C] token tensor as the [n, T, 1, C] NHWC view the row kernels take."""
+    return t if t.dim() == 4 else t.view(t.shape[0], t.shape[1], 1, t.shape[2])
+
+
+# =========================================================================== Linear on the GEMM kernels
+def lin_fwd(x, w_nk, bias, act=ACT_NONE, ls=None, residual=None, row_scale=None):
+    ones, ref = ident(x.device, w_nk.shape[0])
+    return pwbn_fwd(x, w_nk, None, ones, bias, ref, False, None, act, ls, residual, row_scale)
+
+
+def lin_bwd(g, x, y, st, w_kn, w, bias, ls, act, need_dx, need_w, need_b, need_ls=False, dx_residual=None, row_scale=None):
+    """-> (dx, dw, dbias, dls)"""
+    ones, _ = ident(x.device, w.shape[0])
+    dx, dw, _, _, dbeta, dls = pwbn_bwd(g, x, y, st, w_kn, tuple(w.shape), w, None, ones, bias, ls, act, False, need_dx, need_w,
+                                        need_b and bias is not None, need_ls, dx_residual, row_scale)
+    return dx, dw, (dbeta if need_b else None), dls
+
+
+# =========================================================================== tiny coordinate MLPs (f32)
+def coord_mlp_fwd(coords, w0, b0, w2):
+    """Linear(2, 512) -> ReLU -> Linear(512, D, bias=False) on a [T, 2] coordinate table."""
+    hpre = K.linear_fwd(coords, w0, b0)
+    h = K.bn_add_act(hpre, None, None, ACT_RELU)
+    return K.linear_fwd(h, w2, None), (hpre, h)
+
+
+def coord_mlp_bwd(dtab, coords, w0, b0, w2, saved, need):
+    hpre, h = saved
+    dh, dw2, _ = K.linear_bwd(dtab, h, w2, True, need[2], False, _slot(w2, need[2], tuple(w2.shape)), None)
+    dhpre, _, _ = K.bn_add_act_bwd(dh, hpre, None, None, ACT_RELU, stats=False)
+    _, dw0, db0 = K.linear_bwd(dhpre, coords, w0, False, need[0], need[1], _slot(w0, need[0], tuple(w0.shape)),
+                               _slot(b0, need[1], tuple(b0.shape)))
+    return dw0, db0, dw2
+
+
+# =========================================================================== attention / MLP sub-blocks on [n, T, C]
+@dataclass
+class AttnSpec:
+    heads: int
+    n_local: int            # tokens of the window grid (49, or 16 for the carrier grid)
+    n_global: int           # carrier tokens in front (4 in level 2's window attention, else 0)
+    coords2d: torch.Tensor  # [(2w-1)^2, 2] f32 log-spaced relative coordinates
+    idx: torch.Tensor       # int32 [n_local^2] relative position index
+
+
+def attn_sub_fwd(x, P, spec: AttnSpec, ls, row_scale):
+    """x + [rs *] [ls *] proj(softmax(q k^T * scale + bias) v) with q, k, v = qkv(LN(x)).
+    P: dict of tensors (ln_w, ln_b, qkv_w, qkv_b, proj_w, proj_b, cpb_w0, cpb_b0, cpb_w2)."""
+    n, T, _, C = x.shape
+    H = spec.heads
+    hd = C // H
+    dt = x.dtype
+    xn, lnst = K.layernorm_fwd(x, P["ln_w"], P["ln_b"], 1e-5)
+    wq_nk, wq_kn = K.prep_weights(P["qkv_w"], dt, True, True)
+    qkv, yq, stq = lin_fwd(xn, wq_nk, P["qkv_b"])
+    table, mlp_saved = coord_mlp_fwd(spec.coords2d, P["cpb_w0"], P["cpb_b0"], P["cpb_w2"])
+    bias_full = K.relpos_bias_fwd(table, spec.idx, spec.n_local, spec.n_global)
+    S = torch.empty((n, H, T, T), dtype=torch.float32, device=x.device)
+    q, k, v = qkv.view(n * T, 3 * C)[:, 0:C], qkv.view(n * T, 3 * C)[:, C:2 * C], qkv.view(n * T, 3 * C)[:, 2 * C:]
+    K.bgemm(q, (T * 3 * C, hd, 3 * C, 1), k, (T * 3 * C, hd, 1, 3 * C), S, (H * T * T, T * T, T, 1), n, H, T, T, hd,
+            alpha=hd ** -0.5, bias=bias_full)
+    Pm, _ = K.attn_softmax_fwd(S, None)
+    O = torch.empty((n, T, 1, C), dtype=dt, device=x.device)
+    K.bgemm(Pm, (H * T * T, T * T, T, 1), v, (T * 3 * C, hd, 3 * C, 1), O, (T * C, hd, C, 1), n, H, T, hd, T)
+    wp_nk, wp_kn = K.prep_weights(P["proj_w"], dt, True, True)
+    out, yp, stp = lin_fwd(O, wp_nk, P["proj_b"], ACT_NONE, ls, x, row_scale)
+    return out, (x, xn, lnst, qkv, yq, stq, table, mlp_saved, Pm, O, yp, stp, wq_kn, wp_kn)
+
+
+def attn_sub_bwd(g, saved, P, spec: AttnSpec, ls, row_scale, need: dict, need_dx: bool):
+    """-> (dx, grads dict).  need: name -> bool for the entries of P and 'ls'."""
+    x, xn, lnst, qkv, yq, stq, table, mlp_saved, Pm, O, yp, stp, wq_kn, wp_kn = saved
+    n, T, _, C = x.shape
+    H = spec.heads
+    hd = C // H
+    dev = x.device
+    grads = {}
+    upstream = need_dx or any(need[k] for k in ("ln_w", "ln_b", "qkv_w", "qkv_b", "cpb_w0", "cpb_b0", "cpb_w2"))
+    dO, grads["proj_w"], grads["proj_b"], grads["ls"] = lin_bwd(g, O, yp, stp, wp_kn, P["proj_w"], P["proj_b"], ls, ACT_NONE, upstream,
+                                                                 need["proj_w"], need["proj_b"], need["ls"], None, row_scale)
+    if not upstream:
+        return None, grads
+    q, k, v = qkv.view(n * T, 3 * C)[:, 0:C], qkv.view(n * T, 3 * C)[:, C:2 * C], qkv.view(n * T, 3 * C)[:, 2 * C:]
+    L = T * T
+    dT2 = torch.empty((n, H, T, T), dtype=torch.float32, device=dev)
+    K.bgemm(dO, (T * C, hd, C, 1), v, (T * 3 * C, hd, 1, 3 * C), dT2, (H * L, L, T, 1), n, H, T, T, hd)
+    dqkv = torch.empty_like(qkv)
+    dq, dk, dv = dqkv.view(n * T, 3 * C)[:, 0:C], dqkv.view(n * T, 3 * C)[:, C:2 * C], dqkv.view(n * T, 3 * C)[:, 2 * C:]
+    K.bgemm(Pm, (H * L, L, 1, T), dO, (T * C, hd, C, 1), dv, (T * 3 * C, hd, 3 * C, 1), n, H, T, hd, T)
+    dS_buf = torch.empty((_partial_rows(n), H, T, T), dtype=torch.float32, device=dev)
+    from ._lib import check
+
+    check(K._L().dfd_attn_softmax_bwd(dT2.data_ptr(), Pm.data_ptr(), None, None, None, dS_buf.data_ptr(), n, H, T, T, K._stream()),
+          "dfd_attn_softmax_bwd")
+    dS = dS_buf[:n]
+    scale = hd ** -0.5
+    K.bgemm(dS, (H * L, L, T, 1), k, (T * 3 * C, hd, 3 * C, 1), dq, (T * 3 * C, hd, 3 * C, 1), n, H, T, hd, T, alpha=scale)
+    K.bgemm(dS, (H * L, L, 1, T), q, (T * 3 * C, hd, 3 * C, 1), dk, (T * 3 * C, hd, 3 * C, 1), n, H, T, hd, T, alpha=scale)
+    if need["cpb_w0"] or need["cpb_b0"] or need["cpb_w2"]:
+        dfull = torch.empty(H * L, dtype=torch.float32, device=dev)
+        K.sum_rows(dS_buf.view(-1), n, H * L, dfull)
+        dtable = K.relpos_bias_bwd(dfull.view(H, T, T), table, spec.idx, spec.n_local, spec.n_global)
+        grads["cpb_w0"], grads["cpb_b0"], grads["cpb_w2"] = coord_mlp_bwd(dtable, spec.coords2d, P["cpb_w0"], P["cpb_b0"], P["cpb_w2"],
+                                                                          mlp_saved, (need["cpb_w0"], need["cpb_b0"], need["cpb_w2"]))
+    need_xn = need_dx or need["ln_w"] or need["ln_b"]
+    dxn, grads["qkv_w"], grads["qkv_b"], _ = lin_bwd(dqkv, xn, yq, stq, wq_kn, P["qkv_w"], P["qkv_b"], None, ACT_NONE, need_xn,
+                                                     need["qkv_w"], need["qkv_b"])
+    dx = None
+    if need_xn:
+        dx_ln, dg, db = K.layernorm_bwd(dxn, x, P["ln_w"], lnst)
+        grads["ln_w"] = _to_slot(dg, P["ln_w"], need["ln_w"])
+        grads["ln_b"] = _to_slot(db, P["ln_b"], need["ln_b"])
+        if need_dx:
+            dx = K.add(dx_ln, g)
+    return dx, grads
+
+
+def _to_slot(val: torch.Tensor, param: torch.Tensor, need: bool):
+    """Move a freshly computed f32 gradient into the parameter's arena slot when it has one."""
+    if not need:
+        return None
+    slot = _slot(param, True, tuple(param.shape))
+    if slot is None:
+        return val.view(param.shape)
+    return K.axpby(val.reshape(-1), None, 1.0, 0.0, out=slot.view(-1)).view(param.shape)
+
+
+def mlp_sub_fwd(x, P, ls, row_scale):
+    """x + [rs *] [ls *] fc2(GELU(fc1(LN(x)))).  P: ln_w, ln_b, fc1_w, fc1_b, fc2_w, fc2_b."""
+    dt = x.dtype
+    xn, lnst = K.layernorm_fwd(x, P["ln_w"], P["ln_b"], 1e-5)
+    w1_nk, w1_kn = K.prep_weights(P["fc1_w"], dt, True, True)
+    h, _, _ = K.pwconv(xn, None, w1_nk, None, stats=False)
+    hid = P["fc1_w"].shape[0]
+    ones, ref = ident(x.device, hid)
+    st1 = _bn_state(None, 0, _rows(h), ref, ones, P["fc1_b"], False)
+    w2_nk, w2_kn = K.prep_weights(P["fc2_w"], dt, True, True)
+    y2, _, _ = K.pwconv(h, K.pro_bn_act(st1, ACT_GELU), w2_nk, None, stats=False)
+    C = P["fc2_w"].shape[0]
+    ones2, ref2 = ident(x.device, C)
+    st2 = _bn_state(None, 0, _rows(y2), ref2, ones2, P["fc2_b"], False, None, None, ls)
+    out = K.bn_act_apply(y2, st2, ACT_NONE, x, row_scale)
+    return out, (x, xn, lnst, h, st1, y2, st2, w1_kn, w2_kn)
+
+
+def mlp_sub_bwd(g, saved, P, ls, row_scale, need: dict, need_dx: bool):
+    x, xn, lnst, h, st1, y2, st2, w1_kn, w2_kn = saved
+    grads = {}
+    C, hid = P["fc2_w"].shape[0], P["fc1_w"].shape[0]
+    dev = x.device
+    gb = K.scale_rows(g, row_scale) if row_scale is not None else g
+    parts, n = K.bn_bwd_reduce(gb, y2, st2, None)
+    ones2, _ = ident(dev, C)
+    outs = (None, _slot(P["fc2_b"], need["fc2_b"], (C,)), _slot(ls, need["ls"], (C,)), None)
+    coef2, _, db2, dls, _ = K.bn_bwd_finalize_ex(parts, n, _rows(y2), ones2, P["fc2_b"], ls, st2, False, need["fc2_b"] or True, need["ls"],
+                                                 False, outs)
+    grads["fc2_b"], grads["ls"] = (db2 if need["fc2_b"] else None), dls
+    pro2 = K.pro_affine2(y2, coef2)
+    upstream = need_dx or any(need[k] for k in ("ln_w", "ln_b", "fc1_w", "fc1_b"))
+    if need["fc2_w"]:
+        grads["fc2_w"] = K.pwconv_wgrad(gb, pro2, h, K.pro_bn_act(st1, ACT_GELU), _slot(P["fc2_w"], True, (C, hid))).view(P["fc2_w"].shape)
+    if not upstream:
+        return None, grads
+    D, _, _ = K.pwconv(gb, pro2, w2_kn, None, stats=False)
+    dz1, parts, n = K.act_bn_bwd(D, h, None, None, st1, ACT_GELU)
+    if need["fc1_b"]:
+        ones1, _ = ident(dev, hid)
+        _, _, db1, _, _ = K.bn_bwd_finalize_ex(parts, n, _rows(h), ones1, P["fc1_b"], None, st1, False, True, False, False,
+                                               (None, _slot(P["fc1_b"], True, (hid,)), None, None))
+        grads["fc1_b"] = db1
+    if need["fc1_w"]:
+        grads["fc1_w"] = K.pwconv_wgrad(dz1, None, xn, None, _slot(P["fc1_w"], True, (hid, C))).view(P["fc1_w"].shape)
+    dx = None
+    if need_dx or need["ln_w"] or need["ln_b"]:
+        dxn, _, _ = K.pwconv(dz1, None, w1_kn, None, stats=False)
+        dx_ln, dg, db = K.layernorm_bwd(dxn, x, P["ln_w"], lnst)
+        grads["ln_w"] = _to_slot(dg, P["ln_w"], need["ln_w"])
+        grads["ln_b"] = _to_slot(db, P["ln_b"], need["ln_b"])
+        if need_dx:
+            dx = K.add(dx_ln, g)
+    return dx, grads
+
+
+# =========================================================================== HAT block
+_ATTN_KEYS = ("ln_w", "ln_b", "qkv_w", "qkv_b", "proj_w", "proj_b", "cpb_w0", "cpb_b0", "cpb_w2")
+_MLP_KEYS = ("ln_w", "ln_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b")
+_POS_KEYS = ("w0", "b0", "w2")
+
+
+@dataclass
+class HATCtx:
+    heads: int
+    carrier: bool                       # level 2: carrier-token stream + concatenation
+    win_spec: AttnSpec
+    ct_spec: AttnSpec | None
+    coords_win: torch.Tensor            # [49, 2] PosEmbMLPSwinv1D coordinates of the window grid
+    coords_ct: torch.Tensor | None      # [16, 2]
+    cat_src_ct: torch.Tensor | None     # int32 [nW*4]: carrier row of every (window, slot)
+    cat_dst_ct: torch.Tensor | None     # int32 [nW*4]: its row in the concatenated tensor
+    cat_dst_x: torch.Tensor | None      # int32 [nW*49]: row of every window token in the concatenated tensor
+    training: bool
+
+
+def _layout(carrier: bool, has_ls: bool) -> list[str]:
+    """Order of the tensor inputs after (x, ct)."""
+    names = [f"pos.{k}" for k in _POS_KEYS] + [f"attn.{k}" for k in _ATTN_KEYS] + [f"mlp.{k}" for k in _MLP_KEYS]
+    if carrier:
+        names += [f"hpos.{k}" for k in _POS_KEYS] + [f"hattn.{k}" for k in _ATTN_KEYS] + [f"hmlp.{k}" for k in _MLP_KEYS]
+    names += ["gamma3", "gamma4"] + (["gamma1", "gamma2"] if carrier else [])
+    names += ["rs_win", "rs_ct"]
+    return names
+
+
+class HATFunction(torch.autograd.Function):
+    """One hierarchical-attention block.  x: [nW, 49, 1, C] window tokens; ct: [B, 16, 1, C] carrier tokens in row-major
+    image order (None without carrier tokens).  Returns (x_out, ct_out)."""
+
+    @staticmethod
+    def forward(ctx, x, ct, cfg: HATCtx, *t):
+        names = _layout(cfg.carrier, True)
+        T = dict(zip(names, t))
+        nW, Tw, _, C = x.shape
+
+        def sub(prefix, keys):
+            return {k: T[f"{prefix}.{k}"] for k in keys}
+
+        tab_x, pos_saved = coord_mlp_fwd(cfg.coords_win, T["pos.w0"], T["pos.b0"], T["pos.w2"])
+        x1 = K.add_rowtable(x, tab_x)
+        saved_ct = None
+        if cfg.carrier:
+            B, Tc = ct.shape[0], ct.shape[1]
+            tab_c, hpos_saved = coord_mlp_fwd(cfg.coords_ct, T["hpos.w0"], T["hpos.b0"], T["hpos.w2"])
+            c1 = K.add_rowtable(ct, tab_c)
+            c2, hattn_saved = attn_sub_fwd(c1, sub("hattn", _ATTN_KEYS), cfg.ct_spec, T["gamma1"], T["rs_ct"])
+            c3, hmlp_saved = mlp_sub_fwd(c2, sub("hmlp", _MLP_KEYS), T["gamma2"], T["rs_ct"])
+            per = Tc * B // nW                                      # carrier tokens per window (4)
+            xc = torch.empty((nW, Tw + per, 1, C), dtype=x.dtype, device=x.device)
+            K.copy_rows(c3.view(-1, C), cfg.cat_src_ct, xc.view(-1, C), cfg.cat_dst_ct, nW * per)
+            K.copy_rows(x1.view(-1, C), None, xc.view(-1, C), cfg.cat_dst_x, nW * Tw)
+            saved_ct = (hpos_saved, hattn_saved, hmlp_saved, per)
+        else:
+            xc = x1
+        xa, attn_saved = attn_sub_fwd(xc, sub("attn", _ATTN_KEYS), cfg.win_spec, T["gamma3"], T["rs_win"])
+        xm, mlp_saved = mlp_sub_fwd(xa, sub("mlp", _MLP_KEYS), T["gamma4"], T["rs_win"])
+        if cfg.carrier:
+            per = saved_ct[3]
+            x_out = torch.empty_like(x)
+            ct_out = torch.empty_like(ct)
+            K.copy_rows(xm.view(-1, C), cfg.cat_dst_x, x_out.view(-1, C), None, nW * Tw)
+            K.copy_rows(xm.view(-1, C), cfg.cat_dst_ct, ct_out.view(-1, C), cfg.cat_src_ct, nW * per)
+        else:
+            x_out, ct_out = xm, None
+        ctx.cfg = cfg
+        ctx.names = names
+        ctx.T = T
+        ctx.saved = (pos_saved, saved_ct, attn_saved, mlp_saved)
+        ctx.shapes = (tuple(x.shape), tuple(ct.shape) if ct is not None else None, x.dtype)
+        if ct_out is None:
+            ctx.mark_non_differentiable()
+            return x_out, None
+        return x_out, ct_out
+
+    @staticmethod
+    def backward(ctx, gx, gct):
+        cfg: HATCtx = ctx.cfg
+        names, T = ctx.names, ctx.T
+        pos_saved, saved_ct, attn_saved, mlp_saved = ctx.saved
+        x_shape, ct_shape, dt = ctx.shapes
+        need = dict(zip(["x", "ct", "cfg"] + names, ctx.needs_input_grad))
+        nW, Tw, _, C = x_shape
+        dev = gx.device
+        grads: dict = {}
+
+        def sub(prefix, keys):
+            return {k: T[f"{prefix}.{k}"] for k in keys}
+
+        def sub_need(prefix, keys, gamma):
+            d = {k: need[f"{prefix}.{k}"] for k in keys}
+            d["ls"] = need[gamma]
+            return d
+
+        carrier_up = cfg.carrier and (need["ct"] or any(need[n] for n in names if n.startswith(("hpos", "hattn", "hmlp", "gamma1", "gamma2"))))
+        need_x1 = need["x"] or any(need[f"pos.{k}"] for k in _POS_KEYS)
+        gx = _c(gx)
+        if cfg.carrier:
+            per = saved_ct[3]
+            gm = torch.empty((nW, Tw + per, 1, C), dtype=dt, device=dev)
+            K.copy_rows(gx.view(-1, C), None, gm.view(-1, C), cfg.cat_dst_x, nW * Tw)
+            if gct is not None:
+                K.copy_rows(_c(gct).view(-1, C), cfg.cat_src_ct, gm.view(-1, C), cfg.cat_dst_ct, nW * per)
+            else:
+                zero = torch.zeros((nW * per, C), dtype=dt, device=dev)
+                K.copy_rows(zero, None, gm.view(-1, C), cfg.cat_dst_ct, nW * per)
+        else:
+            gm = gx
+        need_xa = True
+        dxa, g_mlp = mlp_sub_bwd(gm, mlp_saved, sub("mlp", _MLP_KEYS), T["gamma4"], T["rs_win"], sub_need("mlp", _MLP_KEYS, "gamma4"), need_xa)
+        for k, v in g_mlp.items():
+            grads["gamma4" if k == "ls" else f"mlp.{k}"] = v
+        need_xc = need_x1 or carrier_up
+        dxc, g_attn = attn_sub_bwd(dxa, attn_saved, sub("attn", _ATTN_KEYS), cfg.win_spec, T["gamma3"], T["rs_win"],
+                                   sub_need("attn", _ATTN_KEYS, "gamma3"), need_xc)
+        for k, v in g_attn.items():
+            grads["gamma3" if k == "ls" else f"attn.{k}"] = v
+        dx = dct = None
+        if cfg.carrier:
+            hpos_saved, hattn_saved, hmlp_saved, per = saved_ct
+            dx1 = None
+            if need_x1:
+                dx1 = torch.empty(x_shape, dtype=dt, device=dev)
+                K.copy_rows(dxc.view(-1, C), cfg.cat_dst_x, dx1.view(-1, C), None, nW * Tw)
+            if carrier_up:
+                dc3 = torch.empty(ct_shape, dtype=dt, device=dev)
+                K.copy_rows(dxc.view(-1, C), cfg.cat_dst_ct, dc3.view(-1, C), cfg.cat_src_ct, nW * per)
+                dc2, g_hm = mlp_sub_bwd(dc3, hmlp_saved, sub("hmlp", _MLP_KEYS), T["gamma2"], T["rs_ct"], sub_need("hmlp", _MLP_KEYS, "gamma2"), True)
+                for k, v in g_hm.items():
+                    grads["gamma2" if k == "ls" else f"hmlp.{k}"] = v
+                need_c1 = need["ct"] or any(need[f"hpos.{k}"] for k in _POS_KEYS)
+                dc1, g_ha = attn_sub_bwd(dc2, hattn_saved, sub("hattn", _ATTN_KEYS), cfg.ct_spec, T["gamma1"], T["rs_ct"],
+                                         sub_need("hattn", _ATTN_KEYS, "gamma1"), need_c1)
+                for k, v in g_ha.items():
+                    grads["gamma1" if k == "ls" else f"hattn.{k}"] = v
+                if need_c1:
+                    if any(need[f"hpos.{k}"] for k in _POS_KEYS):
+                        dtab = K.rowtable_grad(dc1, ct_shape[1])
+                        dw0, db0, dw2 = coord_mlp_bwd(dtab, cfg.coords_ct, T["hpos.w0"], T["hpos.b0"], T["hpos.w2"], hpos_saved,
+                                                      tuple(need[f"hpos.{k}"] for k in _POS_KEYS))
+                        grads["hpos.w0"], grads["hpos.b0"], grads["hpos.w2"] = dw0, db0, dw2
+                    dct = dc1 if need["ct"] else None
+        else:
+            dx1 = dxc
+        if need_x1 and dx1 is not None:
+            if any(need[f"pos.{k}"] for k in _POS_KEYS):
+                dtab = K.rowtable_grad(dx1, Tw)
+                dw0, db0, dw2 = coord_mlp_bwd(dtab, cfg.coords_win, T["pos.w0"], T["pos.b0"], T["pos.w2"], pos_saved,
+                                              tuple(need[f"pos.{k}"] for k in _POS_KEYS))
+                grads["pos.w0"], grads["pos.b0"], grads["pos.w2"] = dw0, db0, dw2
+            dx = dx1 if need["x"] else None
+        flat = [grads.get(nm) if need[nm] else None for nm in names]
+        return (dx, dct, None, *flat)
+
+
+# =========================================================================== ConvBlock (levels 0, 1)
+@dataclass
+class ConvBlockCtx:
+    bn1: BNRef
+    bn2: BNRef
+    training: bool
+    counters: list | None = None
+
+
+class ConvBlockFunction(torch.autograd.Function):
+    """x + [rs *] [gamma *] BN(conv3x3(GELU(BN(conv3x3(x)))))  (both convolutions with bias, folded into the BNs)."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, g1, be1, w2, b2, g2, be2, gamma, row_scale, cfg: ConvBlockCtx):
+        tr = cfg.training
+        N, H, W, C = x.shape
+        need_bwd = any(ctx.needs_input_grad)
+        w1_nk, w1_kn = _gemm_weight(w1, x.dtype, need_bwd)
+        col1 = K.im2col(x, None, ACT_NONE, 3, 1, 1, H, W)
+        y1, parts, n = K.pwconv(col1, None, w1_nk, None, stats=tr)
+        del col1
+        st1 = _bn_state(parts, n, N * H * W, cfg.bn1, g1, be1, tr, cfg.counters, conv_bias=b1)
+        w2_nk, w2_kn = _gemm_weight(w2, x.dtype, need_bwd)
+        col2 = K.im2col(y1, st1, ACT_GELU, 3, 1, 1, H, W)
+        y2, parts, n = K.pwconv(col2, None, w2_nk, None, stats=tr)
+        del col2
+        st2 = _bn_state(parts, n, N * H * W, cfg.bn2, g2, be2, tr, cfg.counters, conv_bias=b2, ls=gamma)
+        out = K.bn_act_apply(y2, st2, ACT_NONE, x, row_scale)
+        ctx.cfg = cfg
+        ctx.save_for_backward(x, y1, y2, st1, st2, w1_kn, w2_kn, w1, b1, g1, be1, w2, b2, g2, be2, gamma, row_scale)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        cfg: ConvBlockCtx = ctx.cfg
+        x, y1, y2, st1, st2, w1_kn, w2_kn, w1, b1, g1, be1, w2, b2, g2, be2, gamma, row_scale = ctx.saved_tensors
+        need = ctx.needs_input_grad
+        tr = cfg.training
+        N, H, W, C = x.shape
+        rows = N * H * W
+        g = _c(g)
+        gb = K.scale_rows(g, row_scale) if row_scale is not None else g
+        parts, n = K.bn_bwd_reduce(gb, y2, st2, None)
+        nb2 = need[7] or need[8]
+        outs = (_slot(g2, nb2, (C,)), _slot(be2, nb2, (C,)), _slot(gamma, need[9], (C,)), _slot(b2, need[6], (C,)))
+        coef2, dg2, dbe2, dgam, db2 = K.bn_bwd_finalize_ex(parts, n, rows, g2, be2, gamma, st2, tr, nb2, need[9] and gamma is not None,
+                                                           need[6], outs)
+        pro2 = K.pro_affine2(y2, coef2)
+        dw2 = None
+        if need[5]:
+            col2 = K.im2col(y1, st1, ACT_GELU, 3, 1, 1, H, W)
+            dwg = K.pwconv_wgrad(gb, pro2, col2, None)
+            del col2
+            dw2 = K.conv_wgrad_from_gemm(dwg, tuple(w2.shape), _slot(w2, True, tuple(w2.shape)))
+        dcol2, _, _ = K.pwconv(gb, pro2, w2_kn, None, stats=False)
+        da1 = K.col2im(dcol2, (N, H, W, C), 3, 1, 1)
+        del dcol2
+        dz1, parts, n = K.act_bn_bwd(da1, y1, None, None, st1, ACT_GELU)
+        nb1 = need[3] or need[4]
+        outs = (_slot(g1, nb1, (C,)), _slot(be1, nb1, (C,)), None, _slot(b1, need[2], (C,)))
+        coef1, dg1, dbe1, _, db1 = K.bn_bwd_finalize_ex(parts, n, rows, g1, be1, None, st1, tr, nb1, False, need[2], outs)
+        pro1 = K.pro_affine2(y1, coef1)
+        dw1 = dx = None
+        if need[1]:
+            col1 = K.im2col(x, None, ACT_NONE, 3, 1, 1, H, W)
+            dwg = K.pwconv_wgrad(dz1, pro1, col1, None)
+            del col1
+            dw1 = K.conv_wgrad_from_gemm(dwg, tuple(w1.shape), _slot(w1, True, tuple(w1.shape)))
+        if need[0]:
+            dcol1, _, _ = K.pwconv(dz1, pro1, w1_kn, None, stats=False)
+            dx = K.add(K.col2im(dcol1, (N, H, W, C), 3, 1, 1), g)
+        return (dx, dw1, db1 if need[2] else None, dg1, dbe1, dw2, db2 if need[6] else None, dg2, dbe2, dgam, None, None)
+
+
+# =========================================================================== Downsample (LayerNorm2d + conv3x3 s2)
+class FVDownsampleFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, ln_w, ln_b, w):
+        N, H, W, C = x.shape
+        need_bwd = any(ctx.needs_input_grad)
+        xn, lnst = K.layernorm_fwd(x, ln_w, ln_b, 1e-6)
+        w_nk, w_kn = _gemm_weight(w, x.dtype, need_bwd)
+        Ho, Wo = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
+        col = K.im2col(xn, None, ACT_NONE, 3, 2, 1, Ho, Wo)
+        y, _, _ = K.pwconv(col, None, w_nk, None, stats=False)
+        ctx.save_for_backward(x, xn, lnst, w_kn, ln_w, ln_b, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, xn, lnst, w_kn, ln_w, ln_b, w = ctx.saved_tensors
+        need = ctx.needs_input_grad
+        N, H, W, C = x.shape
+        g = _c(g)
+        dw = dx = dlw = dlb = None
+        if need[3]:
+            col = K.im2col(xn, None, ACT_NONE, 3, 2, 1, g.shape[1], g.shape[2])
+            dwg = K.pwconv_wgrad(g, None, col, None)
+            del col
+            dw = K.conv_wgrad_from_gemm(dwg, tuple(w.shape), _slot(w, True, tuple(w.shape)))
+        if need[0] or need[1] or need[2]:
+            dcol, _, _ = K.pwconv(g, None, w_kn, None, stats=False)
+            dxn = K.col2im(dcol, (N, H, W, C), 3, 2, 1)
+            dx, dgm, dbt = K.layernorm_bwd(dxn, x, ln_w, lnst)
+            dlw, dlb = _to_slot(dgm, ln_w, need[1]), _to_slot(dbt, ln_b, need[2])
+            if not need[0]:
+                dx = None
+        return dx, dlw, dlb, dw
+
+
+# =========================================================================== carrier-token initialiser
+class TokenInitFunction(torch.autograd.Function):
+    """dw3x3 (+bias) -> AvgPool2d(kernel, stride): [B, H, W, C] -> [B, h*w, 1, C] carrier tokens in row-major order."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, kernel: int, stride: int):
+        N, H, W, C = x.shape
+        y, _, _ = K.dwconv_fwd(x, None, ACT_NONE, w, 3, 1, 1, 1, H, W, stats=False)
+        p = K.avgpool_fwd(y, kernel, stride)
+        out = K.add_rowtable(p, b.view(1, C))
+        ctx.save_for_backward(x, w, b)
+        ctx.geom = (kernel, stride, tuple(y.shape))
+        return out.view(N, p.shape[1] * p.shape[2], 1, C)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w, b = ctx.saved_tensors
+        kernel, stride, yshape = ctx.geom
+        need = ctx.needs_input_grad
+        N, H, W, C = x.shape
+        ho = (H - kernel) // stride + 1
+        g4 = _c(g).view(N, ho, -1, C)
+        db = _to_slot(K.rowtable_grad(g4, 1).view(-1), b, need[2])
+        dx = dw = None
+        if need[0] or need[1]:
+            dy = K.avgpool_bwd(g4, yshape, kernel, stride)
+            if need[0]:
+                dx, _, _ = K.dwconv_bwd_data(dy, None, None, w, None, None, ACT_NONE, tuple(x.shape), 3, 1, 1, 1)
+            if need[1]:
+                dw = K.dwconv_bwd_weight(dy, None, None, x, None, ACT_NONE, 3, 1, 1, 1, _slot(w, True, (C, 1, 3, 3)))
+        return dx, dw, db, None, None
+
+
+__all__ = ["AttnSpec", "ConvBlockCtx", "ConvBlockFunction", "FVDownsampleFunction", "HATCtx", "HATFunction", "TokenInitFunction"]

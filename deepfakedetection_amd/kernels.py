@@ -578,11 +578,20 @@ def channel_stats(x: torch.Tensor):
 
 
 def sum_rows(partials: torch.Tensor, P: int, L: int, out: torch.Tensor, accumulate: bool = False) -> torch.Tensor:
-    """out[i] = sum_p partials[p][i]; `partials` (flat f32) must hold P + ceil(P/32) rows of L floats."""
-    if partials.numel() < (P + (P + 31) // 32) * L:
+    """out[i] = sum_p partials[p][i] in a fixed order; `partials` (flat f32) must hold P + ceil(P/32) rows of L floats
+    (the second reduction stage is written behind the slab).  More than 1024 rows are summed in groups of 1024, last
+    group first, so that a group's second stage only overwrites rows that have already been consumed."""
+    if partials.numel() < (P + (min(P, 1024) + 31) // 32) * L:
         raise ValueError("sum_rows: partial slab too small for the two-stage reduction")
-    check(_L().dfd_sum_rows(_p(partials), P, L, _p(out), int(accumulate), _stream()), "dfd_sum_rows")
-    return out
+    if P <= 1024:
+        check(_L().dfd_sum_rows(_p(partials), P, L, _p(out), int(accumulate), _stream()), "dfd_sum_rows")
+        return out
+    G = (P + 1023) // 1024
+    tmp = torch.empty((G + (G + 31) // 32 + 1) * L, dtype=torch.float32, device=partials.device)
+    for gi in reversed(range(G)):
+        rows = min(1024, P - gi * 1024)
+        check(_L().dfd_sum_rows(partials.data_ptr() + gi * 1024 * L * 4, rows, L, tmp.data_ptr() + gi * L * 4, 0, _stream()), "dfd_sum_rows")
+    return sum_rows(tmp, G, L, out, accumulate)
 
 
 def up2_act_fwd(s: torch.Tensor, act: int) -> torch.Tensor:
@@ -727,6 +736,61 @@ def layernorm_bwd(g: torch.Tensor, x: torch.Tensor, gamma: torch.Tensor, stats: 
     both = torch.empty((2, C), dtype=torch.float32, device=x.device)
     sum_rows(parts, n.value, 2 * C, both)
     return dx, both[0], both[1]
+
+
+def copy_rows(src: torch.Tensor, sidx: torch.Tensor | None, dst: torch.Tensor, didx: torch.Tensor | None, n: int) -> torch.Tensor:
+    """dst[didx[r]] = src[sidx[r]] for r < n over [rows, C] matrices (int32 index tensors; None = identity)."""
+    C = src.shape[-1]
+    if dst.shape[-1] != C or src.dtype != dst.dtype:
+        raise ValueError("copy_rows: source and destination rows differ")
+    check(_L().dfd_copy_rows(_dt(src), _p(src), _p(sidx), _p(dst), _p(didx), n, C, _stream()), "dfd_copy_rows")
+    return dst
+
+
+def add_rowtable(x: torch.Tensor, table: torch.Tensor) -> torch.Tensor:
+    """x [.., T, C] + table [T, C] (f32), broadcast over the leading dimensions."""
+    T, C = table.shape
+    out = torch.empty_like(x)
+    check(_L().dfd_add_rowtable(_dt(x), _p(x), _p(table), _p(out), x.numel() // C, T, C, _stream()), "dfd_add_rowtable")
+    return out
+
+
+def rowtable_grad(g: torch.Tensor, T: int) -> torch.Tensor:
+    C = g.shape[-1]
+    dtable = torch.empty((T, C), dtype=torch.float32, device=g.device)
+    check(_L().dfd_rowtable_grad(_dt(g), _p(g), _p(dtable), g.numel() // C, T, C, 0, _stream()), "dfd_rowtable_grad")
+    return dtable
+
+
+def avgpool_fwd(x: torch.Tensor, k: int, stride: int) -> torch.Tensor:
+    _chk_nhwc(x)
+    N, H, W, C = x.shape
+    out = torch.empty((N, (H - k) // stride + 1, (W - k) // stride + 1, C), dtype=x.dtype, device=x.device)
+    check(_L().dfd_avgpool_fwd(_dt(x), _p(x), _p(out), N, H, W, k, stride, C, _stream()), "dfd_avgpool_fwd")
+    return out
+
+
+def avgpool_bwd(g: torch.Tensor, in_shape, k: int, stride: int) -> torch.Tensor:
+    N, H, W, C = in_shape
+    dx = torch.empty((N, H, W, C), dtype=g.dtype, device=g.device)
+    check(_L().dfd_avgpool_bwd(_dt(g), _p(g), _p(dx), N, H, W, k, stride, C, _stream()), "dfd_avgpool_bwd")
+    return dx
+
+
+def relpos_bias_fwd(table: torch.Tensor, idx: torch.Tensor, n_local: int, n_global: int) -> torch.Tensor:
+    """table [T, H] f32 -> [H, S, S] with S = n_local + n_global."""
+    H = table.shape[1]
+    S = n_local + n_global
+    full = torch.empty((H, S, S), dtype=torch.float32, device=table.device)
+    check(_L().dfd_relpos_bias_fwd(_p(table), _p(idx), _p(full), H, n_local, n_global, _stream()), "dfd_relpos_bias_fwd")
+    return full
+
+
+def relpos_bias_bwd(dfull: torch.Tensor, table: torch.Tensor, idx: torch.Tensor, n_local: int, n_global: int) -> torch.Tensor:
+    T, H = table.shape
+    dtable = torch.empty_like(table)
+    check(_L().dfd_relpos_bias_bwd(_p(dfull), _p(table), _p(idx), _p(dtable), H, T, n_local, n_global, _stream()), "dfd_relpos_bias_bwd")
+    return dtable
 
 
 def axpby(x: torch.Tensor, y: torch.Tensor | None, a: float = 1.0, b: float = 1.0, a_dev: torch.Tensor | None = None,

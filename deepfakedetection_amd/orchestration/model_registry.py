@@ -11,8 +11,10 @@ the builders return the HIP-backed modules of this package:
   efficientformer*  timm-compatible EfficientFormerV2-{S0,S1,S2,L} on the HIP kernels (the reference's
                     prefix entry, model_registry.py:60-66); the builder takes an optional img_size like
                     timm.create_model does in trainers/efficientformer_v2.py:327
-  faster_vit*       registered with the reference's metadata and a real trainer module; the HIP engine is
-                    not built yet and the builder says so loudly (no ATen fallback).
+  faster_vit*       fastervit-compatible FasterViT-{0,1,2,3} at 224 px on the HIP kernels (the reference's prefix
+                    entry, model_registry.py:67-75; it builds faster_vit_2_224 and swaps the head, :43-47).
+Any other name under these prefixes (e.g. faster_vit_4_21k_224) raises a loud NotImplementedError from the builder:
+there is no ATen fallback.
 """
 
 from __future__ import annotations
@@ -49,6 +51,17 @@ def _efformer(model_name: str, num_classes: int, img_size: int = 224) -> nn.Modu
     return build_efficientformer_v2(model_name, num_classes, img_size)
 
 
+def _fastervit(model_name: str, num_classes: int) -> nn.Module:
+    from ..fastervit import build_fastervit
+
+    try:
+        return build_fastervit(model_name, num_classes)
+    except KeyError as exc:
+        raise NotImplementedError(
+            f"FasterViT ('{model_name}') is registered but its MI355X engine is not built: only faster_vit_0/1/2/3_224 "
+            "run on the HIP kernels (there is no ATen fallback).") from exc
+
+
 def _not_built(family: str) -> Callable[[str, int], nn.Module]:
     def build(model_name: str, num_classes: int) -> nn.Module:
         raise NotImplementedError(
@@ -67,8 +80,7 @@ _exact: dict[str, ModelSpec] = {
 _by_prefix: dict[str, ModelSpec] = {
     "efficientformer": ModelSpec("efficientformerv2_s1", "deepfakedetection_amd.trainers.efficientformer_v2",
                                  "efficientformerv2_s1", 224, _efformer),
-    "faster_vit": ModelSpec("faster_vit_2_224", "deepfakedetection_amd.trainers.fastervit", "faster_vit_2_224", 224,
-                            _not_built("FasterViT")),
+    "faster_vit": ModelSpec("faster_vit_2_224", "deepfakedetection_amd.trainers.fastervit", "faster_vit_2_224", 224, _fastervit),
 }
 
 

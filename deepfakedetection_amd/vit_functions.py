@@ -711,7 +711,10 @@ class TailFunction(torch.autograd.Function):
         st = _bn_state(parts, n, N * H * W, cfg.bn, gamma, beta, tr, cfg.counters)
         pooled = K.pool_act(x, st, ACT_NONE)
         feat = K.dropout(pooled, drop_u, cfg.dropout) if drop_u is not None else pooled
-        logits = K.axpby(K.linear_fwd(feat, w_h, b_h), K.linear_fwd(feat, w_d, b_d), 0.5, 0.5)
+        if w_d is None:                       # a single classifier (FasterViT); two heads averaged: EfficientFormerV2
+            logits = K.linear_fwd(feat, w_h, b_h)
+        else:
+            logits = K.axpby(K.linear_fwd(feat, w_h, b_h), K.linear_fwd(feat, w_d, b_d), 0.5, 0.5)
         ctx.cfg = cfg
         ctx.save_for_backward(x, st, feat, gamma, beta, w_h, b_h, w_d, b_d, drop_u)
         return logits
@@ -723,13 +726,16 @@ class TailFunction(torch.autograd.Function):
         need = ctx.needs_input_grad
         N, H, W, C = x.shape
         J = w_h.shape[0]
-        half = K.axpby(_c(dlogits.float()), None, 0.5, 0.0)
         backbone = need[0] or need[1] or need[2]
+        two = w_d is not None
+        half = K.axpby(_c(dlogits.float()), None, 0.5, 0.0) if two else _c(dlogits.float())
         d1, dw_h, db_h = K.linear_bwd(half, feat, w_h, backbone, need[3], need[4], _slot(w_h, need[3], (J, C)), _slot(b_h, need[4], (J,)))
-        d2, dw_d, db_d = K.linear_bwd(half, feat, w_d, backbone, need[5], need[6], _slot(w_d, need[5], (J, C)), _slot(b_d, need[6], (J,)))
+        d2 = dw_d = db_d = None
+        if two:
+            d2, dw_d, db_d = K.linear_bwd(half, feat, w_d, backbone, need[5], need[6], _slot(w_d, need[5], (J, C)), _slot(b_d, need[6], (J,)))
         dx = dgamma = dbeta = None
         if backbone:
-            dfeat = K.axpby(d1, d2, 1.0, 1.0)
+            dfeat = K.axpby(d1, d2, 1.0, 1.0) if two else d1
             dpooled = K.dropout(dfeat, drop_u, cfg.dropout) if drop_u is not None else dfeat
             dz, parts, n = K.act_bn_bwd(None, x, None, dpooled, st, ACT_NONE)
             nb = need[1] or need[2]

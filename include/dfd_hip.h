@@ -336,6 +336,28 @@ int dfd_layernorm_fwd(int dtype, const void* x, const float* gamma, const float*
 int dfd_layernorm_bwd(int dtype, const void* g, const void* x, const float* gamma, const float* stats,
                       void* dx, float* partials, int pcap, int* nparts, long rows, int C, dfd_stream stream);
 
+/* Token bookkeeping of windowed attention (fastervit faster_vit.py window_partition / window_reverse /
+ * ct_dewindow / ct_window / cat / split): dst[didx[r]] = src[sidx[r]], r < n, rows of C elements; a NULL index
+ * array is the identity.  For the one-to-one maps above the backward pass is the same call with the arrays swapped. */
+int dfd_copy_rows(int dtype, const void* src, const int* sidx, void* dst, const int* didx, long n, int C,
+                  dfd_stream stream);
+/* PosEmbMLPSwinv1D: out[r] = x[r] + table[r % T] (table f32 [T][C]); dtable[t] = sum_w g[w*T + t]              */
+int dfd_add_rowtable(int dtype, const void* x, const float* table, void* out, long rows, int T, int C,
+                     dfd_stream stream);
+int dfd_rowtable_grad(int dtype, const void* g, float* dtable, long rows, int T, int C, int accumulate,
+                      dfd_stream stream);
+/* nn.AvgPool2d(k, stride) without padding on NHWC (TokenInitializer) and its gradient (dx [N][H][W][C])         */
+int dfd_avgpool_fwd(int dtype, const void* x, void* out, int N, int H, int W, int k, int stride, int C,
+                    dfd_stream stream);
+int dfd_avgpool_bwd(int dtype, const void* g, void* dx, int N, int H, int W, int k, int stride, int C,
+                    dfd_stream stream);
+/* PosEmbMLPSwinv2D: full [H][S][S], S = n_local + n_global: 16*sigmoid(table[idx[i*n_local+j]][h]) in the local
+ * block, zeros in the first n_global rows / columns; table f32 [T][H]; backward through the sigmoid into dtable  */
+int dfd_relpos_bias_fwd(const float* table, const int* idx, float* full, int H, int n_local, int n_global,
+                        dfd_stream stream);
+int dfd_relpos_bias_bwd(const float* dfull, const float* table, const int* idx, float* dtable, int H, int T,
+                        int n_local, int n_global, dfd_stream stream);
+
 /* ---------------------------------------------------------------- bookkeeping ---
  * Small kernels that keep ATen off the model path (drop-connect / dropout randoms, counters, scaling).        */
 /* out = (a_dev ? a*a_dev[0] : a) * x + b * y   (y may be NULL), f32                                           */

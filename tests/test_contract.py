@@ -172,8 +172,11 @@ def test_registry_lookup_semantics():
     with pytest.raises(KeyError) as err:
         reg.get_model_spec("resnet50")
     assert err.value.args[0] == "Unknown model 'resnet50'. Add it to model_registry.py."
+    fv = pre.builder("faster_vit_0_224", 2)
+    assert fv.head.in_features == 512 and fv.head.out_features == 2           # trainers/fastervit.py:372-373 swaps model.head
+    assert reg.get_model_spec("faster_vit_2_224").builder("faster_vit_2_224", 2).head.in_features == 768
     with pytest.raises(NotImplementedError):
-        pre.builder("faster_vit_0_224", 2)
+        reg.get_model_spec("faster_vit_4_21k_224").builder("faster_vit_4_21k_224", 2)   # registered prefix, no engine: loud
 
 
 def test_builders_return_modules_with_reference_surface():

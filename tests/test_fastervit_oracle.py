@@ -1,0 +1,96 @@
+"""CPU checks of the FasterViT oracle (oracle/fastervit_ref.py) and of the host side of its HIP module.
+
+The `fastervit` package (requirements.txt:16) is absent, so the oracle is a restatement; pinned here by the published
+parameter counts of four variants (31.4 / 53.4 / 75.9 / 159.5 M), the head widths the reference's trainer relies on,
+the state-dict key grammar, and identities of the token bookkeeping.
+"""
+
+from __future__ import annotations
+
+import pytest
+import torch
+
+from oracle.fastervit_ref import FasterViTRef, PosEmb2D, ct_dewindow, ct_window, window_partition, window_reverse
+
+PUBLISHED = {"0": (31_404_840, 31.4, 512), "1": (53_366_696, 53.4, 640), "2": (75_923_816, 75.9, 768), "3": (159_547_944, 159.5, 1024)}
+
+
+def _count(m):
+    seen, n = set(), 0
+    for p in m.parameters():
+        if id(p) not in seen:
+            seen.add(id(p))
+            n += p.numel()
+    return n
+
+
+@pytest.mark.parametrize("variant", sorted(PUBLISHED))
+def test_parameter_counts_match_the_published_table(variant):
+    exact, millions, head = PUBLISHED[variant]
+    m = FasterViTRef(variant, 1000)
+    n = _count(m)
+    assert n == exact and round(n / 1e6, 1) == millions
+    assert m.head.in_features == head                      # trainers/fastervit.py:372 reads model.head.in_features
+
+
+def test_key_grammar():
+    keys = set(FasterViTRef("2", 2).state_dict())
+    for k in ("patch_embed.conv_down.0.weight", "patch_embed.conv_down.4.running_var", "levels.0.blocks.2.conv1.bias",
+              "levels.0.blocks.0.norm2.weight", "levels.1.downsample.norm.weight", "levels.1.downsample.reduction.0.weight",
+              "levels.2.global_tokenizer.pos_embed.weight", "levels.2.global_tokenizer.to_global_feature.pos.weight",
+              "levels.2.blocks.7.hat_attn.qkv.weight", "levels.2.blocks.0.hat_pos_embed.cpb_mlp.0.weight",
+              "levels.2.blocks.0.attn.pos_emb_funct.cpb_mlp.2.weight", "levels.2.blocks.0.attn.pos_emb_funct.relative_position_index",
+              "levels.3.blocks.4.mlp.fc2.bias", "norm.running_mean", "head.weight", "head.bias"):
+        assert k in keys, k
+    assert "levels.3.blocks.0.hat_attn.qkv.weight" not in keys          # hierarchical attention on level 2 only
+    assert "levels.0.blocks.0.gamma" not in keys                        # no layer scale below faster_vit_3
+    names = [n for n, _ in FasterViTRef("2", 2).named_parameters()]
+    assert [n for n in names if "head" in n] == ["head.weight", "head.bias"]      # warm-up set (trainers/fastervit.py:400-402)
+
+
+def test_token_bookkeeping_identities():
+    x = torch.randn(2, 5, 14, 14)
+    w = window_partition(x, 7)
+    assert w.shape == (8, 49, 5)
+    assert torch.equal(window_reverse(w, 7, 14, 14), x)
+    assert torch.equal(w[1, 3], x[0, :, 0, 7 + 3])                       # window (0, 1), token (0, 3)
+    ct = torch.randn(2, 16, 5)
+    rm = ct_dewindow(ct, 4, 4, 2)
+    assert torch.equal(ct_window(rm, 4, 4, 2).reshape(2, 16, 5), ct)
+    assert torch.equal(rm[0, 1 * 4 + 2], ct[0, (0 * 2 + 1) * 4 + 1 * 2 + 0])      # (y=1, x=2) lives in window (0, 1), slot (1, 0)
+
+
+def test_attention_bias_against_a_loop():
+    torch.manual_seed(0)
+    pe = PosEmb2D(7, 4, 53)
+    b = pe.bias(53)[0]
+    assert b.shape == (4, 53, 53)
+    assert float(b[:, :4].abs().max()) == 0.0 and float(b[:, :, :4].abs().max()) == 0.0
+    tab = pe.cpb_mlp(pe.relative_coords_table).view(13, 13, 4)
+    for (i, j) in ((0, 0), (5, 37), (48, 0), (20, 21)):
+        yi, xi, yj, xj = i // 7, i % 7, j // 7, j % 7
+        want = 16 * torch.sigmoid(tab[yi - yj + 6, xi - xj + 6])
+        assert torch.allclose(b[:, 4 + i, 4 + j], want, atol=1e-6)
+    # log-spaced coordinates (Swin-v2): sign(x) * log2(|8x| + 1) / log2(8) with x in [-1, 1] -> +-log2(9)/3 at the extremes
+    import math
+
+    t = pe.relative_coords_table[0]
+    edge = math.log2(9.0) / 3.0
+    assert abs(float(t[12, 12, 0]) - edge) < 1e-6 and abs(float(t[0, 0, 1]) + edge) < 1e-6 and float(t[6, 6].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("variant", ["0", "2"])
+def test_hip_module_has_the_oracles_state_dict(variant):
+    from deepfakedetection_amd.fastervit import HipFasterViT, _window_maps
+
+    ref, hip = FasterViTRef(variant, 3), HipFasterViT(variant, 3)
+    a, b = ref.state_dict(), hip.state_dict()
+    assert list(a) == list(b) and all(a[k].shape == b[k].shape for k in a)
+    hip.load_state_dict(a, strict=True)
+    assert _count(hip) == _count(ref)
+    part, src_ct, dst_ct, dst_x = _window_maps(2, 14, torch.device("cpu"))
+    x = torch.randn(2, 14, 14, 5)
+    assert torch.equal(x.reshape(-1, 5)[part.long()].view(8, 49, 5), window_partition(x.permute(0, 3, 1, 2), 7))
+    assert sorted(torch.cat([dst_ct, dst_x]).tolist()) == list(range(8 * 53))       # the concatenation covers every row once
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        hip(torch.zeros(1, 3, 224, 224))

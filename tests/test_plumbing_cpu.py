@@ -163,15 +163,17 @@ def test_reference_train_yaml_fails_loudly_for_the_engine_that_is_not_built(work
         spec = reg.get_model_spec(key)
         assert hasattr(importlib.import_module(spec.train_module), "main")
     cfg = yaml.safe_load(_config(workspace, training={"epochs": 1, "batch_size": 6, "num_workers": 0, "pretrained": False}).read_text())
-    cfg["models"] = {"faster_vit_2_224": dict(cfg["models"]["tinynet_stub"])}
-    cfg["selection"] = ["faster_vit_2_224"]
+    # every model of the reference's YAMLs now has an engine; a name under a registered prefix without one still
+    # stops with the registry's message
+    name = "faster_vit_4_21k_224"
+    cfg["models"] = {name: dict(cfg["models"]["tinynet_stub"])}
+    cfg["selection"] = [name]
     path = workspace / "fv.yaml"
     path.write_text(yaml.safe_dump(cfg))
-    try:
-        reg.get_model_spec("faster_vit_2_224").builder("faster_vit_2_224", 3)
-    except NotImplementedError:
-        with pytest.raises(NotImplementedError, match="registered but its MI355X engine is not built"):
-            orchestrate(path, mode="training")
+    with pytest.raises(NotImplementedError, match="registered but its MI355X engine is not built"):
+        orchestrate(path, mode="training")
+    for key, cls in (("faster_vit_2_224", "HipFasterViT"), ("faster_vit_0_224", "HipFasterViT"), ("efficientformerv2_s1", "HipEfficientFormerV2")):
+        assert type(reg.get_model_spec(key).builder(key, 2)).__name__ == cls
 
 
 def test_class_count_mismatch_exits(workspace):

@@ -19,13 +19,15 @@ pytestmark = pytest.mark.gpu
 @pytest.mark.parametrize("model_name,weights_file,gpu_tail", [("efficientnet_b0", "EfficientNetModel.pth", False),
                                                              ("efficientnet_b3", "EfficientNetModel.pth", False),
                                                              ("efficientnet_b0", "EfficientNetModel.pth", True),
-                                                             ("efficientformerv2_s1", "EfficientFormerV2_S1.pth", False)])
+                                                             ("efficientformerv2_s1", "EfficientFormerV2_S1.pth", False),
+                                                             ("faster_vit_0_224", "FasterVitModel.pth", False)])
 def test_orchestrated_training_and_inference_on_gpu(tmp_path, monkeypatch, model_name, weights_file, gpu_tail):
     from deepfakedetection_amd.orchestration.orchestrator import orchestrate
 
     monkeypatch.chdir(tmp_path)
     former = model_name.startswith("efficientformer")
-    img = 128 if former else 64                 # 128 px: 16-token attention windows in stages 2 and 3
+    fvit = model_name.startswith("faster_vit")
+    img = 224 if fvit else (128 if former else 64)   # EfficientFormerV2 at 128 px: 16-token attention; FasterViT: 7x7 windows need 224
     _make_dataset(tmp_path / "data", classes=("fake", "real"), per_class=8, size=img + 8)
     base = {
         "seed": 1, "device": "cuda",
@@ -42,7 +44,7 @@ def test_orchestrated_training_and_inference_on_gpu(tmp_path, monkeypatch, model
     run = sorted(Path(out_dir).iterdir())[0]
     ckpt = torch.load(run / "checkpoints" / "latest.ckpt", map_location="cpu")
     assert ckpt["epoch"] == 1 and set(ckpt["optimizer"]["state"][0]) == {"step", "exp_avg", "exp_avg_sq"}
-    head_key = "head_dist.weight" if former else ("_fc.weight" if model_name == "efficientnet_b3" else "classifier.weight")
+    head_key = "head_dist.weight" if former else ("head.weight" if fvit else ("_fc.weight" if model_name == "efficientnet_b3" else "classifier.weight"))
     assert head_key in ckpt["model"]
     log = (run / "logs" / "train.log").read_text()
     assert "Warmup (head only)" in log and "val_acc=" in log
