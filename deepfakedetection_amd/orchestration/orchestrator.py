@@ -162,7 +162,8 @@ _DATA_ENV = (("train_split", "TRAIN_SPLIT"), ("val_split", "VAL_SPLIT"), ("test_
 _TRAIN_ENV = (("batch_size", "BATCH_SIZE"), ("epochs", "EPOCHS"), ("num_workers", "NUM_WORKERS"), ("lr", "LR"),
               ("weight_decay", "WEIGHT_DECAY"), ("accum_steps", "ACCUM_STEPS"), ("warmup_epochs", "WARMUP_EPOCHS"),
               ("early_stop_patience", "EARLY_STOP_PATIENCE"))
-_EXTRA_TRAIN_ENV = (("ft_batch_size", "FT_BATCH_SIZE"), ("pretrained", "PRETRAINED"), ("gpu_input_tail", "GPU_INPUT_TAIL"))
+_EXTRA_TRAIN_ENV = (("ft_batch_size", "FT_BATCH_SIZE"), ("pretrained", "PRETRAINED"), ("gpu_input_tail", "GPU_INPUT_TAIL"),
+                    ("graph_step", "GRAPH_STEP"))
 
 
 def _first_set(*values: Any) -> Any:

@@ -93,7 +93,8 @@ def evaluate(model: nn.Module, dl: DataLoader, device: str, tail=None) -> EvalRe
 
 def train_one_epoch(model: nn.Module, dl: DataLoader, opt: optim.Optimizer, scaler, criterion: nn.Module, device: str, *,
                     use_cuda_amp: bool, progress: Progress, task: TaskID, accum_steps: int = 1, zero_grad_first: bool = False,
-                    reducer: GradAllReducer | None = None, tail=None, label: str = "train", ips_in_extra: bool = False) -> dict:
+                    reducer: GradAllReducer | None = None, tail=None, label: str = "train", ips_in_extra: bool = False,
+                    stepper=None) -> dict:
     """One epoch (efficientformer_v2.py:222-257; fastervit.py:243-300 when accum_steps > 1).  Returns throughput
     figures for logs/throughput.jsonl."""
     model.train()
@@ -105,24 +106,32 @@ def train_one_epoch(model: nn.Module, dl: DataLoader, opt: optim.Optimizer, scal
     for i, (batch_x, batch_y) in enumerate(dl, 1):
         inputs = _base._to_device(batch_x, device, tail)
         targets = batch_y.to(device, non_blocking=True)
-        if zero_grad_first:
-            opt.zero_grad(set_to_none=True)
-        with torch.autocast(device_type="cuda", dtype=torch.bfloat16, enabled=use_cuda_amp):
-            loss = criterion(model(inputs), targets)
-            if accum_steps > 1:
-                loss = loss / accum_steps
-        if reducer is not None and pending + 1 == accum_steps:
-            reducer.arm()
-        scaler.scale(loss).backward()
-        pending += 1
-        if pending == accum_steps:
-            if reducer is not None:
-                reducer.finish()
-            scaler.step(opt)
-            scaler.update()
-            if not zero_grad_first:
+        if stepper is not None:
+            # hipGraph replay of the same body; zero_grad belongs to the first micro-batch of a cycle either way
+            loss = stepper.micro_batch(inputs, targets, first=pending == 0)
+            pending += 1
+            if pending == accum_steps:
+                stepper.optimizer_step()
+                pending = 0
+        else:
+            if zero_grad_first:
                 opt.zero_grad(set_to_none=True)
-            pending = 0
+            with torch.autocast(device_type="cuda", dtype=torch.bfloat16, enabled=use_cuda_amp):
+                loss = criterion(model(inputs), targets)
+                if accum_steps > 1:
+                    loss = loss / accum_steps
+            if reducer is not None and pending + 1 == accum_steps:
+                reducer.arm()
+            scaler.scale(loss).backward()
+            pending += 1
+            if pending == accum_steps:
+                if reducer is not None:
+                    reducer.finish()
+                scaler.step(opt)
+                scaler.update()
+                if not zero_grad_first:
+                    opt.zero_grad(set_to_none=True)
+                pending = 0
         bsz = targets.size(0)
         seen_total += bsz
         if i % LOG_EVERY == 0 or i == len(dl):
@@ -134,15 +143,19 @@ def train_one_epoch(model: nn.Module, dl: DataLoader, opt: optim.Optimizer, scal
         else:
             progress.update(task, advance=1, description=f"{label} | loss={shown:.4f} | {ips:.0f} img/s")
     if pending > 0:
-        if reducer is not None:
-            reducer.finish()
-        scaler.step(opt)
-        scaler.update()
+        if stepper is not None:
+            stepper.optimizer_step()
+        else:
+            if reducer is not None:
+                reducer.finish()
+            scaler.step(opt)
+            scaler.update()
         opt.zero_grad(set_to_none=True)
     if str(device).startswith("cuda"):
         torch.cuda.synchronize()
     seconds = perf_counter() - start
-    return {"images": seen_total, "seconds": seconds, "images_per_sec": seen_total / max(1e-9, seconds)}
+    return {"images": seen_total, "seconds": seconds, "images_per_sec": seen_total / max(1e-9, seconds),
+            "launch": "hipgraph" if (stepper is not None and stepper.replays > 0 and not stepper.failed) else "eager"}
 
 
 def log_throughput(env, chief: bool, world: int, **record) -> None:
@@ -237,7 +250,8 @@ def run(spec: TrainerSpec) -> None:  # noqa: PLR0915
             # train_one_epoch with zero_grad first, no accumulation and the rate in the `extra` column
             stats = train_one_epoch(model, train_dl, warm_opt, scaler, criterion, device, use_cuda_amp=use_cuda, progress=progress,
                                     task=task, accum_steps=1, zero_grad_first=True, reducer=reducer, tail=train_tail,
-                                    label="warmup", ips_in_extra=True)
+                                    label="warmup", ips_in_extra=True,
+                                    stepper=_base.make_stepper(model, criterion, warm_opt, accum_steps=1, use_cuda=use_cuda, world=world))
             log_throughput(env, chief, world, phase="warmup", epoch=0, model=model_name, batch_size=batch_size, **stats)
             if reducer is not None:
                 reducer.detach()
@@ -263,6 +277,7 @@ def run(spec: TrainerSpec) -> None:  # noqa: PLR0915
         if reducer is not None:
             reducer.attach()
         scheduler = optim.lr_scheduler.CosineAnnealingLR(opt, T_max=max(1, epochs - 1))
+        stepper = _base.make_stepper(model, criterion, opt, accum_steps=accum, use_cuda=use_cuda, world=world)
         start_epoch = 0
         resume_state = maybe_load_checkpoint(env, model=model, optimizer=opt, scheduler=scheduler)
         if resume_state is not None:
@@ -278,7 +293,8 @@ def run(spec: TrainerSpec) -> None:  # noqa: PLR0915
                 ft_dl.sampler.set_epoch(epoch)
             task = progress.add_task(f"epoch {epoch}", total=len(ft_dl), extra="")
             stats = train_one_epoch(model, ft_dl, opt, scaler, criterion, device, use_cuda_amp=use_cuda, progress=progress, task=task,
-                                    accum_steps=accum, zero_grad_first=spec.zero_grad_first, reducer=reducer, tail=train_tail)
+                                    accum_steps=accum, zero_grad_first=spec.zero_grad_first, reducer=reducer, tail=train_tail,
+                                    stepper=stepper)
             log_throughput(env, chief, world, phase="fine-tune", epoch=epoch, model=model_name,
                            batch_size=ft_dl.batch_size, accum_steps=accum, **stats)
             scheduler.step()

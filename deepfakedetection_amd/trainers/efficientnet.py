@@ -205,10 +205,23 @@ def evaluate(model: nn.Module, dl: DataLoader, device: str, criterion: nn.Module
     return EvalResult(acc=n_correct / max(1, n_total), loss=s_loss / max(1, n_total), total=int(n_total), correct=int(n_correct))
 
 
+def make_stepper(model: nn.Module, criterion: nn.Module, opt, *, accum_steps: int, use_cuda: bool, world: int):
+    """hipGraph replay of the loop body ($GRAPH_STEP, YAML training.graph_step; default on): one rank on a HIP device
+    with the HIP optimizer.  Otherwise None: the loop runs eagerly as the reference's does."""
+    if not use_cuda or world > 1 or getattr(opt, "arena", None) is None:
+        return None
+    if env_str("GRAPH_STEP", "1").lower() in {"0", "false", "no", "off"}:
+        return None
+    from ..graph_step import GraphedTrainStep
+
+    return GraphedTrainStep(model, criterion, opt, accum_steps=accum_steps, use_amp=True)
+
+
 def train_one_epoch(model: nn.Module, dl: DataLoader, opt: optim.Optimizer, scaler, criterion: nn.Module, device: str, *,
                     use_cuda_amp: bool, progress: Progress, task: TaskID, accum_steps: int = 1,
-                    reducer: GradAllReducer | None = None, tail=None) -> float:
-    """One epoch; returns the mean training loss (reference :265-333)."""
+                    reducer: GradAllReducer | None = None, tail=None, stepper=None, stats: dict | None = None) -> float:
+    """One epoch; returns the mean training loss (reference :265-333).  `stepper` (graph_step.GraphedTrainStep)
+    replays the captured loop body instead of dispatching it; `stats` receives throughput figures."""
     model.train()
     start = perf_counter()
     opt.zero_grad(set_to_none=True)
@@ -218,21 +231,28 @@ def train_one_epoch(model: nn.Module, dl: DataLoader, opt: optim.Optimizer, scal
     for i, (batch_x, batch_y) in enumerate(dl, 1):
         inputs = _to_device(batch_x, device, tail)
         targets = batch_y.to(device, non_blocking=True)
-        with torch.autocast(device_type="cuda", dtype=torch.bfloat16, enabled=use_cuda_amp):
-            loss = criterion(model(inputs), targets)
-            if accum_steps > 1:
-                loss = loss / accum_steps
-        if reducer is not None and pending + 1 == accum_steps:
-            reducer.arm()                   # this backward completes the step: buckets leave as they fill
-        scaler.scale(loss).backward()
-        pending += 1
-        if pending == accum_steps:
-            if reducer is not None:
-                reducer.finish()
-            scaler.step(opt)
-            scaler.update()
-            opt.zero_grad(set_to_none=True)
-            pending = 0
+        if stepper is not None:
+            loss = stepper.micro_batch(inputs, targets, first=pending == 0)      # zero_grad is part of the "first" body
+            pending += 1
+            if pending == accum_steps:
+                stepper.optimizer_step()
+                pending = 0
+        else:
+            with torch.autocast(device_type="cuda", dtype=torch.bfloat16, enabled=use_cuda_amp):
+                loss = criterion(model(inputs), targets)
+                if accum_steps > 1:
+                    loss = loss / accum_steps
+            if reducer is not None and pending + 1 == accum_steps:
+                reducer.arm()                   # this backward completes the step: buckets leave as they fill
+            scaler.scale(loss).backward()
+            pending += 1
+            if pending == accum_steps:
+                if reducer is not None:
+                    reducer.finish()
+                scaler.step(opt)
+                scaler.update()
+                opt.zero_grad(set_to_none=True)
+                pending = 0
         bsz = targets.size(0)
         seen_total += bsz
         loss_sum += loss.detach().double() * (bsz * max(1, accum_steps))
@@ -242,11 +262,20 @@ def train_one_epoch(model: nn.Module, dl: DataLoader, opt: optim.Optimizer, scal
         ips = seen / max(1e-6, perf_counter() - start)
         progress.update(task, advance=1, description=f"train | loss={shown:.4f} | {ips:.0f} img/s")
     if pending > 0:
-        if reducer is not None:
-            reducer.finish()
-        scaler.step(opt)
-        scaler.update()
+        if stepper is not None:
+            stepper.optimizer_step()
+        else:
+            if reducer is not None:
+                reducer.finish()
+            scaler.step(opt)
+            scaler.update()
         opt.zero_grad(set_to_none=True)
+    if stats is not None:
+        if str(device).startswith("cuda"):
+            torch.cuda.synchronize()
+        seconds = perf_counter() - start
+        stats.update(images=seen_total, seconds=seconds, images_per_sec=seen_total / max(1e-9, seconds),
+                     launch="hipgraph" if (stepper is not None and stepper.replays > 0 and not stepper.failed) else "eager")
     (total_loss,) = all_reduce_counts(float(loss_sum), device=device)
     (total_seen,) = all_reduce_counts(float(seen_total), device=device)
     return total_loss / max(1.0, total_seen)
@@ -270,6 +299,21 @@ def _load_pretrained(model: nn.Module, name: str) -> None:
             console.print(f"[bold green]Loaded pretrained weights[/] {path} ({len(usable)}/{len(own)} tensors)")
             return
     console.print("[bold yellow]⚠️  No local pretrained weights[/] (set training.pretrained); starting from random init")
+
+
+def _log_throughput(env, chief: bool, world: int, **record) -> None:
+    """One JSON line per phase in OUTPUT_DIR/logs/throughput.jsonl: the machine-readable twin of the progress bar's
+    `img/s` (reference :317-325)."""
+    if not chief or "images_per_sec" not in record:
+        return
+    import json
+    from time import time
+
+    path = Path(env.logs_dir) / "throughput.jsonl"
+    path.parent.mkdir(parents=True, exist_ok=True)
+    record = {"timestamp": time(), "n_gpus": world, **record, "images_per_sec_all_ranks": record["images_per_sec"] * world}
+    with path.open("a", encoding="utf-8") as fh:
+        fh.write(json.dumps(record) + "\n")
 
 
 def _make_criterion_and_optimizer(use_cuda: bool):
@@ -357,8 +401,11 @@ def main() -> None:  # noqa: PLR0915
                 reducer.attach()
             task = progress.add_task("warmup (head only)", total=len(train_dl), extra="")
             console.print("[bold]Warmup (head only)[/]")
+            stats: dict = {}
             train_one_epoch(model, train_dl, warm_opt, scaler, criterion, device, use_cuda_amp=use_cuda, progress=progress,
-                            task=task, accum_steps=1, reducer=reducer, tail=train_tail)
+                            task=task, accum_steps=1, reducer=reducer, tail=train_tail, stats=stats,
+                            stepper=make_stepper(model, criterion, warm_opt, accum_steps=1, use_cuda=use_cuda, world=world))
+            _log_throughput(env, chief, world, phase="warmup", epoch=0, model=model_name, batch_size=batch_size, **stats)
             if reducer is not None:
                 reducer.detach()
             res = evaluate(model, val_dl, device, criterion, val_tail)
@@ -378,6 +425,7 @@ def main() -> None:  # noqa: PLR0915
         if reducer is not None:
             reducer.attach()
         scheduler = optim.lr_scheduler.CosineAnnealingLR(opt, T_max=max(1, epochs - 1))
+        stepper = make_stepper(model, criterion, opt, accum_steps=accum_steps, use_cuda=use_cuda, world=world)
         start_epoch = 0
         resume_state = maybe_load_checkpoint(env, model=model, optimizer=opt, scheduler=scheduler)
         if resume_state is not None:
@@ -392,9 +440,12 @@ def main() -> None:  # noqa: PLR0915
             if hasattr(train_dl_ft.sampler, "set_epoch"):
                 train_dl_ft.sampler.set_epoch(epoch)
             task = progress.add_task(f"epoch {epoch}", total=len(train_dl_ft), extra="")
+            stats = {}
             train_loss = train_one_epoch(model, train_dl_ft, opt, scaler, criterion, device, use_cuda_amp=use_cuda,
                                          progress=progress, task=task, accum_steps=accum_steps, reducer=reducer,
-                                         tail=train_tail)
+                                         tail=train_tail, stepper=stepper, stats=stats)
+            _log_throughput(env, chief, world, phase="fine-tune", epoch=epoch, model=model_name, batch_size=ft_batch,
+                            accum_steps=accum_steps, **stats)
             scheduler.step()
             res = evaluate(model, val_dl, device, criterion, val_tail)
             console.print(f"[bold cyan]epoch {epoch}[/] | train_loss={train_loss:.4f} | val_loss={res.loss:.4f} | "

@@ -65,3 +65,42 @@ def test_orchestrated_training_and_inference_on_gpu(tmp_path, monkeypatch, model
     row = json.loads((run2 / "logs" / "metrics.jsonl").read_text().splitlines()[0])
     assert row["model"] == model_name and 0.0 <= row["accuracy"] <= 1.0 and "threshold" in row
     assert sum(map(sum, row["confusion_matrix"])) == 16
+
+
+@pytest.mark.parametrize("accum", [1, 3])
+def test_graphed_step_is_bitwise_the_eager_step(accum):
+    """graph_step.GraphedTrainStep replays exactly the kernels the eager loop body launches (same order, same
+    fixed-order reductions, Philox masks from the same device-resident state): after several optimizer cycles the
+    parameters, BatchNorm statistics and counters are bit-identical, also across an epoch boundary where the trainer
+    drops the gradients (zero_grad(set_to_none=True))."""
+    from deepfakedetection_amd.efficientnet import HipEfficientNet
+    from deepfakedetection_amd.graph_step import GraphedTrainStep
+    from deepfakedetection_amd.optim import HipAdamW, HipCrossEntropyLoss
+
+    g = torch.Generator().manual_seed(3)
+    batches = [(torch.randn(8, 3, 64, 64, generator=g).cuda(), torch.randint(0, 2, (8,), generator=g).cuda()) for _ in range(5 * accum)]
+
+    def run(graph: bool):
+        torch.manual_seed(11)
+        model = HipEfficientNet("b0", "timm", 2).cuda().train()
+        opt = HipAdamW(model.parameters(), lr=1e-3, weight_decay=5e-2)
+        step = GraphedTrainStep(model, HipCrossEntropyLoss(0.1), opt, accum_steps=accum)
+        if not graph:
+            step.failed = True                              # the object's own eager path
+        losses = []
+        for i, (x, y) in enumerate(batches):
+            if i == 3 * accum:
+                opt.zero_grad(set_to_none=True)              # what train_one_epoch does at the start of an epoch
+            losses.append(step.micro_batch(x, y, first=i % accum == 0).clone())
+            if (i + 1) % accum == 0:
+                step.optimizer_step()
+        torch.cuda.synchronize()
+        return model, torch.stack(losses).cpu(), step
+
+    m_e, l_e, _ = run(False)
+    m_g, l_g, step = run(True)
+    assert step.replays >= 4 * accum - accum and not step.failed and step.step_graph is not None
+    assert torch.equal(l_e, l_g), (l_e, l_g)
+    for (n1, a), (_, b) in zip(m_e.state_dict().items(), m_g.state_dict().items()):
+        assert torch.equal(a, b), n1
+    assert float((m_e.conv_stem.weight - HipEfficientNet("b0", "timm", 2).conv_stem.weight.cuda()).abs().max()) > 0   # it trained
