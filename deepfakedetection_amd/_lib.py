@@ -93,7 +93,7 @@ SIGNATURES: dict[str, tuple] = {
     "dfd_channel_stats": (c_int, [c_int, P, c_long, c_int, P, c_int, _PI, P]),
     "dfd_sum_rows": (c_int, [P, c_int, c_long, P, c_int, P]),
     "dfd_up2_act_fwd": (c_int, [c_int, P, c_int, P, c_int, c_int, c_int, c_int, P]),
-    "dfd_up2_act_bwd": (c_int, [c_int, P, P, c_int, P, c_int, c_int, c_int, c_int, P]),
+    "dfd_up2_act_bwd": (c_int, [c_int, P, P, c_int, P, c_int, c_int, c_int, c_int, P, P]),
     "dfd_subsample_add": (c_int, [c_int, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
     "dfd_subsample_add_bwd": (c_int, [c_int, P, P, c_int, c_int, c_int, c_int, c_int, P]),
     "dfd_bgemm": (c_int, [c_int, P, POINTER(Mat), c_int, P, POINTER(Mat), c_int, P, POINTER(Mat), P, c_float, c_int, c_int,

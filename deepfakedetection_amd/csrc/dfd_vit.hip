@@ -372,6 +372,28 @@ k_up2_act_fwd(const T* __restrict__ s, T* __restrict__ out, int N, int h, int w,
         Vec<T>::store(out + i * V, u);
     }
 }
+// pass 1 of the backward (optional, needs a workspace the size of g): gq[Y][X] = g[Y][X] * act'(up(s)[Y][X]); pass 2 is then
+// the activation-free transposed interpolation of gq.  One activation derivative per OUTPUT element instead of one per tap.
+template <typename T, int ACT>
+__global__ void __launch_bounds__(DFD_THREADS)
+k_up2_act_grad(const T* __restrict__ g, const T* __restrict__ s, T* __restrict__ gq, int N, int h, int w, int C) {
+    constexpr int V = Vec<T>::N;
+    const int CV = C / V, H2 = 2 * h, W2 = 2 * w;
+    const long total = (long)N * H2 * W2 * CV;
+    for (long i = (long)blockIdx.x * DFD_THREADS + threadIdx.x; i < total; i += (long)gridDim.x * DFD_THREADS) {
+        const int cv = (int)(i % CV);
+        long tq = i / CV;
+        const int X = (int)(tq % W2); tq /= W2;
+        const int Y = (int)(tq % H2);
+        const long n = tq / H2;
+        float u[V], gv[V];
+        up2_sample<T>(s + n * h * w * (long)C, h, w, C, cv * V, Y, X, u);
+        Vec<T>::load(g + i * V, gv);
+#pragma unroll
+        for (int j = 0; j < V; ++j) gv[j] *= act_grad<ACT>(u[j]);
+        Vec<T>::store(gq + i * V, gv);
+    }
+}
 // ds[m][k] = sum over the (at most 4x4) outputs (Y, X) that read s[m][k]:  wy * wx * g[Y][X] * act'(up(s)[Y][X])
 template <typename T, int ACT>
 __global__ void __launch_bounds__(DFD_THREADS)
@@ -418,10 +440,19 @@ k_up2_act_bwd(const T* __restrict__ g, const T* __restrict__ s, T* __restrict__ 
     }
 }
 template <typename T>
-static int up2_t(bool bwd, const void* a, const void* s, int act, void* out, int N, int h, int w, int C, hipStream_t st) {
+static int up2_t(bool bwd, const void* a, const void* s, int act, void* out, int N, int h, int w, int C, hipStream_t st, void* ws = nullptr) {
     const long tot = (long)N * h * w * (C / Vec<T>::N) * (bwd ? 1 : 4);
     long grid = (tot + DFD_THREADS - 1) / DFD_THREADS;
     if (grid > 16384) grid = 16384;
+    if (bwd && ws && act != DFD_ACT_NONE) {
+        long grid4 = (tot * 4 + DFD_THREADS - 1) / DFD_THREADS;
+        if (grid4 > 16384) grid4 = 16384;
+        DISPATCH_ACT(act, {
+            hipLaunchKernelGGL((k_up2_act_grad<T, ACT>), dim3((unsigned)grid4), dim3(DFD_THREADS), 0, st, (const T*)a, (const T*)s, (T*)ws, N, h, w, C);
+        });
+        hipLaunchKernelGGL((k_up2_act_bwd<T, DFD_ACT_NONE>), dim3((unsigned)grid), dim3(DFD_THREADS), 0, st, (const T*)ws, (const T*)s, (T*)out, N, h, w, C);
+        return DFD_CHECK_LAUNCH();
+    }
     DISPATCH_ACT(act, {
         if (bwd) hipLaunchKernelGGL((k_up2_act_bwd<T, ACT>), dim3((unsigned)grid), dim3(DFD_THREADS), 0, st, (const T*)a, (const T*)s, (T*)out, N, h, w, C);
         else hipLaunchKernelGGL((k_up2_act_fwd<T, ACT>), dim3((unsigned)grid), dim3(DFD_THREADS), 0, st, (const T*)s, (T*)out, N, h, w, C);
@@ -434,11 +465,11 @@ extern "C" int dfd_up2_act_fwd(int dtype, const void* s, int act, void* out, int
     if (dtype == DFD_F32) return up2_t<float>(false, nullptr, s, act, out, N, h, w, C, (hipStream_t)stream);
     return DFD_EINVAL;
 }
-extern "C" int dfd_up2_act_bwd(int dtype, const void* g, const void* s, int act, void* ds, int N, int h, int w, int C,
+extern "C" int dfd_up2_act_bwd(int dtype, const void* g, const void* s, int act, void* ds, int N, int h, int w, int C, void* ws,
                                dfd_stream stream) {
     if (!g || !s || !ds || N < 1 || h < 1 || w < 1 || C < 8 || C % 8) return DFD_EINVAL;
-    if (dtype == DFD_BF16) return up2_t<bf16>(true, g, s, act, ds, N, h, w, C, (hipStream_t)stream);
-    if (dtype == DFD_F32) return up2_t<float>(true, g, s, act, ds, N, h, w, C, (hipStream_t)stream);
+    if (dtype == DFD_BF16) return up2_t<bf16>(true, g, s, act, ds, N, h, w, C, (hipStream_t)stream, ws);
+    if (dtype == DFD_F32) return up2_t<float>(true, g, s, act, ds, N, h, w, C, (hipStream_t)stream, ws);
     return DFD_EINVAL;
 }
 
@@ -524,44 +555,76 @@ template <> struct ElemIO<DFD_BF16> {
 };
 struct MatDesc { long sb, sh, sr, sc; };
 
+// 4x4 register tiles: LDS holds A transposed ([k][Mp]) and B ([k][Np]) with Mp, Np padded to multiples of 4 (pad = 0),
+// so a thread reads one float4 of each per k and does 16 FMAs; staging walks the operand's unit-stride dimension with
+// the 32 low lanes (no integer divisions anywhere).
+template <int DT>
+__device__ __forceinline__ void bg_stage(float* __restrict__ dst, int ld, const void* __restrict__ src, long base, long s_outer, long s_inner,
+                                         int n_outer, int n_inner, bool transpose, int round) {
+    // element (o, i) at base + o*s_outer + i*s_inner with i the fast (ideally unit-stride) index;
+    // stored at dst[o*ld + i] (transpose == false) or dst[i*ld + o] (transpose == true)
+    const int li = threadIdx.x & 31, lo = threadIdx.x >> 5;
+    for (int o = lo; o < n_outer; o += DFD_THREADS / 32)
+        for (int i = li; i < n_inner; i += 32) {
+            float v = ElemIO<DT>::ld(src, base + o * s_outer + i * s_inner);
+            if (round) v = bf2f(f2bf(v));
+            dst[transpose ? i * ld + o : o * ld + i] = v;
+        }
+}
 template <int DA, int DB, int DC>
 __global__ void __launch_bounds__(DFD_THREADS)
 k_bgemm(const void* __restrict__ A, MatDesc da, const void* __restrict__ B, MatDesc db, void* __restrict__ C, MatDesc dc,
         const float* __restrict__ bias, float alpha, int nh, int M, int N, int K, int round_a, int round_b) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    float* sa = sm;                 // [M][K+1]
-    float* sb = sm + (long)M * (K + 1);   // [K][N]
+    const int Mp = (M + 3) & ~3, Np = (N + 3) & ~3;
+    float* sa = sm;                       // [K][Mp]
+    float* sb = sm + (long)K * Mp;        // [K][Np]
     const int bh = blockIdx.x, b = bh / nh, h = bh - b * nh;
     const long a0 = (long)b * da.sb + (long)h * da.sh, b0 = (long)b * db.sb + (long)h * db.sh, c0 = (long)b * dc.sb + (long)h * dc.sh;
     const int t = threadIdx.x;
-    // stage A: walk the stride-1 dimension fastest
-    if (da.sc <= da.sr) {
-        for (int i = t; i < M * K; i += DFD_THREADS) { const int r = i / K, c = i - r * K; sa[r * (K + 1) + c] = ElemIO<DA>::ld(A, a0 + r * da.sr + c * da.sc); }
-    } else {
-        for (int i = t; i < M * K; i += DFD_THREADS) { const int c = i / M, r = i - c * M; sa[r * (K + 1) + c] = ElemIO<DA>::ld(A, a0 + r * da.sr + c * da.sc); }
-    }
-    if (db.sc <= db.sr) {
-        for (int i = t; i < K * N; i += DFD_THREADS) { const int r = i / N, c = i - r * N; sb[r * N + c] = ElemIO<DB>::ld(B, b0 + r * db.sr + c * db.sc); }
-    } else {
-        for (int i = t; i < K * N; i += DFD_THREADS) { const int c = i / K, r = i - c * K; sb[r * N + c] = ElemIO<DB>::ld(B, b0 + r * db.sr + c * db.sc); }
-    }
-    // an f32 intermediate that a bf16 pipeline would have stored in bf16 is rounded the same way here
-    if (round_a) for (int i = t; i < M * (K + 1); i += DFD_THREADS) sa[i] = bf2f(f2bf(sa[i]));
-    if (round_b) for (int i = t; i < K * N; i += DFD_THREADS) sb[i] = bf2f(f2bf(sb[i]));
+    // zero the pad columns (read as operands of discarded outputs only, but keep them finite)
+    for (int i = t; i < K * (Mp - M); i += DFD_THREADS) { const int k = i / (Mp - M); sa[k * Mp + M + (i - k * (Mp - M))] = 0.f; }
+    for (int i = t; i < K * (Np - N); i += DFD_THREADS) { const int k = i / (Np - N); sb[k * Np + N + (i - k * (Np - N))] = 0.f; }
+    // A is [m][k]: fast index = whichever has the smaller stride
+    if (da.sc <= da.sr) bg_stage<DA>(sa, Mp, A, a0, da.sr, da.sc, M, K, true, round_a);        // outer m, inner k -> sa[k][m]
+    else bg_stage<DA>(sa, Mp, A, a0, da.sc, da.sr, K, M, false, round_a);                     // outer k, inner m -> sa[k][m]
+    if (db.sc <= db.sr) bg_stage<DB>(sb, Np, B, b0, db.sr, db.sc, K, N, false, round_b);       // outer k, inner n -> sb[k][n]
+    else bg_stage<DB>(sb, Np, B, b0, db.sc, db.sr, N, K, true, round_b);                      // outer n, inner k -> sb[k][n]
     __syncthreads();
-    // walk C's stride-1 dimension fastest for the stores
-    const bool col_fast = dc.sc <= dc.sr;
-    for (int e = t; e < M * N; e += DFD_THREADS) {
-        int m, n;
-        if (col_fast) { m = e / N; n = e - m * N; } else { n = e / M; m = e - n * M; }
-        const float* ar = sa + m * (K + 1);
-        float s0 = 0.f, s1 = 0.f;
-        int k = 0;
-        for (; k + 1 < K; k += 2) { s0 = fmaf(ar[k], sb[k * N + n], s0); s1 = fmaf(ar[k + 1], sb[(k + 1) * N + n], s1); }
-        if (k < K) s0 = fmaf(ar[k], sb[k * N + n], s0);
-        float v = alpha * (s0 + s1);
-        if (bias) v += bias[((long)h * M + m) * N + n];
-        ElemIO<DC>::st(C, c0 + m * dc.sr + n * dc.sc, v);
+    const int tm = Mp >> 2, tn = Np >> 2;
+    const bool n_fast = dc.sc <= dc.sr;               // neighbouring threads along C's unit-stride dimension
+    for (int tile = t; tile < tm * tn; tile += DFD_THREADS) {
+        int im, in;
+        if (n_fast) { im = tile / tn; in = tile - im * tn; } else { in = tile / tm; im = tile - in * tm; }
+        float acc[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+        const float* pa = sa + 4 * im;
+        const float* pb = sb + 4 * in;
+        for (int k = 0; k < K; ++k) {
+            const float4 av = *reinterpret_cast<const float4*>(pa + k * Mp);
+            const float4 bv = *reinterpret_cast<const float4*>(pb + k * Np);
+            const float a4[4] = {av.x, av.y, av.z, av.w}, b4[4] = {bv.x, bv.y, bv.z, bv.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(a4[i], b4[j], acc[i][j]);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = 4 * im + i;
+            if (m >= M) continue;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int n = 4 * in + j;
+                if (n >= N) continue;
+                float v = alpha * acc[i][j];
+                if (bias) v += bias[((long)h * M + m) * N + n];
+                ElemIO<DC>::st(C, c0 + m * dc.sr + n * dc.sc, v);
+            }
+        }
     }
 }
 // long-K variant for tiny outputs (M, N <= 16: talking-head weight gradients, K = Nq*Nk): K is walked in
@@ -608,7 +671,7 @@ extern "C" int dfd_bgemm(int dt_a, const void* A, const dfd_mat* sa, int dt_b, c
                          void* C, const dfd_mat* sc, const float* bias, float alpha, int nb, int nh, int M, int N, int K,
                          int round_a, int round_b, dfd_stream stream) {
     if (!A || !B || !C || !sa || !sb || !sc || nb < 1 || nh < 1 || M < 1 || N < 1 || K < 1) return DFD_EINVAL;
-    const size_t lds = ((size_t)M * (K + 1) + (size_t)K * N) * 4;
+    const size_t lds = ((size_t)K * ((M + 3) & ~3) + (size_t)K * ((N + 3) & ~3)) * 4;
     const bool small = M <= 16 && N <= 16 && lds > 48 * 1024 && !round_a && !round_b;
     if (!small && lds > 150 * 1024) return DFD_EUNSUPPORTED;
     const MatDesc da{sa->sb, sa->sh, sa->sr, sa->sc}, db{sb->sb, sb->sh, sb->sr, sb->sc}, dc{sc->sb, sc->sh, sc->sr, sc->sc};

@@ -95,12 +95,12 @@ class HipAttention2d(nn.Module):
         self.register_buffer("attention_bias_idxs", idx, persistent=False)
         self.register_buffer("_idx32", idx.reshape(-1).to(torch.int32), persistent=False)
 
-    def run(self, x, ls: LayerScale2d, row_scale, training: bool, counters) -> torch.Tensor:
+    def run(self, x, ls: LayerScale2d, row_scale, training: bool, counters, derived=None) -> torch.Tensor:
         names = ([] if self.stride_conv is None else ["stride_conv"]) + ["q", "k", "v", "v_local", "proj"]
         mods = {nm: getattr(self, nm) for nm in names}
         flat = [t for nm in names for t in mods[nm].tensors()]
         geo = AttnGeom(self.heads, self.key_dim, self.d, self.N, self.N, self.key_dim ** -0.5)
-        cfg = AttentionCtx(geo, self.stride, {nm: _bnref(m.bn) for nm, m in mods.items()}, self._idx32, training, counters)
+        cfg = AttentionCtx(geo, self.stride, {nm: _bnref(m.bn) for nm, m in mods.items()}, self._idx32, training, counters, derived)
         return AttentionFunction.apply(x, cfg, *flat, self.talking_head1.weight, self.talking_head1.bias, self.talking_head2.weight,
                                        self.talking_head2.bias, self.attention_biases, ls.gamma, row_scale)
 
@@ -112,8 +112,8 @@ class HipConvMlp(nn.Module):
         self.mid = ConvNorm(hidden, hidden, 3, groups=hidden)
         self.fc2 = ConvNorm(hidden, dim, 1)
 
-    def run(self, x, ls: LayerScale2d, row_scale, training: bool, counters) -> torch.Tensor:
-        cfg = ConvMlpCtx(_bnref(self.fc1.bn), _bnref(self.mid.bn), _bnref(self.fc2.bn), training, counters)
+    def run(self, x, ls: LayerScale2d, row_scale, training: bool, counters, derived=None) -> torch.Tensor:
+        cfg = ConvMlpCtx(_bnref(self.fc1.bn), _bnref(self.mid.bn), _bnref(self.fc2.bn), training, counters, derived)
         return ConvMlpFunction.apply(x, *self.fc1.tensors(), *self.mid.tensors(), *self.fc2.tensors(), ls.gamma, row_scale, cfg)
 
 
@@ -136,10 +136,10 @@ class HipBlock(nn.Module):
             return None
         return rng.drop_path_scale(x.shape[0], 1.0 - self.drop_path, stream_id=2 * self.index + which)
 
-    def forward(self, x, rng=None, counters=None):
+    def forward(self, x, rng=None, counters=None, derived=None):
         if self.token_mixer is not None:
-            x = self.token_mixer.run(x, self.ls1, self._scale(x, rng, 0), self.training, counters)
-        return self.mlp.run(x, self.ls2, self._scale(x, rng, 1), self.training, counters)
+            x = self.token_mixer.run(x, self.ls1, self._scale(x, rng, 0), self.training, counters, derived)
+        return self.mlp.run(x, self.ls2, self._scale(x, rng, 1), self.training, counters, derived)
 
 
 class HipLocalGlobalQuery(nn.Module):
@@ -176,7 +176,7 @@ class HipDownsample(nn.Module):
         self.conv = ConvNorm(cin, cout, 3, 2)
         self.attn = HipAttention2dDownsample(cin, cout, resolution) if use_attn else None
 
-    def forward(self, x, counters=None):
+    def forward(self, x, counters=None, derived=None):
         flat = list(self.conv.tensors())
         if self.attn is None:
             cfg = DownsampleCtx(_bnref(self.conv.bn), self.training, counters)
@@ -189,7 +189,7 @@ class HipDownsample(nn.Module):
         flat.append(a.attention_biases)
         geo = AttnGeom(a.heads, a.key_dim, a.d, a.N2, a.N, a.key_dim ** -0.5)
         cfg = DownsampleCtx(_bnref(self.conv.bn), self.training, counters, True, geo, {nm: _bnref(m.bn) for nm, m in mods.items()},
-                            a._idx32)
+                            a._idx32, derived)
         return DownsampleFunction.apply(x, cfg, *flat)
 
 
@@ -208,11 +208,11 @@ class HipStage(nn.Module):
             HipBlock(dim, ratios[i], resolution, block_stride, block_attn and i >= first_attn, dprs[i], first_index + i)
             for i in range(depth)])
 
-    def forward(self, x, rng=None, counters=None):
+    def forward(self, x, rng=None, counters=None, derived=None):
         if not isinstance(self.downsample, nn.Identity):
-            x = self.downsample(x, counters)
+            x = self.downsample(x, counters, derived)
         for blk in self.blocks:
-            x = blk(x, rng, counters)
+            x = blk(x, rng, counters, derived)
         return x
 
 
@@ -285,9 +285,25 @@ class HipEfficientFormerV2(nn.Module):
         h = ConvStemFunction.apply(xh, *c1.tensors(), ConvStemCtx(2, 1, _bnref(c1.bn), dt, tr, ACT_GELU, counters))
         h = DenseConvBNFunction.apply(h, *c2.tensors(), DenseConvCtx(3, 2, _bnref(c2.bn), tr, ACT_GELU, counters))
         rng = self.rng(x.device) if tr else None
+        derived = self._derived_weights(dt)
         for stage in self.stages:
-            h = stage(h, rng, counters)
+            h = stage(h, rng, counters, derived)
         return h
+
+    def _derived_weights(self, dt: torch.dtype) -> dict:
+        """{weight.data_ptr(): (w_nk, w_kn)} for every 1x1 convolution of the network, refreshed by ONE batched launch per
+        forward pass (kernels.DerivedWeights); one cache entry per activation dtype, never freed by a train / eval switch
+        (a captured hipGraph holds raw pointers into it)."""
+        from . import kernels as K
+
+        weights = [m.conv.weight for m in self.modules() if isinstance(m, ConvNorm) and m.conv.kernel_size == (1, 1)]
+        caches = self.__dict__.setdefault("_derived_caches", {})
+        cache = caches.get(dt)
+        if cache is None or not cache.valid_for(weights, dt):
+            with torch.inference_mode(False):
+                cache = caches[dt] = K.DerivedWeights([(w, True, True, False) for w in weights], dt)
+        cache.refresh()
+        return {w.data_ptr(): pair for w, pair in zip(weights, cache.out)}
 
     def forward(self, x: torch.Tensor, dropout_u: torch.Tensor | None = None) -> torch.Tensor:
         counters: list = []

@@ -605,7 +605,8 @@ def up2_act_fwd(s: torch.Tensor, act: int) -> torch.Tensor:
 def up2_act_bwd(g: torch.Tensor, s: torch.Tensor, act: int) -> torch.Tensor:
     N, h, w, C = s.shape
     ds = torch.empty_like(s)
-    check(_L().dfd_up2_act_bwd(_dt(s), _p(g), _p(s), act, _p(ds), N, h, w, C, _stream()), "dfd_up2_act_bwd")
+    ws = torch.empty_like(g) if act != ACT_NONE else None
+    check(_L().dfd_up2_act_bwd(_dt(s), _p(g), _p(s), act, _p(ds), N, h, w, C, _p(ws), _stream()), "dfd_up2_act_bwd")
     return ds
 
 

@@ -43,9 +43,13 @@ def _rows(t: torch.Tensor) -> int:
 
 
 def _prep(w: torch.Tensor, dt: torch.dtype, derived, need_bwd: bool = True):
-    """(w_nk, w_kn) of a 1x1 convolution weight [O, I, 1, 1] (or a 2-D GEMM weight) in the activation dtype."""
+    """(w_nk, w_kn) of a 1x1 convolution weight [O, I, 1, 1] (or a 2-D GEMM weight) in the activation dtype.
+    derived: {weight.data_ptr(): (w_nk, w_kn)} refreshed for the whole network by one batched launch per forward
+    (kernels.DerivedWeights), or None: prepare this layer on the spot."""
     if derived is not None:
-        return derived
+        hit = derived.get(w.data_ptr())
+        if hit is not None:
+            return hit
     return K.prep_weights(w, dt, True, need_bwd)
 
 
@@ -338,7 +342,7 @@ class ConvMlpCtx:
     bn2: BNRef
     training: bool
     counters: list | None = None
-    derived: tuple | None = None          # ((w1_nk, w1_kn), (w2_nk, w2_kn)) or None
+    derived: dict | None = None           # see _prep
 
 
 class ConvMlpFunction(torch.autograd.Function):
@@ -353,12 +357,12 @@ class ConvMlpFunction(torch.autograd.Function):
         tr = cfg.training
         N, H, W, C = x.shape
         need_bwd = any(ctx.needs_input_grad)
-        w1_nk, w1_kn = _prep(w1, x.dtype, cfg.derived[0] if cfg.derived else None, need_bwd)
+        w1_nk, w1_kn = _prep(w1, x.dtype, cfg.derived, need_bwd)
         y1, parts, n = K.pwconv(x, None, w1_nk, None, stats=tr)
         st1 = _bn_state(parts, n, N * H * W, cfg.bn1, g1, be1, tr, cfg.counters, conv_bias=b1)
         y2, parts, n = K.dwconv_fwd(y1, st1, ACT_GELU, wd, 3, 1, 1, 1, H, W, stats=tr)
         st2 = _bn_state(parts, n, N * H * W, cfg.bnd, gd, bed, tr, cfg.counters, conv_bias=bd)
-        w2_nk, w2_kn = _prep(w2, x.dtype, cfg.derived[1] if cfg.derived else None, need_bwd)
+        w2_nk, w2_kn = _prep(w2, x.dtype, cfg.derived, need_bwd)
         y3, parts, n = K.pwconv(y2, K.pro_bn_act(st2, ACT_GELU), w2_nk, None, stats=tr)
         st3 = _bn_state(parts, n, N * H * W, cfg.bn2, g2, be2, tr, cfg.counters, conv_bias=b2, ls=ls)
         out = K.bn_act_apply(y3, st3, ACT_NONE, x, row_scale)
@@ -419,6 +423,7 @@ class AttentionCtx:
     idx: torch.Tensor                  # int32 [Nq*Nk] bias index
     training: bool
     counters: list | None = None
+    derived: dict | None = None
 
 
 _ATT_ORDER = ("stride_conv", "q", "k", "v", "v_local", "proj")
@@ -448,7 +453,7 @@ class AttentionFunction(torch.autograd.Function):
         mats = {}
         for nm in ("q", "k", "v"):
             w, b, gm, be = P4[nm]
-            w_nk, kn[nm] = _prep(w, dt, None)
+            w_nk, kn[nm] = _prep(w, dt, cfg.derived)
             mats[nm] = pwbn_fwd(xs, w_nk, b, gm, be, cfg.bns[nm], tr, cn)
         q, yq, stq = mats["q"]
         k, yk, stk = mats["k"]
@@ -463,7 +468,7 @@ class AttentionFunction(torch.autograd.Function):
             s = None
             a = K.bn_add_act(yl, stl, O, ACT_GELU)
         w, b, gm, be = P4["proj"]
-        w_nk, kn["proj"] = _prep(w, dt, None)
+        w_nk, kn["proj"] = _prep(w, dt, cfg.derived)
         out, yp, stp = pwbn_fwd(a, w_nk, b, gm, be, cfg.bns["proj"], tr, cn, ACT_NONE, ls, x, row_scale)
         ctx.cfg = cfg
         ctx.names = names
@@ -562,6 +567,7 @@ class DownsampleCtx:
     geo: AttnGeom | None = None
     bns: dict | None = None            # q_proj, k, v, v_local, proj
     idx: torch.Tensor | None = None
+    derived: dict | None = None
 
 
 _DS_ORDER = ("q_proj", "k", "v", "v_local", "proj")
@@ -595,20 +601,20 @@ class DownsampleFunction(torch.autograd.Function):
         qin = K.subsample_add(lq, bl, x, 2)
         kn = {}
         w, b, gm, be = P4["q_proj"]
-        w_nk, kn["q_proj"] = _prep(w, dt, None)
+        w_nk, kn["q_proj"] = _prep(w, dt, cfg.derived)
         q, yq, stq = pwbn_fwd(qin, w_nk, b, gm, be, cfg.bns["q_proj"], tr, cn)
         w, b, gm, be = P4["k"]
-        w_nk, kn["k"] = _prep(w, dt, None)
+        w_nk, kn["k"] = _prep(w, dt, cfg.derived)
         k, yk, stk = pwbn_fwd(x, w_nk, b, gm, be, cfg.bns["k"], tr, cn)
         w, b, gm, be = P4["v"]
-        w_nk, kn["v"] = _prep(w, dt, None)
+        w_nk, kn["v"] = _prep(w, dt, cfg.derived)
         v, yv, stv = pwbn_fwd(x, w_nk, b, gm, be, cfg.bns["v"], tr, cn)
         O, S, P, T2 = attn_core_fwd(q, k, v, table, cfg.idx, None, geo)
         w, b, gm, be = P4["v_local"]
         yl, stl = dwbn_fwd(v, w, b, gm, be, cfg.bns["v_local"], tr, cn, 3, 2)
         a = K.bn_add_act(yl, stl, O, ACT_GELU)
         w, b, gm, be = P4["proj"]
-        w_nk, kn["proj"] = _prep(w, dt, None)
+        w_nk, kn["proj"] = _prep(w, dt, cfg.derived)
         out, yp, stp = pwbn_fwd(a, w_nk, b, gm, be, cfg.bns["proj"], tr, cn, ACT_NONE, None, conv_out, None)
         ctx.save_for_backward(x, yc, stc, wg_kn, qin, q, yq, stq, k, yk, stk, v, yv, stv, S, P, O, yl, stl, a, yp, stp,
                               kn["q_proj"], kn["k"], kn["v"], kn["proj"], *t)

@@ -289,8 +289,10 @@ int dfd_channel_stats(int dtype, const void* x, long rows, int C, float* partial
 int dfd_sum_rows(float* partials, int P, long L, float* out, int accumulate, dfd_stream stream);
 /* out [N][2h][2w][C] = act(bilinear_x2(s [N][h][w][C])), align_corners = False (nn.Upsample in Attention2d) */
 int dfd_up2_act_fwd(int dtype, const void* s, int act, void* out, int N, int h, int w, int C, dfd_stream stream);
+/* ws (optional): scratch of the size and type of g; with it the activation derivative is evaluated once per output
+ * element (two launches) instead of once per interpolation tap                                                 */
 int dfd_up2_act_bwd(int dtype, const void* g, const void* s, int act, void* ds, int N, int h, int w, int C,
-                    dfd_stream stream);
+                    void* ws, dfd_stream stream);
 /* LocalGlobalQuery: out[n,i,j,:] = a[n,i,j,:] + bias[:] + x[n, i*stride, j*stride, :]  (AvgPool2d(1, stride))
  * and its gradient into x: dx[n, i*stride, j*stride, :] += g[n,i,j,:]                                        */
 int dfd_subsample_add(int dtype, const void* a, const float* bias, const void* x, void* out, int N, int H,
