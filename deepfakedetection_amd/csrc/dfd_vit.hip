@@ -667,18 +667,79 @@ k_bgemm_small(const void* __restrict__ A, MatDesc da, const void* __restrict__ B
     }
 }
 
+// K-parallel variant for tiny outputs with a long reduction (M, N <= 8: the talking-head weight gradients,
+// dW[g][h] = sum over 2401 positions): thread t walks k = t, t + 256, ... with all M*N sums in registers, reading
+// both operands straight from global memory (coalesced along k), then the 256 partial sums of every output are
+// combined through LDS in a fixed order.
+template <int DA, int DB, int DC>
+__global__ void __launch_bounds__(DFD_THREADS)
+k_bgemm_kred(const void* __restrict__ A, MatDesc da, const void* __restrict__ B, MatDesc db, void* __restrict__ C, MatDesc dc,
+             const float* __restrict__ bias, float alpha, int nh, int M, int N, int K) {
+    __shared__ float red[64 * DFD_THREADS / 4];          // 64 outputs x 64 lanes per pass (four passes of 64 threads)
+    const int bh = blockIdx.x, b = bh / nh, h = bh - b * nh;
+    const long a0 = (long)b * da.sb + (long)h * da.sh, b0 = (long)b * db.sb + (long)h * db.sh, c0 = (long)b * dc.sb + (long)h * dc.sh;
+    const int t = threadIdx.x;
+    float acc[8][8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = 0.f;
+    for (int k = t; k < K; k += DFD_THREADS) {
+        float av[8], bv[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) av[i] = i < M ? ElemIO<DA>::ld(A, a0 + i * da.sr + (long)k * da.sc) : 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) bv[j] = j < N ? ElemIO<DB>::ld(B, b0 + (long)k * db.sr + j * db.sc) : 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[i][j] = fmaf(av[i], bv[j], acc[i][j]);
+    }
+    // wave-level sums first (fixed butterfly), then the four wave results through LDS
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float v = acc[i][j];
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+            acc[i][j] = v;
+        }
+    const int lane = t & 63, wave = t >> 6;
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) red[wave * 64 + i * 8 + j] = acc[i][j];
+    }
+    __syncthreads();
+    if (t < 64) {
+        const int m = t >> 3, n = t & 7;
+        if (m < M && n < N) {
+            float v = alpha * (red[t] + red[64 + t] + red[128 + t] + red[192 + t]);
+            if (bias) v += bias[((long)h * M + m) * N + n];
+            ElemIO<DC>::st(C, c0 + m * dc.sr + n * dc.sc, v);
+        }
+    }
+}
+
 extern "C" int dfd_bgemm(int dt_a, const void* A, const dfd_mat* sa, int dt_b, const void* B, const dfd_mat* sb, int dt_c,
                          void* C, const dfd_mat* sc, const float* bias, float alpha, int nb, int nh, int M, int N, int K,
                          int round_a, int round_b, dfd_stream stream) {
     if (!A || !B || !C || !sa || !sb || !sc || nb < 1 || nh < 1 || M < 1 || N < 1 || K < 1) return DFD_EINVAL;
     const size_t lds = ((size_t)K * ((M + 3) & ~3) + (size_t)K * ((N + 3) & ~3)) * 4;
     const bool small = M <= 16 && N <= 16 && lds > 48 * 1024 && !round_a && !round_b;
+    const bool kred = M <= 8 && N <= 8 && K >= 512 && !round_a && !round_b;
     if (!small && lds > 150 * 1024) return DFD_EUNSUPPORTED;
     const MatDesc da{sa->sb, sa->sh, sa->sr, sa->sc}, db{sb->sb, sb->sh, sb->sr, sb->sc}, dc{sc->sb, sc->sh, sc->sr, sc->sc};
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid((unsigned)(nb * nh));
 #define BG(DA, DB, DC)                                                                                                  \
     do {                                                                                                                \
+        if (kred) {                                                                                                     \
+            hipLaunchKernelGGL((k_bgemm_kred<DA, DB, DC>), grid, dim3(DFD_THREADS), 0, st, A, da, B, db, C, dc, bias, alpha, nh, M, N, K); \
+            break;                                                                                                      \
+        }                                                                                                               \
         if (small) {                                                                                                    \
             hipLaunchKernelGGL((k_bgemm_small<DA, DB, DC>), grid, dim3(DFD_THREADS), 0, st, A, da, B, db, C, dc, bias, alpha, nh, M, N, K); \
             break;                                                                                                      \
