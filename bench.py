@@ -375,27 +375,38 @@ def main() -> None:
         torch.cuda.synchronize()
         K.set_profile_sink(None)
         agg: dict[str, list[float]] = {}
-        for name, nbytes, flops, e0, e1 in sink:
-            a = agg.setdefault(name, [0.0, 0.0, 0.0, 0])
+        for name, nbytes, flops, e0, e1, b8d in sink:
+            a = agg.setdefault(name, [0.0, 0.0, 0.0, 0, 0.0])
             a[0] += e0.elapsed_time(e1) * 1e-3
             a[1] += nbytes
             a[2] += flops
             a[3] += 1
+            a[4] += b8d
         total_t = sum(a[0] for a in agg.values())
-        for name, (t, b, f, n) in sorted(agg.items(), key=lambda kv: -kv[1][0]):
+        # GBps: SURVEY section 8(d) algorithmic bytes (kernels._bytes_8d); GBps_incl_fusion_operands: every tensor the
+        # call touches, i.e. including what the engine's own fusions add (second affine2 operand, residual)
+        for name, (t, b, f, n, b8) in sorted(agg.items(), key=lambda kv: -kv[1][0]):
             breakdown.append({"kernel": name, "launches_per_step": n // args.profile_steps,
                               "ms_per_step": round(t / args.profile_steps * 1e3, 4),
-                              "share": round(t / total_t, 4), "GBps": round(b / t / 1e9, 1),
-                              "TFLOPs": round(f / t / 1e12, 2)})
+                              "share": round(t / total_t, 4), "GBps": round(b8 / t / 1e9, 1),
+                              "frac_of_hbm_peak": round(b8 / t / 1e9 / HBM_PEAK_GBS, 4),
+                              "GBps_incl_fusion_operands": round(b / t / 1e9, 1), "TFLOPs": round(f / t / 1e12, 2)})
         # dominant family by time; every family in this step is HBM-bound by arithmetic
         # intensity (all 1x1 layers < 312 flop/B), so bound = "hbm"
         top = breakdown[0]
-        t, b, f, n = agg[top["kernel"]]
-        roofline = {"kernel": top["kernel"], "bound": "hbm", "achieved": round(b / t / 1e9, 1), "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(b / t / 1e9 / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(top["kernel"], args),
-                    "avg_launch_us": round(t / n * 1e6, 2), "avg_launch_bytes": int(b / n),
+        t, b, f, n, b8 = agg[top["kernel"]]
+        roofline = {"kernel": top["kernel"], "bound": "hbm", "achieved": round(b8 / t / 1e9, 1), "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": round(b8 / t / 1e9 / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(top["kernel"], args),
+                    "bytes": "SURVEY 8(d): M*(K+Nout)*2 + K*Nout*2 per 1x1 pass; N*C*(Hin*Win+Hout*Wout)*2 + k*k*C*4 per depthwise forward",
+                    "achieved_incl_fusion_operands": round(b / t / 1e9, 1),
+                    "avg_launch_us": round(t / n * 1e6, 2), "avg_launch_bytes": int(b8 / n),
                     "share_of_step": top["share"], "mfma_tflops": round(f / t / 1e12, 2),
                     "mfma_frac": round(f / t / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4)}
+        dw = [agg[k] for k in ("dwconv_fwd", "dwconv_bwd_data", "dwconv_bwd_weight") if k in agg]
+        if dw:
+            tdw, bdw = sum(a[0] for a in dw), sum(a[4] for a in dw)
+            roofline["depthwise_family"] = {"achieved": round(bdw / tdw / 1e9, 1), "frac": round(bdw / tdw / 1e9 / HBM_PEAK_GBS, 4),
+                                            "ms_per_step": round(tdw / args.profile_steps * 1e3, 3)}
 
     if rank == 0:
         ms = elapsed / args.steps * 1e3

@@ -117,6 +117,10 @@ k_pw_tnw(const bf16* __restrict__ a, ProArgs pa, int Na, const bf16* __restrict_
                 load_f32<8>(cf + 2 * N + ch * 8, c2);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) v[j] = fmaf(c0[j], v[j], fmaf(c1[j], v2[j], c2[j]));
+            } else if constexpr (MODE == DFD_PRO_BN_ACT) {
+                // BN + activation without a squeeze-excite gate (EfficientFormerV2 ConvMlp: GELU(BN(mid conv)))
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = act_fwd<ACT>(fmaf(c0[j], v[j], c1[j]));
             } else {
                 float gt[8];
                 load_f32<8>(pr.gate + (long)pro_image(pr, m) * N + ch * 8, gt);
@@ -246,7 +250,8 @@ k_pw_tnw(const bf16* __restrict__ a, ProArgs pa, int Na, const bf16* __restrict_
 // ===========================================================================
 static bool tnw_pro_ok(int mode_narrow, int mode_wide) {
     return (mode_narrow == DFD_PRO_NONE || mode_narrow == DFD_PRO_AFFINE2) &&
-           (mode_wide == DFD_PRO_NONE || mode_wide == DFD_PRO_AFFINE2 || mode_wide == DFD_PRO_BN_ACT_GATE);
+           (mode_wide == DFD_PRO_NONE || mode_wide == DFD_PRO_AFFINE2 || mode_wide == DFD_PRO_BN_ACT_GATE ||
+            mode_wide == DFD_PRO_BN_ACT);
 }
 
 template <int ROWS, int NA, int NBT>
@@ -254,7 +259,7 @@ static int tnw_launch(const void* a, const dfd_prologue* pro_a, int Na, const vo
                       int M, int swap, float* dw, int accumulate, float* ws, size_t ws_bytes, hipStream_t st) {
     const ProArgs pa = pro_args(pro_a), pb = pro_args(pro_b);
     const int ma = pro_a ? pro_a->mode : DFD_PRO_NONE, mb = pro_b ? pro_b->mode : DFD_PRO_NONE;
-    const int act = (mb == DFD_PRO_BN_ACT_GATE && pro_b) ? pro_b->act : DFD_ACT_NONE;
+    const int act = ((mb == DFD_PRO_BN_ACT_GATE || mb == DFD_PRO_BN_ACT) && pro_b) ? pro_b->act : DFD_ACT_NONE;
     // 2 workgroups per CU (64 KB of tiles each); every wave should see several 32-row steps
     int nblocks = 512;
     int rpb = (M + nblocks - 1) / nblocks;
@@ -269,6 +274,11 @@ static int tnw_launch(const void* a, const dfd_prologue* pro_a, int Na, const vo
         if (act != DFD_ACT_SILU) return DFD_EUNSUPPORTED;
         if (ma == DFD_PRO_AFFINE2) LAUNCH_TNW(DFD_PRO_AFFINE2, DFD_PRO_BN_ACT_GATE, DFD_ACT_SILU);
         else LAUNCH_TNW(DFD_PRO_NONE, DFD_PRO_BN_ACT_GATE, DFD_ACT_SILU);
+    } else if (mb == DFD_PRO_BN_ACT) {
+        if (ma != DFD_PRO_AFFINE2) return DFD_EUNSUPPORTED;          // the engine's use: dW = (BN-backward of g) x act(BN(y))
+        if (act == DFD_ACT_GELU) LAUNCH_TNW(DFD_PRO_AFFINE2, DFD_PRO_BN_ACT, DFD_ACT_GELU);
+        else if (act == DFD_ACT_SILU) LAUNCH_TNW(DFD_PRO_AFFINE2, DFD_PRO_BN_ACT, DFD_ACT_SILU);
+        else return DFD_EUNSUPPORTED;
     } else if (mb == DFD_PRO_AFFINE2) {
         if (ma == DFD_PRO_AFFINE2) return DFD_EUNSUPPORTED;
         LAUNCH_TNW(DFD_PRO_NONE, DFD_PRO_AFFINE2, DFD_ACT_NONE);

@@ -198,7 +198,7 @@ class MBConvFunction(torch.autograd.Function):
         dw_proj = None
         if need[11]:
             pro_q = K.pro_bn_act_gate(st2, ACT_SILU, gate, Ho * Wo)
-            with K.side_stream():
+            with K.side_stream(N * Ho * Wo):
                 dw_proj = K.pwconv_wgrad(gb, pro_dy3, y2, pro_q, _dest(ctx, 11, (Cout, Cmid))).view(Cout, Cmid, 1, 1)
         # ---- squeeze-excite backward
         dgate = K.pool_bwd_reduce(D, y2, st2, ACT_SILU)
@@ -219,7 +219,7 @@ class MBConvFunction(torch.autograd.Function):
             coef1, dg_exp, db_exp = K.bn_bwd_finalize(parts, n, N * H * W, g_exp, st1, tr, need[2] or need[3],
                                                       _dest(ctx, 2, (Cmid,)), _dest(ctx, 3, (Cmid,)))
             pro_dy1 = K.pro_affine2(y1, coef1)
-            with K.side_stream():
+            with K.side_stream(N * Ho * Wo):
                 if need[4]:
                     dw_dw = K.dwconv_bwd_weight(dz2, y2, coef2, y1, st1, ACT_SILU, geom.kernel, geom.stride,
                                                 geom.pad_lead, geom.pad_lead, _dest(ctx, 4, (Cmid, 1, kk, kk)))
@@ -229,7 +229,7 @@ class MBConvFunction(torch.autograd.Function):
                 dx, _, _ = K.pwconv(dz1, pro_dy1, wexp_kn, g if cfg.skip else None, stats=False)
         else:
             if need[4]:
-                with K.side_stream():
+                with K.side_stream(N * Ho * Wo):
                     dw_dw = K.dwconv_bwd_weight(dz2, y2, coef2, x, None, ACT_NONE, geom.kernel, geom.stride,
                                                 geom.pad_lead, geom.pad_lead, _dest(ctx, 4, (Cmid, 1, kk, kk)))
             if need[0]:

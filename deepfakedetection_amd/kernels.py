@@ -41,15 +41,21 @@ def _stream() -> int:
 # grid sized for the whole chip, so two of them at once just take turns; kept for experiments only.
 _side_streams: dict[int, torch.cuda.Stream] = {}
 _side_enabled = os.environ.get("DFD_SIDE_STREAM", "0") == "1"
+_side_max_rows = int(os.environ.get("DFD_SIDE_MAXROWS", "0"))      # experiments: only layers with at most this many rows
 
 
 class side_stream:
-    """`with side_stream(): ...` enqueues the body on the side stream, ordered after everything already
+    """`with side_stream(rows): ...` enqueues the body on the side stream, ordered after everything already
     enqueued on the current stream; pair with `join_side()` before the results are consumed."""
+
+    def __init__(self, rows: int = 0) -> None:
+        self.rows = rows
 
     def __enter__(self):
         self._ctx = None
         if not _side_enabled or _profile_sink is not None:
+            return self
+        if _side_max_rows and self.rows > _side_max_rows:
             return self
         cur = torch.cuda.current_stream()
         side = _side_streams.get(cur.device_index)
@@ -882,6 +888,41 @@ def _flops(name: str, args) -> float:
     return 0.0
 
 
+def _bytes_8d(name: str, args, fallback: int) -> int:
+    """Algorithmic bytes of SURVEY.md section 8(d) — every activation tensor the UNFUSED op must move once, without
+    the operands the engine's own fusions add (the second tensor of an affine2 prologue, residuals, statistics):
+      1x1 conv / dgrad   M*(K + Nout)*es + K*Nout*es          1x1 wgrad   M*(Ni + Nj)*es + Ni*Nj*4
+      depthwise fwd      N*C*(Hin*Win + Hout*Wout)*es + k*k*C*4
+      depthwise dgrad    N*C*(Hout*Wout + Hin*Win [+ Hin*Win when the activation derivative is fused])*es
+      depthwise wgrad    N*C*(Hout*Wout + Hin*Win)*es
+    Everything else: the tensors of the call (as `bytes incl. fusion operands`)."""
+    try:
+        if name == "pwconv":
+            a, w = args[0], args[2]
+            K_, es = a.shape[-1], a.element_size()
+            M = a.numel() // K_
+            return (M * K_ + M * w.shape[0]) * es + w.numel() * es
+        if name == "pwconv_wgrad":
+            p, q = args[0], args[2]
+            M = p.numel() // p.shape[-1]
+            return M * (p.shape[-1] + q.shape[-1]) * p.element_size() + p.shape[-1] * q.shape[-1] * 4
+        if name == "dwconv_fwd":
+            x, k, Ho, Wo = args[0], args[4], args[8], args[9]
+            N, H, W, C = x.shape
+            return N * C * (H * W + Ho * Wo) * x.element_size() + k * k * C * 4
+        if name == "dwconv_bwd_data":
+            dz, xin, in_shape = args[0], args[4], args[7]
+            N, H, W, C = in_shape
+            return N * C * (dz.shape[1] * dz.shape[2] + H * W * (2 if xin is not None else 1)) * dz.element_size()
+        if name == "dwconv_bwd_weight":
+            dz, xin = args[0], args[3]
+            N, H, W, C = xin.shape
+            return N * C * (dz.shape[1] * dz.shape[2] + H * W) * dz.element_size()
+    except (IndexError, AttributeError, TypeError):
+        pass
+    return fallback
+
+
 def _timed(name: str, fn):
     def inner(*args, **kwargs):
         sink = _profile_sink
@@ -891,8 +932,8 @@ def _timed(name: str, fn):
         e0.record()
         out = fn(*args, **kwargs)
         e1.record()
-        sink.append((name, _tensor_bytes(args) + _tensor_bytes(list(kwargs.values())) + _tensor_bytes(out),
-                     _flops(name, args), e0, e1))
+        nbytes = _tensor_bytes(args) + _tensor_bytes(list(kwargs.values())) + _tensor_bytes(out)
+        sink.append((name, nbytes, _flops(name, args), e0, e1, _bytes_8d(name, args, nbytes)))
         return out
 
     inner.__name__ = name

@@ -469,3 +469,22 @@ def test_sum_rows_beyond_1024_partial_rows():
     out = torch.empty(L, device="cuda")
     K.sum_rows(parts.cuda().view(-1), P, L, out)
     close(out, parts[:P].double().sum(0).float(), 1e-5, "multi-group row sum")
+
+
+@pytest.mark.parametrize("act", [R.ACT_GELU, R.ACT_SILU])
+def test_wave_autonomous_wgrad_with_bn_act_prologue(act):
+    """EfficientFormerV2 ConvMlp fc2 weight gradient at the 56x56 stage: narrow operand through the BN-backward affine
+    map, wide operand through BN + activation (no gate), M above the wave-autonomous kernel's threshold."""
+    K = _k()
+    rd = torch.bfloat16
+    N, HW, Ni, Nj = 4, 50003, 32, 128
+    p, p2 = gen((N, HW, 1, Ni), 1, rd, 0.5), gen((N, HW, 1, Ni), 2, rd, 0.5)
+    q = gen((N, HW, 1, Nj), 3, rd, 0.5)
+    coef3 = rand_state(Ni, 4)[:3].contiguous()
+    st = rand_state(Nj, 5)
+    P = R.prologue(p.float().view(N, HW, Ni), 3, rd, coef=coef3, a2=p2.float().view(N, HW, Ni))
+    Q = R.prologue(q.float().view(N, HW, Nj), 1, rd, act, st)
+    want = P.reshape(-1, Ni).t().double() @ Q.reshape(-1, Nj).double()
+    dp2, dcoef, dst = p2.cuda(), coef3.cuda(), st.cuda()
+    got = K.pwconv_wgrad(p.cuda(), K.pro_affine2(dp2, dcoef), q.cuda(), K.pro_bn_act(dst, act))
+    close(got, want.float(), 4e-3, "wgrad affine2 x bn_act")
