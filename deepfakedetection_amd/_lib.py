@@ -83,6 +83,10 @@ SIGNATURES: dict[str, tuple] = {
     "dfd_ce_loss": (c_int, [P, P, c_int, c_int, c_float, c_float, P, P, P, P]),
     "dfd_softmax_argmax": (c_int, [P, c_int, c_int, P, P, P]),
     "dfd_adamw_step": (c_int, [P, c_int, P, P]),
+    # ---- ABI 111
+    "dfd_se_fwd": (c_int, [c_int, P, P, c_int, c_int, c_int, c_int, P, P, P, P, c_int, c_int, P, P, P, P, P, c_size_t, P]),
+    "dfd_se_bwd": (c_int, [c_int, P, P, P, c_int, c_int, c_int, c_int, P, P, P, P, P, c_int, c_int, P, P, P, P, P, P, c_int,
+                           P, c_size_t, P, P]),
     # ---- ABI 110
     "dfd_bn_finalize_ex": (c_int, [P, c_int, c_int, c_double, P, P, P, P, P, P, c_float, c_float, P, P]),
     "dfd_bn_eval_coeffs_ex": (c_int, [P, P, P, P, P, P, c_float, c_int, P, P]),

@@ -161,6 +161,128 @@ k_se_fc_bwd_w(const float* __restrict__ pooled, const float* __restrict__ ws, in
     }
 }
 
+// ---- one workgroup per image: the whole squeeze-excite MLP behind the pooling kernel (and the sum of its
+// H*W split vectors), forward and backward.  Same summation orders as the short kernels above.
+int dfd_pool_launch(int dtype, bool bwd, const void* D, const void* y, const float* bnstate, int act, float* out, int N,
+                    int HW, int C, void* ws, size_t ws_bytes, hipStream_t st, int* splits, float* mul);
+
+#define SE_IMG_THREADS 1024
+// four rows of `w` against the LDS vector at once (independent load streams); each dot keeps wave_dot's order
+__device__ __forceinline__ void lds_dot4(const float* sp, const float* __restrict__ w, int C, int R, int r0, int rstep, int lane,
+                                         float (&s)[4]) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) s[k] = 0.f;
+    for (int c = lane * 4; c < C; c += 256) {
+        const float4 x = *reinterpret_cast<const float4*>(sp + c);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int r = r0 + k * rstep;
+            if (r < R) {
+                const float4 y = *reinterpret_cast<const float4*>(w + (long)r * C + c);
+                s[k] = fmaf(x.x, y.x, fmaf(x.y, y.y, fmaf(x.z, y.z, fmaf(x.w, y.w, s[k]))));
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) s[k] = wave_sum(s[k]);
+}
+
+template <int ACT>
+__global__ void __launch_bounds__(SE_IMG_THREADS)
+k_se_fwd_img(const float* __restrict__ parts, int splits, float mul, float* __restrict__ pooled, const float* __restrict__ w1,
+             const float* __restrict__ b1, const float* __restrict__ w2t, const float* __restrict__ b2, int N, int C, int R,
+             float* __restrict__ hpre, float* __restrict__ gate) {
+    __shared__ __attribute__((aligned(16))) float sp[SE_MAX_C];
+    __shared__ float sh[SE_MAX_R];
+    const int n = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    constexpr int NW = SE_IMG_THREADS / 64;
+    for (int c = t; c < C; c += SE_IMG_THREADS) {
+        float v;
+        if (splits > 1) {
+            float s = 0.f;
+            for (int z = 0; z < splits; ++z) s += parts[((long)z * N + n) * C + c];
+            v = s * mul;
+            pooled[(long)n * C + c] = v;
+        } else {
+            v = pooled[(long)n * C + c];
+        }
+        sp[c] = v;
+    }
+    __syncthreads();
+    for (int rb = wave; rb < R; rb += 4 * NW) {
+        float s4[4];
+        lds_dot4(sp, w1, C, R, rb, NW, lane, s4);
+        if (lane == 0) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int r = rb + k * NW;
+                if (r < R) {
+                    const float z = s4[k] + (b1 ? b1[r] : 0.f);
+                    hpre[(long)n * R + r] = z;
+                    sh[r] = act_rt<ACT>(z);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    for (int c = t; c < C; c += SE_IMG_THREADS) {
+        float s = b2 ? b2[c] : 0.f;
+        for (int r = 0; r < R; ++r) s = fmaf(w2t[(long)r * C + c], sh[r], s);
+        gate[(long)n * C + c] = sigmoid_f(s);
+    }
+}
+
+template <int ACT>
+__global__ void __launch_bounds__(SE_IMG_THREADS)
+k_se_bwd_img(const float* __restrict__ parts, int splits, const float* __restrict__ dgate_in, const float* __restrict__ gate,
+             const float* __restrict__ hpre, const float* __restrict__ w1, const float* __restrict__ w2t, int N, int C, int R,
+             float* __restrict__ ws, float* __restrict__ dpooled) {
+    __shared__ __attribute__((aligned(16))) float sp[SE_MAX_C];
+    __shared__ float sd[SE_MAX_R];
+    float* ws_g = ws;
+    float* ws_dh = ws + (long)N * C;
+    float* ws_h = ws_dh + (long)N * R;
+    constexpr int NW = SE_IMG_THREADS / 64;
+    const int n = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    for (int c = t; c < C; c += SE_IMG_THREADS) {
+        float d;
+        if (splits > 1) {
+            d = 0.f;
+            for (int z = 0; z < splits; ++z) d += parts[((long)z * N + n) * C + c];
+        } else {
+            d = dgate_in[(long)n * C + c];
+        }
+        const float g = gate[(long)n * C + c];
+        const float v = d * g * (1.f - g);
+        ws_g[(long)n * C + c] = v;
+        sp[c] = v;
+    }
+    __syncthreads();
+    for (int rb = wave; rb < R; rb += 4 * NW) {
+        float s4[4];
+        lds_dot4(sp, w2t, C, R, rb, NW, lane, s4);
+        if (lane == 0) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int r = rb + k * NW;
+                if (r < R) {
+                    const float z = hpre[(long)n * R + r];
+                    const float dh = s4[k] * act_grad<ACT>(z);
+                    ws_dh[(long)n * R + r] = dh;
+                    ws_h[(long)n * R + r] = act_rt<ACT>(z);
+                    sd[r] = dh;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    for (int c = t; c < C; c += SE_IMG_THREADS) {
+        float s = 0.f;
+        for (int r = 0; r < R; ++r) s = fmaf(sd[r], w1[(long)r * C + c], s);
+        dpooled[(long)n * C + c] = s;
+    }
+}
+
 __global__ void k_transpose_f32(const float* __restrict__ in, float* __restrict__ out, int rows, int cols) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;       // index into out [cols][rows]
     if (i >= rows * cols) return;
@@ -181,6 +303,49 @@ extern "C" int dfd_se_fc_fwd(const float* pooled, const float* w1, const float* 
         hipLaunchKernelGGL((k_se_gate<ACT>), dim3((C + DFD_THREADS - 1) / DFD_THREADS, N), dim3(DFD_THREADS), 0, st, hpre, w2t,
                            b2, C, R, gate);
     });
+    return DFD_CHECK_LAUNCH();
+}
+
+extern "C" int dfd_se_fwd(int dtype, const void* y, const float* bnstate, int act_in, int N, int HW, int C, const float* w1,
+                          const float* b1, const float* w2, const float* b2, int R, int act, float* pooled, float* hpre,
+                          float* gate, float* w2t, void* ws, size_t ws_bytes, dfd_stream stream) {
+    if (!y || !bnstate || !w1 || !pooled || !hpre || !gate || !w2t || N < 1 || C < 1 || R < 1 || C % 4) return DFD_EINVAL;
+    if (C > SE_MAX_C || R > SE_MAX_R) return DFD_EUNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    if (w2) hipLaunchKernelGGL(k_transpose_f32, dim3((C * R + 255) / 256), dim3(256), 0, st, w2, w2t, C, R);
+    int splits = 1;
+    float mul = 1.f;
+    const int rc = dfd_pool_launch(dtype, false, nullptr, y, bnstate, act_in, pooled, N, HW, C, ws, ws_bytes, st, &splits, &mul);
+    if (rc != DFD_OK) return rc;
+    DISPATCH_ACT(act, {
+        hipLaunchKernelGGL((k_se_fwd_img<ACT>), dim3(N), dim3(SE_IMG_THREADS), 0, st, (const float*)ws, splits, mul, pooled, w1, b1,
+                           w2t, b2, N, C, R, hpre, gate);
+    });
+    return DFD_CHECK_LAUNCH();
+}
+
+extern "C" int dfd_se_bwd(int dtype, const void* D, const void* y, const float* bnstate, int act_in, int N, int HW, int C,
+                          const float* gate, const float* hpre, const float* pooled, const float* w1, const float* w2t, int R,
+                          int act, float* dgate, float* dpooled, float* dw1, float* db1, float* dw2, float* db2, int accumulate,
+                          void* pool_ws, size_t pool_ws_bytes, float* ws, dfd_stream stream) {
+    if (!D || !y || !bnstate || !gate || !hpre || !pooled || !w1 || !w2t || !dgate || !dpooled || !ws || N < 1 || C < 1 ||
+        R < 1 || C % 4)
+        return DFD_EINVAL;
+    if (C > SE_MAX_C || R > SE_MAX_R) return DFD_EUNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    int splits = 1;
+    float mul = 1.f;
+    const int rc = dfd_pool_launch(dtype, true, D, y, bnstate, act_in, dgate, N, HW, C, pool_ws, pool_ws_bytes, st, &splits, &mul);
+    if (rc != DFD_OK) return rc;
+    DISPATCH_ACT(act, {
+        hipLaunchKernelGGL((k_se_bwd_img<ACT>), dim3(N), dim3(SE_IMG_THREADS), 0, st, (const float*)pool_ws, splits, dgate, gate, hpre,
+                           w1, w2t, N, C, R, ws, dpooled);
+    });
+    if (hipGetLastError() != hipSuccess) return DFD_ELAUNCH;
+    if (dw1 && dw2) {
+        hipLaunchKernelGGL(k_se_fc_bwd_w, dim3((C + 63) / 64, R), dim3(DFD_THREADS), 0, st, pooled, ws, N, C, R, dw1, db1,
+                           dw2, db2, accumulate);
+    }
     return DFD_CHECK_LAUNCH();
 }
 

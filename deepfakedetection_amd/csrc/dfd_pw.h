@@ -97,6 +97,32 @@ __device__ __forceinline__ uint4 apply_pro_c(uint4 q, uint4 q2, const float (&c0
     }
 }
 
+// same with the gate values in registers too (read from an LDS table or from global memory by the caller)
+template <typename T, int PRO, int ACT, int E>
+__device__ __forceinline__ uint4 apply_pro_v(uint4 q, uint4 q2, const float (&c0)[E], const float (&c1)[E], const float (&c2)[E],
+                                             const float (&gt)[E]) {
+    if constexpr (PRO == DFD_PRO_NONE) {
+        return q;
+    } else {
+        float v[E];
+        q_to_f(q, v);
+        if constexpr (PRO == DFD_PRO_AFFINE2) {
+            float v2[E];
+            q_to_f(q2, v2);
+#pragma unroll
+            for (int j = 0; j < E; ++j) v[j] = fmaf(c0[j], v[j], fmaf(c1[j], v2[j], c2[j]));
+        } else {
+#pragma unroll
+            for (int j = 0; j < E; ++j) v[j] = act_fwd<ACT>(fmaf(c0[j], v[j], c1[j]));
+            if constexpr (PRO == DFD_PRO_BN_ACT_GATE) {
+#pragma unroll
+                for (int j = 0; j < E; ++j) v[j] = round_to<T>(v[j]) * gt[j];
+            }
+        }
+        return f_to_q(v);
+    }
+}
+
 // activations instantiated for the GEMM prologues (EfficientNet: SiLU; EfficientFormerV2 / FasterViT: GELU)
 #define DISPATCH_ACT_PW(ACTV, ...)                                                   \
     switch (ACTV) {                                                                  \

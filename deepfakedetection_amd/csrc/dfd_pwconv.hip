@@ -305,7 +305,7 @@ k_pw_nt(const T* __restrict__ a, ProArgs pa, const T* __restrict__ w, T* __restr
 template <typename T, int PROP, int PROQ, int ACT>
 __global__ void __launch_bounds__(DFD_THREADS, 2)
 k_pw_tn(const T* __restrict__ p, ProArgs pp, int Ni, const T* __restrict__ q, ProArgs pq, int Nj, int M,
-        int i_tiles, int j_tiles, int rows_per_split, float* __restrict__ ws) {
+        int i_tiles, int j_tiles, int rows_per_split, int gate_imgs, float* __restrict__ ws) {
     constexpr int E = El<T>::EPC;
     constexpr int BMK = (sizeof(T) == 2) ? 64 : 32;         // reduction rows per step
     constexpr int ROWB = (sizeof(T) == 2) ? 256 : TN_F32_ROW;
@@ -355,8 +355,33 @@ k_pw_tn(const T* __restrict__ p, ProArgs pp, int Ni, const T* __restrict__ q, Pr
     // tiles read zeros there
     if (cp < CPRW || cq < CPRW) {
         for (int i = t; i < 4 * TILE / 16; i += DFD_THREADS) reinterpret_cast<uint4*>(smem)[i] = make_uint4(0, 0, 0, 0);
-        __syncthreads();
     }
+    // the prologue coefficients of this output tile's channels, and the gate rows of every image the row
+    // split touches, live in LDS: in the staging path a per-chunk global load sits between the prefetched
+    // operand and its LDS store, where nothing hides its latency (this kernel has no registers to spare)
+    float* ctab = reinterpret_cast<float*>(smem + 4 * TILE);          // [5][TN_B]: p c0,c1,c2 ; q scale,shift
+    float* gtab = ctab + 5 * TN_B;                                    // [gate_imgs][TN_B]
+    int img0 = 0;
+    if constexpr (PROP != DFD_PRO_NONE || PROQ != DFD_PRO_NONE) {
+        for (int i = t; i < 5 * TN_B; i += DFD_THREADS) {
+            const int r = i / TN_B, c = i - r * TN_B;
+            float v = 0.f;
+            if (r < 3) { if (PROP == DFD_PRO_AFFINE2 && i0 + c < Ni) v = pp.coef[r * Ni + i0 + c]; }
+            else if (PROQ != DFD_PRO_NONE && j0 + c < Nj) v = pq.coef[(r - 3) * Nj + j0 + c];
+            ctab[i] = v;
+        }
+        if constexpr (PROQ == DFD_PRO_BN_ACT_GATE) {
+            if (gate_imgs > 0 && mend > mbeg) {
+                img0 = pro_image(pq, mbeg);
+                const int nimg = pro_image(pq, mend - 1) - img0 + 1;      // <= gate_imgs (host)
+                for (int i = t; i < nimg * TN_B; i += DFD_THREADS) {
+                    const int r = i / TN_B, c = i - r * TN_B;
+                    gtab[i] = (j0 + c < Nj) ? pq.gate[(long)(img0 + r) * Nj + j0 + c] : 0.f;
+                }
+            }
+        }
+    }
+    __syncthreads();
 
     f32x4_t acc[4][4];
 #pragma unroll
@@ -390,8 +415,13 @@ k_pw_tn(const T* __restrict__ p, ProArgs pp, int Ni, const T* __restrict__ q, Pr
             if (a_ >> 16) {
                 const int r = a_ & 255, chk = (a_ >> 8) & 255;
                 uint4 v = rp[i];
-                if (PROP != DFD_PRO_NONE && mb + r < mend)
-                    v = apply_pro<T, PROP, DFD_ACT_NONE>(rp[i], rp2[i], pp.coef, nullptr, i0 + chk * E, Ni);
+                if (PROP != DFD_PRO_NONE && mb + r < mend) {
+                    float c0[E], c1[E], c2[E];
+                    load_f32<E>(ctab + chk * E, c0);
+                    load_f32<E>(ctab + TN_B + chk * E, c1);
+                    load_f32<E>(ctab + 2 * TN_B + chk * E, c2);
+                    v = apply_pro_v<T, PROP, DFD_ACT_NONE, E>(rp[i], rp2[i], c0, c1, c2, c2);
+                }
                 if constexpr (sizeof(T) == 2) *reinterpret_cast<uint4*>(pb_ + tn_off_bf16(r, chk)) = v;
                 else *reinterpret_cast<uint4*>(pb_ + r * ROWB + chk * 16) = v;
             }
@@ -399,9 +429,15 @@ k_pw_tn(const T* __restrict__ p, ProArgs pp, int Ni, const T* __restrict__ q, Pr
                 const int r = b_ & 255, chk = (b_ >> 8) & 255, m = mb + r;
                 uint4 v = rq[i];
                 if (PROQ != DFD_PRO_NONE && m < mend) {
-                    const float* grow = nullptr;
-                    if constexpr (PROQ == DFD_PRO_BN_ACT_GATE) grow = pq.gate + (long)pro_image(pq, m) * Nj;
-                    v = apply_pro<T, PROQ, ACT>(rq[i], rq[i], pq.coef, grow, j0 + chk * E, Nj);
+                    float c0[E], c1[E], gt[E];
+                    load_f32<E>(ctab + 3 * TN_B + chk * E, c0);
+                    load_f32<E>(ctab + 4 * TN_B + chk * E, c1);
+                    if constexpr (PROQ == DFD_PRO_BN_ACT_GATE) {
+                        const int img = pro_image(pq, m);
+                        if (gate_imgs > 0) load_f32<E>(gtab + (img - img0) * TN_B + chk * E, gt);
+                        else load_f32<E>(pq.gate + (long)img * Nj + j0 + chk * E, gt);
+                    }
+                    v = apply_pro_v<T, PROQ, ACT, E>(rq[i], rq[i], c0, c1, c1, gt);
                 }
                 if constexpr (sizeof(T) == 2) *reinterpret_cast<uint4*>(qb_ + tn_off_bf16(r, chk)) = v;
                 else *reinterpret_cast<uint4*>(qb_ + r * ROWB + chk * 16) = v;
@@ -692,16 +728,23 @@ static int pw_tn_t(const void* p, const dfd_prologue* pro_p, int Ni, const void*
     if ((size_t)(splits + splits / 32 + 2) * Ni * Nj * 4 > ws_bytes) return DFD_EWORKSPACE;
     constexpr int BMK = (sizeof(T) == 2) ? 64 : 32;
     constexpr int ROWB = (sizeof(T) == 2) ? 256 : TN_F32_ROW;
-    const int lds = 2 * 2 * BMK * ROWB;
+    int lds = 2 * 2 * BMK * ROWB + 5 * TN_B * 4;
     const ProArgs pp = pro_args(pro_p), pq = pro_args(pro_q);
     const int mp = pro_p ? pro_p->mode : DFD_PRO_NONE, mq = pro_q ? pro_q->mode : DFD_PRO_NONE;
+    // gate rows in LDS when the images one row split touches fit beside two resident workgroups' tiles
+    int gate_imgs = 0;
+    if (mq == DFD_PRO_BN_ACT_GATE) {
+        const int need = (rps + pq.HW - 2) / pq.HW + 1;
+        if ((size_t)lds + (size_t)need * TN_B * 4 <= (size_t)80 * 1024) gate_imgs = need;
+        lds += gate_imgs * TN_B * 4;
+    }
     const int act = (pro_q && (mq == DFD_PRO_BN_ACT || mq == DFD_PRO_BN_ACT_GATE)) ? pro_q->act : DFD_ACT_NONE;
     if (!(mp == DFD_PRO_NONE || mp == DFD_PRO_AFFINE2)) return DFD_EUNSUPPORTED;
     if (mq == DFD_PRO_AFFINE2) return DFD_EUNSUPPORTED;
     dim3 grid(it * jt, splits);
 #define LAUNCH_TN(PP, PQ)                                                                                                \
     hipLaunchKernelGGL((k_pw_tn<T, PP, PQ, ACT>), grid, dim3(DFD_THREADS), lds, st, (const T*)p, pp, Ni, (const T*)q, pq, Nj, \
-                       M, it, jt, rps, ws)
+                       M, it, jt, rps, gate_imgs, ws)
     if (mq == DFD_PRO_NONE) {
         constexpr int ACT = DFD_ACT_NONE;
         if (mp == DFD_PRO_AFFINE2) LAUNCH_TN(DFD_PRO_AFFINE2, DFD_PRO_NONE); else LAUNCH_TN(DFD_PRO_NONE, DFD_PRO_NONE);

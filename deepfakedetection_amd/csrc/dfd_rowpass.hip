@@ -529,9 +529,11 @@ extern "C" size_t dfd_pool_ws(int dtype, int N, int HW, int C) {
     return pool_ws_bytes(N, HW, C, dtype == DFD_BF16 ? Vec<bf16>::N : Vec<float>::N);
 }
 
+// defer != nullptr: the caller's next kernel adds the split vectors itself (dfd_se_fwd / dfd_se_bwd): no k_pool_sum
+// launch; defer[0] = splits (1: `out` is final), mul_out = the factor still to apply to the sum
 template <typename T, bool BWD>
 static int pool_t(const void* D, const void* y, const float* bnstate, int act, float* out, int N, int HW, int C,
-                  void* ws, size_t ws_bytes, hipStream_t st) {
+                  void* ws, size_t ws_bytes, hipStream_t st, int* defer = nullptr, float* mul_out = nullptr) {
     const ChanMap cm = make_chanmap(C, Vec<T>::N);
     int splits = 1, rows_per = HW;
     if (ws) {
@@ -545,11 +547,23 @@ static int pool_t(const void* D, const void* y, const float* bnstate, int act, f
         hipLaunchKernelGGL((k_pool<T, ACT, BWD>), grid, dim3(DFD_THREADS), 0, st, (const T*)D, (const T*)y, bnstate, out, HW,
                            C, mul, cm, rows_per, parts);
     });
-    if (splits > 1) {
+    if (defer) {
+        *defer = splits;
+        *mul_out = mul;
+    } else if (splits > 1) {
         const long NC = (long)N * C;
         hipLaunchKernelGGL(k_pool_sum, dim3((unsigned)((NC + 255) / 256)), dim3(256), 0, st, parts, splits, NC, mul, out);
     }
     return DFD_CHECK_LAUNCH();
+}
+int dfd_pool_launch(int dtype, bool bwd, const void* D, const void* y, const float* bnstate, int act, float* out, int N,
+                    int HW, int C, void* ws, size_t ws_bytes, hipStream_t st, int* splits, float* mul) {
+    if (!shape_ok(dtype, N, HW, C) || !y || !bnstate || !out || (bwd && !D)) return DFD_EINVAL;
+    if (dtype == DFD_BF16)
+        return bwd ? pool_t<bf16, true>(D, y, bnstate, act, out, N, HW, C, ws, ws_bytes, st, splits, mul)
+                   : pool_t<bf16, false>(nullptr, y, bnstate, act, out, N, HW, C, ws, ws_bytes, st, splits, mul);
+    return bwd ? pool_t<float, true>(D, y, bnstate, act, out, N, HW, C, ws, ws_bytes, st, splits, mul)
+               : pool_t<float, false>(nullptr, y, bnstate, act, out, N, HW, C, ws, ws_bytes, st, splits, mul);
 }
 extern "C" int dfd_pool_act(int dtype, const void* y, const float* bnstate, int act, float* pooled, int N, int HW,
                             int C, void* ws, size_t ws_bytes, dfd_stream stream) {
@@ -613,4 +627,4 @@ extern "C" int dfd_bn_bwd_finalize(const float* partials, int nparts, int C, dou
                                   nullptr, accumulate, coef, stream);
 }
 
-extern "C" int dfd_version(void) { return 110; }   // see include/dfd_hip.h
+extern "C" int dfd_version(void) { return 111; }   // see include/dfd_hip.h

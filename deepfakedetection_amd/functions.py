@@ -160,9 +160,9 @@ class MBConvFunction(torch.autograd.Function):
             y2, parts, n = K.dwconv_fwd(x, None, ACT_NONE, w_dw, geom.kernel, geom.stride, geom.pad_lead, geom.pad_lead,
                                         Ho, Wo, stats=tr)
         st2 = _bn_state(parts, n, N * Ho * Wo, cfg.bn_dw, g_dw, b_dw, tr, cfg.counters)
-        pooled = K.pool_act(y2, st2, ACT_SILU)
         w1, w2 = se_w1.reshape(se_w1.shape[0], -1), se_w2.reshape(se_w2.shape[0], -1)
-        hpre, gate, w2t = K.se_fc_fwd(pooled, w1, se_b1, w2, se_b2, ACT_SILU, cfg.derived[2] if cfg.derived is not None else None)
+        pooled, hpre, gate, w2t = K.se_fwd(y2, st2, ACT_SILU, w1, se_b1, w2, se_b2, ACT_SILU,
+                                           cfg.derived[2] if cfg.derived is not None else None)
         wproj_nk, wproj_kn = cfg.derived[1] if cfg.derived is not None else K.prep_weights(w_proj, dt, True, need_bwd)
         pro = K.pro_bn_act_gate(st2, ACT_SILU, gate, Ho * Wo)
         y3, parts, n = K.pwconv(y2, pro, wproj_nk, None, stats=tr)
@@ -201,10 +201,9 @@ class MBConvFunction(torch.autograd.Function):
             with K.side_stream(N * Ho * Wo):
                 dw_proj = K.pwconv_wgrad(gb, pro_dy3, y2, pro_q, _dest(ctx, 11, (Cout, Cmid))).view(Cout, Cmid, 1, 1)
         # ---- squeeze-excite backward
-        dgate = K.pool_bwd_reduce(D, y2, st2, ACT_SILU)
         want_se = need[7] or need[8] or need[9] or need[10]
         se_outs = (_dest(ctx, 7, (R, Cmid)), _dest(ctx, 8, (R,)), _dest(ctx, 9, (Cmid, R)), _dest(ctx, 10, (Cmid,)))
-        dpooled, dw1, db1, dw2, db2 = K.se_fc_bwd(dgate, gate, hpre, pooled, w1, w2t, ACT_SILU, want_se, se_outs)
+        dpooled, dw1, db1, dw2, db2 = K.se_bwd(D, y2, st2, ACT_SILU, gate, hpre, pooled, w1, w2t, ACT_SILU, want_se, se_outs)
         if dw1 is not None:
             dw1, dw2 = dw1.view(dw1.shape[0], -1, 1, 1), dw2.view(dw2.shape[0], -1, 1, 1)
         # ---- SiLU' and depthwise BN backward

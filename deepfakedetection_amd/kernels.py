@@ -318,6 +318,48 @@ def se_fc_bwd(dgate, gate, hpre, pooled, w1, w2t, act: int, want_param_grads: bo
     return dpooled, dw1, db1, dw2, db2
 
 
+def se_fwd(y: torch.Tensor, state: torch.Tensor, act_in: int, w1, b1, w2, b2, act: int, w2t: torch.Tensor | None = None):
+    """pool_act + se_fc_fwd in two launches (dfd_se_fwd): returns pooled, hpre, gate, w2t."""
+    _chk_nhwc(y)
+    N, H, W, C = y.shape
+    R = w1.shape[0]
+    dev = y.device
+    pooled = torch.empty((N, C), dtype=torch.float32, device=dev)
+    hpre = torch.empty((N, R), dtype=torch.float32, device=dev)
+    gate = torch.empty((N, C), dtype=torch.float32, device=dev)
+    ready = w2t is not None
+    if not ready:
+        w2t = torch.empty((R, C), dtype=torch.float32, device=dev)
+    ws, ws_bytes = _pool_workspace(y, N, H * W, C)
+    check(_L().dfd_se_fwd(_dt(y), _p(y), _p(state), act_in, N, H * W, C, _p(w1), _p(b1), None if ready else _p(w2), _p(b2), R,
+                          act, _p(pooled), _p(hpre), _p(gate), _p(w2t), ws, ws_bytes, _stream()), "dfd_se_fwd", f"C={C} R={R}")
+    return pooled, hpre, gate, w2t
+
+
+def se_bwd(D, y, state, act_in: int, gate, hpre, pooled, w1, w2t, act: int, want_param_grads: bool = True,
+           outs=(None, None, None, None)):
+    """pool_bwd_reduce + se_fc_bwd in three launches (dfd_se_bwd): returns dpooled, dw1, db1, dw2, db2."""
+    _chk_nhwc(y)
+    N, H, W, C = y.shape
+    R = w1.shape[0]
+    dev = y.device
+    dpooled = torch.empty((N, C), dtype=torch.float32, device=dev)
+    dgate = scratch(dev, "se_dgate", N * C * 4)
+    ws = scratch(dev, "se_ws", (N * C + 2 * N * R) * 4)
+    if want_param_grads:
+        dw1 = _dst(outs[0], (R, C), dev)
+        db1 = _dst(outs[1], (R,), dev)
+        dw2 = _dst(outs[2], (C, R), dev)
+        db2 = _dst(outs[3], (C,), dev)
+    else:
+        dw1 = db1 = dw2 = db2 = None
+    pws, pws_bytes = _pool_workspace(y, N, H * W, C)
+    check(_L().dfd_se_bwd(_dt(y), _p(D), _p(y), _p(state), act_in, N, H * W, C, _p(gate), _p(hpre), _p(pooled), _p(w1), _p(w2t),
+                          R, act, _p(dgate), _p(dpooled), _p(dw1), _p(db1), _p(dw2), _p(db2), 0, pws, pws_bytes, _p(ws),
+                          _stream()), "dfd_se_bwd")
+    return dpooled, dw1, db1, dw2, db2
+
+
 # ------------------------------------------------------------------ depthwise
 def _dw_shape(x_shape, Ho: int, Wo: int, k: int, stride: int, pad_top: int, pad_left: int) -> DwShape:
     N, H, W, C = x_shape

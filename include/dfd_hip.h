@@ -65,7 +65,8 @@ typedef void* dfd_stream;          /* a hipStream_t */
  * dfd_pool_ws, dfd_image_prep; 102 = dfd_prep_weights_multi, dfd_se_fc_fwd accepts a prepared w2t;
  * 110 = the EfficientFormerV2 / FasterViT set (section "token mixers" below), the *_ex BatchNorm entry
  * points (convolution bias and LayerScale folded into the BatchNorm coefficients), GELU in every
- * prologue, and the bookkeeping kernels (dfd_rand, dfd_step_tick, dfd_axpby, dfd_add). */
+ * prologue, and the bookkeeping kernels (dfd_rand, dfd_step_tick, dfd_axpby, dfd_add);
+ * 111 = dfd_se_fwd / dfd_se_bwd (squeeze-excite in two / three launches). */
 int dfd_version(void);
 
 /* ---------------------------------------------------------------- BatchNorm ---
@@ -151,6 +152,22 @@ int dfd_se_fc_bwd(const float* dgate, const float* gate, const float* hpre,
                   int N, int C, int R, int act, float* dpooled,
                   float* dw1, float* db1, float* dw2, float* db2, int accumulate,
                   float* ws, dfd_stream stream);
+/* The whole squeeze-excite branch behind one call each way (reference call sites: the `x * self.se(x)` step of
+ * timm's InvertedResidual.forward / efficientnet_pytorch's MBConvBlock.forward, reached from
+ * trainers/efficientnet.py:297 `model(x)`): pooling kernel + ONE workgroup per image that adds the pooling
+ * splits and runs both FC layers (forward: 2 launches instead of 4; backward: 3 instead of 5).
+ *   forward : pooled = mean_hw act_in(scale*y+shift); hpre = W1 pooled + b1; gate = sigmoid(W2 act(hpre) + b2)
+ *   backward: dgate = sum_hw D*act_in(scale*y+shift) -> dpooled, dw1, db1, dw2, db2 (as dfd_se_fc_bwd)
+ * pool ws / ws_bytes as for dfd_pool_act; ws (backward) as for dfd_se_fc_bwd.  C % 4 == 0.               */
+int dfd_se_fwd(int dtype, const void* y, const float* bnstate, int act_in, int N, int HW, int C,
+               const float* w1, const float* b1, const float* w2, const float* b2, int R, int act,
+               float* pooled, float* hpre, float* gate, float* w2t, void* ws, size_t ws_bytes,
+               dfd_stream stream);
+int dfd_se_bwd(int dtype, const void* D, const void* y, const float* bnstate, int act_in, int N, int HW,
+               int C, const float* gate, const float* hpre, const float* pooled, const float* w1,
+               const float* w2t, int R, int act, float* dgate, float* dpooled, float* dw1, float* db1,
+               float* dw2, float* db2, int accumulate, void* pool_ws, size_t pool_ws_bytes, float* ws,
+               dfd_stream stream);
 
 /* ----------------------------------------------------------- depthwise conv ---
  * F.conv2d(groups=C) of MBConvBlock._depthwise_conv / timm conv_dw, k in {3,5},

@@ -9,6 +9,7 @@ Used to steer kernel optimisation; numbers quoted in DESIGN.md come from here.
 
 from __future__ import annotations
 
+import os
 import sys
 from pathlib import Path
 
@@ -95,6 +96,10 @@ def main() -> None:
             st = state(Cm)
             gate = torch.rand((N, Cm), device="cuda")
             pro = K.pro_bn_act_gate(st, ACT_SILU, gate, Ho * Ho)
+            if os.environ.get("NOPRO") == "1":          # what-if: activated and gated tensor materialised
+                pro = None
+            elif os.environ.get("NOPRO") == "2":        # what-if: activated tensor materialised, gate applied here
+                pro = K.pro_bn_act_gate(st, 0, gate, Ho * Ho)
             t = timeit(lambda: K.pwconv(y2, pro, w_nk, None, True))
             fl = 2.0 * M_out * b.cout * Cm
             rows.append(("pw_project", f"M{M_out} {Cm}->{b.cout}", t, M_out * (Cm + b.cout) * ES, fl))

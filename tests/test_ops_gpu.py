@@ -382,6 +382,39 @@ def test_se_fc(case):
 
 
 @pytest.mark.parametrize("rd", DT)
+@pytest.mark.parametrize("case", [(3, 56, 56, 96, 4), (5, 7, 7, 1152, 48), (4, 14, 14, 480, 20), (2, 112, 112, 32, 8)])
+def test_se_branch_in_one_call_each_way(rd, case):
+    """dfd_se_fwd / dfd_se_bwd (pooling + one workgroup per image) against the separate entry points: same
+    summation orders, so the results are identical, with and without the H*W split of the pooling kernel."""
+    K = _k()
+    N, H, W, C, Rr = case
+    g = torch.Generator().manual_seed(77)
+    y, D = dev(gen((N, H, W, C), 78, rd)), dev(gen((N, H, W, C), 79, rd))
+    st = torch.zeros((4, C))
+    st[0] = torch.rand(C, generator=g) + 0.5
+    st[1] = torch.randn(C, generator=g) * 0.1
+    st[3] = 1.0
+    st = dev(st)
+    w1 = dev(torch.randn((Rr, C), generator=g) * C ** -0.5)
+    b1 = dev(torch.randn(Rr, generator=g) * 0.1)
+    w2 = dev(torch.randn((C, Rr), generator=g) * Rr ** -0.5)
+    b2 = dev(torch.randn(C, generator=g) * 0.1)
+    pooled0 = K.pool_act(y, st, R.ACT_SILU)
+    h0, g0, w2t = K.se_fc_fwd(pooled0, w1, b1, w2, b2, R.ACT_SILU)
+    for prepared in (None, w2t):
+        pooled, hpre, gate, w2t1 = K.se_fwd(y, st, R.ACT_SILU, w1, b1, w2, b2, R.ACT_SILU, prepared)
+        for a, b, name in ((pooled, pooled0, "pooled"), (hpre, h0, "hpre"), (gate, g0, "gate"), (w2t1, w2t, "w2t")):
+            assert torch.equal(a, b), name
+    dgate = K.pool_bwd_reduce(D, y, st, R.ACT_SILU)
+    want = K.se_fc_bwd(dgate, g0, h0, pooled0, w1, w2t, R.ACT_SILU)
+    got = K.se_bwd(D, y, st, R.ACT_SILU, g0, h0, pooled0, w1, w2t, R.ACT_SILU)
+    for a, b, name in zip(got, want, ("dpooled", "dw1", "db1", "dw2", "db2")):
+        assert torch.equal(a, b), name
+    dp_only = K.se_bwd(D, y, st, R.ACT_SILU, g0, h0, pooled0, w1, w2t, R.ACT_SILU, want_param_grads=False)
+    assert torch.equal(dp_only[0], want[0]) and dp_only[1] is None
+
+
+@pytest.mark.parametrize("rd", DT)
 @pytest.mark.parametrize("case", [(2, 32, 32, 32, 0), (2, 33, 31, 40, 1), (1, 224, 224, 32, 1)])
 def test_stem(case, rd):
     K = _k()
