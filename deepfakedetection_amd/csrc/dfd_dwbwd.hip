@@ -12,9 +12,12 @@
 // staged-column map is a compile-time table once the parity of pad_left is a template
 // parameter (PLP).
 #include "dfd_dwq.h"
+#ifndef DFD_ABLATE
+#define DFD_ABLATE 0   // timing experiments (scripts/build_variant.sh): 1 = staging only, 2 = taps only
+#endif
 
 // stage dy = ka*dz + kb*y + kc (or dz as is) for rows gy0.., cols gx0.. of the [SH][SW] dy image
-template <typename T, bool COEF>
+template <typename T, bool COEF, int U = 4>
 __device__ __forceinline__ void stage_dy(uint4* __restrict__ tile, const T* __restrict__ dz, const T* __restrict__ yraw,
                                          const float* __restrict__ cf, int cvbV, int vl, long img_base, int SH, int SW, int C,
                                          int c0, bool cvalid, int gy0, int gx0, int IH, int IW, unsigned magic, int cvb_log2) {
@@ -29,11 +32,11 @@ __device__ __forceinline__ void stage_dy(uint4* __restrict__ tile, const T* __re
         }
     }
     const int total = (IH * IW) << cvb_log2;
-    for (int base = threadIdx.x; base < total; base += DFD_THREADS * 4) {
-        uint4 r1[4], r2[4];
-        bool inb[4];
+    for (int base = threadIdx.x; base < total; base += DFD_THREADS * U) {
+        uint4 r1[U], r2[U];
+        bool inb[U];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < U; ++u) {
             const int idx = base + u * DFD_THREADS;
             const int pix = idx >> cvb_log2;
             const int iy = (int)(((unsigned)pix * magic) >> 20);
@@ -47,7 +50,7 @@ __device__ __forceinline__ void stage_dy(uint4* __restrict__ tile, const T* __re
             }
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < U; ++u) {
             const int idx = base + u * DFD_THREADS;
             if (idx >= total) continue;
             uint4 q = make_uint4(0, 0, 0, 0);
@@ -119,10 +122,15 @@ k_dw_bwd_data_q(const T* __restrict__ dz, const T* __restrict__ yraw, const floa
         const int sy0 = (S == 1) ? ny : (ny >= 0 ? ny / 2 : -((-ny + 1) / 2));
         const int sx0 = (S == 1) ? nx : (nx >= 0 ? nx / 2 : -((-nx + 1) / 2));
         __syncthreads();
-        stage_dy<T, COEF>(tile, dz, yraw, cf, cvbV, vl, (long)n * g.Ho * g.Wo * g.C, g.Ho, g.Wo, g.C, c0, cvalid, sy0, sx0,
+#if DFD_ABLATE != 2
+        stage_dy<T, COEF, StageDepth<K, S>::DY>(tile, dz, yraw, cf, cvbV, vl, (long)n * g.Ho * g.Wo * g.C, g.Ho, g.Wo, g.C, c0, cvalid, sy0, sx0,
                           g.IH, g.IW, g.iw_magic, g.cvb_log2);
+#endif
         __syncthreads();
         if (!cvalid) continue;
+#if DFD_ABLATE == 1
+        continue;
+#endif
 #pragma unroll 1
         for (int q = lane; q < g.NQ; q += PL) {
             const int qy = (int)(((unsigned)q * g.qw_magic) >> 20), qx = q - qy * g.QW;
@@ -341,10 +349,10 @@ k_dw_bwd_weight_q(const T* __restrict__ dz, const T* __restrict__ yraw, const fl
                 sc[j] = *reinterpret_cast<const f2*>(cf + 3 * cvbV + vl * V + 2 * j);
                 sh[j] = *reinterpret_cast<const f2*>(cf + 4 * cvbV + vl * V + 2 * j);
             }
-            stage_q<T, ACT, PRO>(tile, xin, sc, sh, (long)n * g.H * g.W * g.C, g.H, g.W, g.C, c0, cvalid, oy0 * S - g.pt,
+            stage_q<T, ACT, PRO, (K == 3 ? 8 : 4)>(tile, xin, sc, sh, (long)n * g.H * g.W * g.C, g.H, g.W, g.C, c0, cvalid, oy0 * S - g.pt,
                                  ox0 * S - g.pl, g.IH, g.IW, g.iw_magic, g.cvb_log2);
         }
-        stage_dy<T, COEF>(dyt, dz, yraw, cf, cvbV, vl, (long)n * g.Ho * g.Wo * g.C, g.Ho, g.Wo, g.C, c0, cvalid, oy0, ox0,
+        stage_dy<T, COEF, StageDepth<K, S>::DY>(dyt, dz, yraw, cf, cvbV, vl, (long)n * g.Ho * g.Wo * g.C, g.Ho, g.Wo, g.C, c0, cvalid, oy0, ox0,
                           g.TH, TW, tw_magic, g.cvb_log2);
         __syncthreads();
         if (!cvalid || !lane_on) continue;

@@ -60,7 +60,7 @@ k_dw_fwd_q(const T* __restrict__ x, const float* __restrict__ bnstate, const flo
                 sc[j] = *reinterpret_cast<const f2*>(cf + vl * V + 2 * j);
                 sh[j] = *reinterpret_cast<const f2*>(cf + cvb * V + vl * V + 2 * j);
             }
-            stage_q<T, ACT, PRO>(tile, x, sc, sh, (long)n * g.H * g.W * g.C, g.H, g.W, g.C, c0, cvalid, oy0 * S - g.pt,
+            stage_q<T, ACT, PRO, StageDepth<K, S>::X>(tile, x, sc, sh, (long)n * g.H * g.W * g.C, g.H, g.W, g.C, c0, cvalid, oy0 * S - g.pt,
                                  ox0 * S - g.pl, g.IH, g.IW, g.iw_magic, g.cvb_log2);
         }
         __syncthreads();

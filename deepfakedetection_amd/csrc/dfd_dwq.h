@@ -4,6 +4,15 @@
 
 typedef float f2 __attribute__((ext_vector_type(2)));
 
+// 16-byte vectors a lane requests before it touches the first one while staging a tile (a tile is at most ~10
+// vectors per lane and tensor).  Measured per layer on MI355X (scripts/bench_layers.py): the 3x3 kernels gain up
+// to 30 % from 6-8 in flight (fewer exposed memory round trips per work item); the 5x5 kernels sit at the
+// 128-VGPR cap of four workgroups per CU and lose to the spills, so they keep 4.
+template <int K, int S> struct StageDepth {
+    static constexpr int X = (K == 3 && S == 1) ? 8 : 4;     // one tensor (input tile)
+    static constexpr int DY = (K == 3) ? 6 : 4;              // two tensors (dz and y of the BN-backward map)
+};
+
 struct DwQGeom {
     int N, H, W, C, Ho, Wo, pt, pl;
     int CV, cvb_log2;
@@ -65,17 +74,17 @@ bool dfd_dwq_geom(const dfd_dwconv_shape* s, int vec, int max_cvb, bool centre_i
                   int extra_centre, int lane_div, DwQGeom* g, int* tile_bytes);
 
 // stage the input tile: tile[pix][vl] = rnd(act(scale*x+shift)) or x, zero outside the image
-template <typename T, int ACT, bool PRO>
+template <typename T, int ACT, bool PRO, int U = 4>
 __device__ __forceinline__ void stage_q(uint4* __restrict__ tile, const T* __restrict__ src, const f2 (&sc)[V2<T>::N],
                                         const f2 (&sh)[V2<T>::N], long img_base, int SH, int SW, int C, int c0, bool cvalid,
                                         int gy0, int gx0, int IH, int IW, unsigned magic, int cvb_log2) {
     constexpr int N2 = V2<T>::N;
     const int total = (IH * IW) << cvb_log2;
-    for (int base = threadIdx.x; base < total; base += DFD_THREADS * 4) {
-        uint4 raw[4];
-        bool inb[4];
+    for (int base = threadIdx.x; base < total; base += DFD_THREADS * U) {
+        uint4 raw[U];
+        bool inb[U];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < U; ++u) {
             const int idx = base + u * DFD_THREADS;
             const int pix = idx >> cvb_log2;
             const int iy = (int)(((unsigned)pix * magic) >> 20);
@@ -85,7 +94,7 @@ __device__ __forceinline__ void stage_q(uint4* __restrict__ tile, const T* __res
             if (inb[u]) raw[u] = *reinterpret_cast<const uint4*>(src + img_base + ((long)gy * SW + gx) * C + c0);
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < U; ++u) {
             const int idx = base + u * DFD_THREADS;
             if (idx >= total) continue;
             uint4 q = make_uint4(0, 0, 0, 0);
