@@ -113,7 +113,8 @@ SIGNATURES: dict[str, tuple] = {
     "dfd_layernorm_bwd": (c_int, [c_int, P, P, P, P, P, P, c_int, _PI, c_long, c_int, P]),
     "dfd_copy_rows": (c_int, [c_int, P, P, P, P, c_long, c_int, P]),
     "dfd_add_rowtable": (c_int, [c_int, P, P, P, c_long, c_int, c_int, P]),
-    "dfd_rowtable_grad": (c_int, [c_int, P, P, c_long, c_int, c_int, c_int, P]),
+    "dfd_rowtable_grad_ws": (c_size_t, [c_int, c_int]),
+    "dfd_rowtable_grad": (c_int, [c_int, P, P, c_long, c_int, c_int, c_int, P, c_size_t, P]),
     "dfd_avgpool_fwd": (c_int, [c_int, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "dfd_avgpool_bwd": (c_int, [c_int, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "dfd_relpos_bias_fwd": (c_int, [P, P, P, c_int, c_int, c_int, P]),

@@ -692,9 +692,27 @@ k_linear_fwd(const float* __restrict__ x, const float* __restrict__ w, const flo
         if (lane == 0) out[(long)n * J + j] = s + (b ? b[j] : 0.f);
     }
 }
+// few input features (the coordinate MLPs' Linear(2, 512)): one lane per output, no cross-lane reduction
+__global__ void __launch_bounds__(DFD_THREADS)
+k_linear_fwd_smallk(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b,
+                    float* __restrict__ out, long total, int K, int J) {
+    const long i = (long)blockIdx.x * DFD_THREADS + threadIdx.x;
+    if (i >= total) return;
+    const long n = i / J;
+    const int j = (int)(i - n * J);
+    float s = 0.f;
+    for (int k = 0; k < K; ++k) s = fmaf(x[n * K + k], w[(long)j * K + k], s);
+    out[i] = s + (b ? b[j] : 0.f);
+}
 extern "C" int dfd_linear_fwd(const float* x, const float* w, const float* b, float* out, int N, int K, int J,
                               dfd_stream stream) {
     if (!x || !w || !out || N < 1 || K < 1 || J < 1) return DFD_EINVAL;
+    if (K <= 16) {
+        const long total = (long)N * J;
+        hipLaunchKernelGGL(k_linear_fwd_smallk, dim3((unsigned)((total + DFD_THREADS - 1) / DFD_THREADS)), dim3(DFD_THREADS), 0,
+                           (hipStream_t)stream, x, w, b, out, total, K, J);
+        return DFD_CHECK_LAUNCH();
+    }
     hipLaunchKernelGGL(k_linear_fwd, dim3(N), dim3(DFD_THREADS), 0, (hipStream_t)stream, x, w, b, out, K, J);
     return DFD_CHECK_LAUNCH();
 }

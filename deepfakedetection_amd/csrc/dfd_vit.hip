@@ -1291,30 +1291,72 @@ extern "C" int dfd_add_rowtable(int dtype, const void* x, const float* table, vo
     } else return DFD_EINVAL;
     return DFD_CHECK_LAUNCH();
 }
-// dtable[t][c] = sum_w g[w*T + t][c]   (f32 output; a workgroup per (t, channel chunk), fixed order over w)
+// dtable[t][c] = sum_w g[w*T + t][c]   (f32 output).  grid (t, channel chunk, split of the window range): a lane owns one
+// 16-byte channel vector and every rpb-th window of its split, four loads in flight; the row lanes are combined in a
+// fixed order, the splits by dfd_launch_sum_partials.
+#define ROWTAB_MAX_SPLITS 32
 template <typename T>
 __global__ void __launch_bounds__(DFD_THREADS)
-k_rowtable_grad(const T* __restrict__ g, float* __restrict__ dtable, long nw, int Tn, int C, int accumulate) {
-    const int t = blockIdx.x;
-    for (int c = blockIdx.y * DFD_THREADS + threadIdx.x; c < C; c += gridDim.y * DFD_THREADS) {
-        float s = 0.f;
-        for (long w = 0; w < nw; ++w) {
-            const T* p = g + (w * Tn + t) * C + c;
-            if constexpr (sizeof(T) == 2) s += bf2f(reinterpret_cast<const unsigned short*>(p)[0]);
-            else s += reinterpret_cast<const float*>(p)[0];
+k_rowtable_grad(const T* __restrict__ g, float* __restrict__ parts, long nw, int Tn, int C, ChanMap cm, long w_per) {
+    constexpr int V = Vec<T>::N;
+    __shared__ float red[DFD_THREADS * V];
+    const int tid = threadIdx.x, vl = tid % cm.cvb, rl = tid / cm.cvb;
+    const bool active = rl < cm.rpb;
+    const int t = blockIdx.x, c0 = (blockIdx.y * cm.cvb + vl) * V;
+    const long w_beg = (long)blockIdx.z * w_per;
+    long w_end = w_beg + w_per;
+    if (w_end > nw) w_end = nw;
+    float acc[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) acc[j] = 0.f;
+    if (active) {
+        const T* base = g + (long)t * C + c0;
+        const long step = (long)Tn * C;
+        long w = w_beg + rl;
+        for (; w + 3 * cm.rpb < w_end; w += 4 * cm.rpb) {
+            float v[4][V];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) Vec<T>::load(base + (w + (long)u * cm.rpb) * step, v[u]);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int j = 0; j < V; ++j) acc[j] += v[u][j];
         }
-        float* o = dtable + (long)t * C + c;
-        *o = (accumulate ? *o : 0.f) + s;
+        for (; w < w_end; w += cm.rpb) {
+            float v[V];
+            Vec<T>::load(base + w * step, v);
+#pragma unroll
+            for (int j = 0; j < V; ++j) acc[j] += v[j];
+        }
     }
+    reduce_rowlanes<V>(acc, red, cm.cvb, cm.rpb, vl, rl, active);
+    if (rl == 0) store_f32<V>(parts + ((long)blockIdx.z * Tn + t) * C + c0, acc);
 }
-extern "C" int dfd_rowtable_grad(int dtype, const void* g, float* dtable, long rows, int T, int C, int accumulate, dfd_stream stream) {
-    if (!g || !dtable || rows < 1 || T < 1 || rows % T || C < 1) return DFD_EINVAL;
+static int rowtable_splits(long nw, int Tn, int C, int vec) {
+    const ChanMap cm = make_chanmap(C, vec);
+    long s = 2048 / ((long)Tn * cm.nvc > 0 ? (long)Tn * cm.nvc : 1);
+    const long max_s = nw / ((long)cm.rpb * 4);
+    if (s > max_s) s = max_s;
+    if (s > ROWTAB_MAX_SPLITS) s = ROWTAB_MAX_SPLITS;
+    return s < 1 ? 1 : (int)s;
+}
+extern "C" size_t dfd_rowtable_grad_ws(int T, int C) { return (size_t)(ROWTAB_MAX_SPLITS + 2) * T * C * sizeof(float); }
+extern "C" int dfd_rowtable_grad(int dtype, const void* g, float* dtable, long rows, int T, int C, int accumulate, float* ws,
+                                 size_t ws_bytes, dfd_stream stream) {
+    if (!g || !dtable || !ws || rows < 1 || T < 1 || rows % T || C < 1 || (dtype != DFD_BF16 && dtype != DFD_F32)) return DFD_EINVAL;
+    const int vec = dtype == DFD_BF16 ? Vec<bf16>::N : Vec<float>::N;
+    if (C % vec) return DFD_EINVAL;
+    if (ws_bytes < dfd_rowtable_grad_ws(T, C)) return DFD_EWORKSPACE;
     hipStream_t st = (hipStream_t)stream;
-    const dim3 grid(T, (C + DFD_THREADS - 1) / DFD_THREADS);
-    if (dtype == DFD_BF16) hipLaunchKernelGGL((k_rowtable_grad<bf16>), grid, dim3(DFD_THREADS), 0, st, (const bf16*)g, dtable, rows / T, T, C, accumulate);
-    else if (dtype == DFD_F32) hipLaunchKernelGGL((k_rowtable_grad<float>), grid, dim3(DFD_THREADS), 0, st, (const float*)g, dtable, rows / T, T, C, accumulate);
-    else return DFD_EINVAL;
-    return DFD_CHECK_LAUNCH();
+    const long nw = rows / T;
+    const ChanMap cm = make_chanmap(C, vec);
+    const int splits = rowtable_splits(nw, T, C, vec);
+    const long w_per = (nw + splits - 1) / splits;
+    const dim3 grid(T, cm.nvc, splits);
+    if (dtype == DFD_BF16) hipLaunchKernelGGL((k_rowtable_grad<bf16>), grid, dim3(DFD_THREADS), 0, st, (const bf16*)g, ws, nw, T, C, cm, w_per);
+    else hipLaunchKernelGGL((k_rowtable_grad<float>), grid, dim3(DFD_THREADS), 0, st, (const float*)g, ws, nw, T, C, cm, w_per);
+    if (hipGetLastError() != hipSuccess) return DFD_ELAUNCH;
+    return dfd_launch_sum_partials(ws, splits, (long)T * C, dtable, accumulate, st);
 }
 
 // average pooling k x k, stride s, no padding (TokenInitializer's AvgPool2d(5, 3)) and its gradient

@@ -807,7 +807,10 @@ def add_rowtable(x: torch.Tensor, table: torch.Tensor) -> torch.Tensor:
 def rowtable_grad(g: torch.Tensor, T: int) -> torch.Tensor:
     C = g.shape[-1]
     dtable = torch.empty((T, C), dtype=torch.float32, device=g.device)
-    check(_L().dfd_rowtable_grad(_dt(g), _p(g), _p(dtable), g.numel() // C, T, C, 0, _stream()), "dfd_rowtable_grad")
+    nbytes = int(_L().dfd_rowtable_grad_ws(T, C))
+    ws = scratch(g.device, "rowtable_ws", nbytes)
+    check(_L().dfd_rowtable_grad(_dt(g), _p(g), _p(dtable), g.numel() // C, T, C, 0, _p(ws), nbytes, _stream()),
+          "dfd_rowtable_grad")
     return dtable
 
 

@@ -66,7 +66,7 @@ typedef void* dfd_stream;          /* a hipStream_t */
  * 110 = the EfficientFormerV2 / FasterViT set (section "token mixers" below), the *_ex BatchNorm entry
  * points (convolution bias and LayerScale folded into the BatchNorm coefficients), GELU in every
  * prologue, and the bookkeeping kernels (dfd_rand, dfd_step_tick, dfd_axpby, dfd_add);
- * 111 = dfd_se_fwd / dfd_se_bwd (squeeze-excite in two / three launches). */
+ * 111 = dfd_se_fwd / dfd_se_bwd (squeeze-excite in two / three launches); dfd_rowtable_grad takes a workspace. */
 int dfd_version(void);
 
 /* ---------------------------------------------------------------- BatchNorm ---
@@ -363,8 +363,9 @@ int dfd_copy_rows(int dtype, const void* src, const int* sidx, void* dst, const 
 /* PosEmbMLPSwinv1D: out[r] = x[r] + table[r % T] (table f32 [T][C]); dtable[t] = sum_w g[w*T + t]              */
 int dfd_add_rowtable(int dtype, const void* x, const float* table, void* out, long rows, int T, int C,
                      dfd_stream stream);
+size_t dfd_rowtable_grad_ws(int T, int C);       /* bytes of scratch for dfd_rowtable_grad (no initial contents required) */
 int dfd_rowtable_grad(int dtype, const void* g, float* dtable, long rows, int T, int C, int accumulate,
-                      dfd_stream stream);
+                      float* ws, size_t ws_bytes, dfd_stream stream);
 /* nn.AvgPool2d(k, stride) without padding on NHWC (TokenInitializer) and its gradient (dx [N][H][W][C])         */
 int dfd_avgpool_fwd(int dtype, const void* x, void* out, int N, int H, int W, int k, int stride, int C,
                     dfd_stream stream);
