@@ -679,17 +679,25 @@ extern "C" int dfd_dropout(const float* x, const float* u, float p, float* out, 
     return DFD_CHECK_LAUNCH();
 }
 
+// grid (N, ceil(J / 16)): a workgroup owns 16 outputs of one row, a wave four of them (independent dot products,
+// each summed in wave_dot's order)
 __global__ void __launch_bounds__(DFD_THREADS)
 k_linear_fwd(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b, float* __restrict__ out,
              int K, int J) {
     const int n = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float* xr = x + (long)n * K;
-    for (int j = wave; j < J; j += 4) {
-        const float* wr = w + (long)j * K;
-        float s = 0.f;
-        for (int k = lane; k < K; k += 64) s = fmaf(xr[k], wr[k], s);
-        s = wave_sum(s);
-        if (lane == 0) out[(long)n * J + j] = s + (b ? b[j] : 0.f);
+    const int j0 = blockIdx.y * 16 + wave * 4;
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int k = lane; k < K; k += 64) {
+        const float xv = xr[k];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (j0 + u < J) s[u] = fmaf(xv, w[(long)(j0 + u) * K + k], s[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const float r = wave_sum(s[u]);
+        if (lane == 0 && j0 + u < J) out[(long)n * J + j0 + u] = r + (b ? b[j0 + u] : 0.f);
     }
 }
 // few input features (the coordinate MLPs' Linear(2, 512)): one lane per output, no cross-lane reduction
@@ -713,16 +721,31 @@ extern "C" int dfd_linear_fwd(const float* x, const float* w, const float* b, fl
                            (hipStream_t)stream, x, w, b, out, total, K, J);
         return DFD_CHECK_LAUNCH();
     }
-    hipLaunchKernelGGL(k_linear_fwd, dim3(N), dim3(DFD_THREADS), 0, (hipStream_t)stream, x, w, b, out, K, J);
+    hipLaunchKernelGGL(k_linear_fwd, dim3(N, (J + 15) / 16), dim3(DFD_THREADS), 0, (hipStream_t)stream, x, w, b, out, K, J);
     return DFD_CHECK_LAUNCH();
 }
 
-__global__ void k_linear_bwd_x(const float* __restrict__ dout, const float* __restrict__ w, float* __restrict__ dx, int K, int J) {
-    const int n = blockIdx.y, k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= K) return;
+// grid (ceil(K / 64), N), 256 threads: wave q sums every 4th output feature for its 64 input features; the four
+// partial sums are combined in wave order
+__global__ void __launch_bounds__(DFD_THREADS)
+k_linear_bwd_x(const float* __restrict__ dout, const float* __restrict__ w, float* __restrict__ dx, int K, int J) {
+    __shared__ float red[4][64];
+    const int n = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, k = blockIdx.x * 64 + lane;
     float s = 0.f;
-    for (int j = 0; j < J; ++j) s = fmaf(dout[(long)n * J + j], w[(long)j * K + k], s);
-    dx[(long)n * K + k] = s;
+    if (k < K) {
+        int j = wave;
+        for (; j + 12 < J; j += 16) {
+            float d[4], wv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { d[u] = dout[(long)n * J + j + 4 * u]; wv[u] = w[(long)(j + 4 * u) * K + k]; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) s = fmaf(d[u], wv[u], s);
+        }
+        for (; j < J; j += 4) s = fmaf(dout[(long)n * J + j], w[(long)j * K + k], s);
+    }
+    red[wave][lane] = s;
+    __syncthreads();
+    if (wave == 0 && k < K) dx[(long)n * K + k] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
 }
 __global__ void k_linear_bwd_w(const float* __restrict__ dout, const float* __restrict__ x, float* __restrict__ dw,
                                float* __restrict__ db, int N, int K, int J, int accumulate) {
@@ -753,7 +776,7 @@ extern "C" int dfd_linear_bwd(const float* dout, const float* x, const float* w,
     hipStream_t st = (hipStream_t)stream;
     if (dx) {
         if (!w) return DFD_EINVAL;
-        hipLaunchKernelGGL(k_linear_bwd_x, dim3((K + 255) / 256, N), dim3(256), 0, st, dout, w, dx, K, J);
+        hipLaunchKernelGGL(k_linear_bwd_x, dim3((K + 63) / 64, N), dim3(DFD_THREADS), 0, st, dout, w, dx, K, J);
     }
     if (dw) {
         if (!x) return DFD_EINVAL;
