@@ -354,6 +354,28 @@ def test_bn_finalize_and_eval(case):
     close(st2, torch.stack([gamma * rstd, beta - rm * gamma * rstd, rm, rstd]), 1e-5, "bn_eval")
 
 
+@pytest.mark.parametrize("rd", DT)
+def test_bn_statistics_with_a_large_mean(rd):
+    """Variance is E[x^2] - mean^2 from f32 partial sums combined in double: bound the loss for a
+    channel whose mean is 30x its standard deviation, at the largest row count of the benchmark (N*H*W = 3.2 M)."""
+    K = _k()
+    N, H, W, C = 16, 448, 448, 16
+    g = torch.Generator().manual_seed(61)
+    x = (torch.randn((N, H, W, C), generator=g) + 30.0).to(rd)
+    w = torch.zeros((C, 1, 3, 3))
+    w[:, 0, 1, 1] = 1.0                                    # identity depthwise conv: y = x, statistics of x
+    gamma, beta = torch.ones(C), torch.zeros(C)
+    bn = K.BNParams(dev(gamma), dev(beta), dev(torch.zeros(C)), dev(torch.ones(C)), 0.1, 1e-5)
+    y, parts, n = K.dwconv_fwd(dev(x), None, 0, dev(w), 3, 1, 1, 1, H, W, stats=True)
+    st = K.bn_finalize(parts, n, N * H * W, bn).cpu()
+    flat = x.float().reshape(-1, C).double()
+    mean, var = flat.mean(0), flat.var(0, unbiased=False)
+    assert torch.allclose(st[2].double(), mean, rtol=0, atol=1e-4), (st[2].double() - mean).abs().max()
+    rstd = 1.0 / torch.sqrt(var + 1e-5)
+    rel = ((st[3].double() - rstd).abs() / rstd).max().item()
+    assert rel < 2e-3, rel
+
+
 @pytest.mark.parametrize("case", [(4, 32, 8), (3, 1152, 48), (2, 96, 4), (5, 2304, 96)])
 def test_se_fc(case):
     K = _k()
