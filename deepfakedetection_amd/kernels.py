@@ -104,14 +104,24 @@ def _chk_nhwc(t: torch.Tensor) -> None:
 
 def scratch(device: torch.device, name: str, nbytes: int) -> torch.Tensor:
     """A grow-only f32 scratch buffer per (device, stream, purpose): reuse is ordered by the stream it belongs to,
-    so two models / threads on different streams never share a buffer (the C ABI itself is re-entrant)."""
+    so two models / threads on different streams never share a buffer (the C ABI itself is re-entrant).
+
+    While the stream is being captured into a hipGraph the buffer is a fresh allocation instead: it comes from the
+    graph's private pool, which lives exactly as long as the graph.  A cached buffer would be recorded by address and
+    could later be replaced (grown) and freed by code outside the graph while replays still write to it."""
+    need = (nbytes + 3) // 4
+    if torch.cuda.is_current_stream_capturing():
+        return torch.empty(max(need, 1), dtype=torch.float32, device=device)
     key = (device.index if device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream, name)
     buf = _scratch.get(key)
-    need = (nbytes + 3) // 4
     if buf is None or buf.numel() < need:
         buf = torch.empty(max(need, 1), dtype=torch.float32, device=device)
         _scratch[key] = buf
     return buf
+
+
+def _nbytes(t: torch.Tensor | None) -> int:
+    return 0 if t is None else t.numel() * t.element_size()
 
 
 def _dst(out: torch.Tensor | None, shape, device) -> torch.Tensor:
@@ -223,28 +233,23 @@ def act_bn_bwd(D: torch.Tensor | None, y: torch.Tensor, gate: torch.Tensor | Non
     return dz, parts, n.value
 
 
-_pool_ws: dict[tuple[int, int], torch.Tensor] = {}
 
 
-def _pool_workspace(y: torch.Tensor, N: int, HW: int, C: int) -> tuple[int, int]:
-    """(pointer, bytes) of the pooling workspace (partial vectors of the H*W splits), one per device."""
+def _pool_workspace(y: torch.Tensor, N: int, HW: int, C: int) -> torch.Tensor | None:
+    """The pooling workspace (partial vectors of the H*W splits) as a tensor the caller keeps alive across the launch;
+    None when the shape needs none."""
     nbytes = int(_L().dfd_pool_ws(_dt(y), N, HW, C))
     if nbytes == 0:
-        return 0, 0
-    key = (y.device.index if y.device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream)
-    buf = _pool_ws.get(key)
-    if buf is None or buf.numel() * 4 < nbytes:
-        buf = torch.zeros((nbytes + 3) // 4, dtype=torch.float32, device=y.device)
-        _pool_ws[key] = buf
-    return buf.data_ptr(), buf.numel() * 4
+        return None
+    return scratch(y.device, "pool_ws", nbytes)
 
 
 def pool_act(y: torch.Tensor, state: torch.Tensor, act: int) -> torch.Tensor:
     _chk_nhwc(y)
     N, H, W, C = y.shape
     pooled = torch.empty((N, C), dtype=torch.float32, device=y.device)
-    ws, ws_bytes = _pool_workspace(y, N, H * W, C)
-    check(_L().dfd_pool_act(_dt(y), _p(y), _p(state), act, _p(pooled), N, H * W, C, ws, ws_bytes, _stream()), "dfd_pool_act")
+    ws = _pool_workspace(y, N, H * W, C)
+    check(_L().dfd_pool_act(_dt(y), _p(y), _p(state), act, _p(pooled), N, H * W, C, _p(ws), _nbytes(ws), _stream()), "dfd_pool_act")
     return pooled
 
 
@@ -252,8 +257,8 @@ def pool_bwd_reduce(D: torch.Tensor, y: torch.Tensor, state: torch.Tensor, act: 
     _chk_nhwc(y)
     N, H, W, C = y.shape
     dgate = torch.empty((N, C), dtype=torch.float32, device=y.device)
-    ws, ws_bytes = _pool_workspace(y, N, H * W, C)
-    check(_L().dfd_pool_bwd_reduce(_dt(y), _p(D), _p(y), _p(state), act, _p(dgate), N, H * W, C, ws, ws_bytes, _stream()),
+    ws = _pool_workspace(y, N, H * W, C)
+    check(_L().dfd_pool_bwd_reduce(_dt(y), _p(D), _p(y), _p(state), act, _p(dgate), N, H * W, C, _p(ws), _nbytes(ws), _stream()),
           "dfd_pool_bwd_reduce")
     return dgate
 
@@ -330,9 +335,9 @@ def se_fwd(y: torch.Tensor, state: torch.Tensor, act_in: int, w1, b1, w2, b2, ac
     ready = w2t is not None
     if not ready:
         w2t = torch.empty((R, C), dtype=torch.float32, device=dev)
-    ws, ws_bytes = _pool_workspace(y, N, H * W, C)
+    ws = _pool_workspace(y, N, H * W, C)
     check(_L().dfd_se_fwd(_dt(y), _p(y), _p(state), act_in, N, H * W, C, _p(w1), _p(b1), None if ready else _p(w2), _p(b2), R,
-                          act, _p(pooled), _p(hpre), _p(gate), _p(w2t), ws, ws_bytes, _stream()), "dfd_se_fwd", f"C={C} R={R}")
+                          act, _p(pooled), _p(hpre), _p(gate), _p(w2t), _p(ws), _nbytes(ws), _stream()), "dfd_se_fwd", f"C={C} R={R}")
     return pooled, hpre, gate, w2t
 
 
@@ -353,9 +358,9 @@ def se_bwd(D, y, state, act_in: int, gate, hpre, pooled, w1, w2t, act: int, want
         db2 = _dst(outs[3], (C,), dev)
     else:
         dw1 = db1 = dw2 = db2 = None
-    pws, pws_bytes = _pool_workspace(y, N, H * W, C)
+    pws = _pool_workspace(y, N, H * W, C)
     check(_L().dfd_se_bwd(_dt(y), _p(D), _p(y), _p(state), act_in, N, H * W, C, _p(gate), _p(hpre), _p(pooled), _p(w1), _p(w2t),
-                          R, act, _p(dgate), _p(dpooled), _p(dw1), _p(db1), _p(dw2), _p(db2), 0, pws, pws_bytes, _p(ws),
+                          R, act, _p(dgate), _p(dpooled), _p(dw1), _p(db1), _p(dw2), _p(db2), 0, _p(pws), _nbytes(pws), _p(ws),
                           _stream()), "dfd_se_bwd")
     return dpooled, dw1, db1, dw2, db2
 
