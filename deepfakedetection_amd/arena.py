@@ -16,9 +16,14 @@ it into the slot in place.
 
 from __future__ import annotations
 
+import weakref
+
 import torch
 
-_registry: dict[int, tuple["GradArena", int]] = {}
+# parameter address -> (weak reference to the arena that owns a slot for it, slot index).  Weak: an arena lives as long
+# as its optimizer; a dead optimizer must neither keep its model's parameters alive nor answer for a new tensor that
+# happens to get the same address.
+_registry: dict[int, tuple["weakref.ReferenceType[GradArena]", int]] = {}
 
 
 class GradArena:
@@ -35,8 +40,9 @@ class GradArena:
         self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
         self.slots = [self.flat[o:o + p.numel()] for o, p in zip(self.offsets, self.params)]
         self.written = [False] * len(self.params)
+        me = weakref.ref(self)
         for i, p in enumerate(self.params):
-            _registry[p.data_ptr()] = (self, i)
+            _registry[p.data_ptr()] = (me, i)
 
     def reset(self) -> None:
         self.written = [False] * len(self.params)
@@ -47,8 +53,16 @@ class GradArena:
 
     def release(self) -> None:
         for p in self.params:
-            if _registry.get(p.data_ptr(), (None, 0))[0] is self:
+            hit = _registry.get(p.data_ptr())
+            if hit is not None and hit[0]() is self:
                 del _registry[p.data_ptr()]
+
+    def __del__(self) -> None:
+        try:
+            for ptr in [k for k, (ref, _) in _registry.items() if ref() is None or ref() is self]:
+                del _registry[ptr]
+        except Exception:  # noqa: BLE001 - interpreter shutdown
+            pass
 
 
 def grad_dest(param_ptr: int, shape) -> torch.Tensor | None:
@@ -57,7 +71,10 @@ def grad_dest(param_ptr: int, shape) -> torch.Tensor | None:
     hit = _registry.get(param_ptr)
     if hit is None:
         return None
-    arena, i = hit
+    arena, i = hit[0](), hit[1]
+    if arena is None:
+        del _registry[param_ptr]
+        return None
     if arena.written[i]:
         return None
     arena.written[i] = True

@@ -2,10 +2,11 @@
 
     python scripts/make_profile_summary.py <tag> <gpurun_out/prof_TAG dir> <gpurun_out/pmc_TAG dir> <bench default json>
 
-Inputs: `rocprofv3 --kernel-trace --stats` of `bench.py --steps 10 --warmup 2 ...` (kernel stats csv),
-four `rocprofv3 --pmc` passes of `bench.py --steps 2 --warmup 1 --no-graph ...` (FETCH_SIZE | WRITE_SIZE |
-TCC_EA0_RDREQ_* | TCC_EA0_WRREQ_*), and the JSON line of a plain `python bench.py`.
-Outputs: profiles/<tag>_bench_kernel_stats.csv, _pmc_traffic.json, _bench_default_line.json, _summary.md."""
+Inputs: `rocprofv3 --kernel-trace --stats` of `bench.py --steps 10 --warmup 2 ...` (kernel stats csv,
+scripts/profile_round.sh), five `rocprofv3 --pmc` passes of `bench.py --steps 2 --warmup 1 --no-graph ...`
+(FETCH_SIZE | WRITE_SIZE | TCC_EA0_RDREQ_* | TCC_EA0_WRREQ_* | SQ/GRBM group; scripts/profile_pmc.sh), and the JSON
+line of a plain `python bench.py`.
+Outputs: profiles/<tag>_bench_kernel_stats.csv, _pmc_traffic.json, _pmc_sq.json, _bench_default_line.json, _summary.md."""
 import collections
 import csv
 import json
@@ -30,7 +31,8 @@ def family(name):
     return "other"
 
 
-stats = list(csv.DictReader(open(next(prof_dir.glob("*kernel_stats.csv")))))
+stats_path = next(iter(sorted(prof_dir.glob("b0_kernel_stats.csv")) or sorted(prof_dir.glob("*kernel_stats.csv"))))
+stats = list(csv.DictReader(open(stats_path)))
 steps = int([r for r in stats if "k_stem_fwd" in r["Name"]][0]["Calls"])
 agg = collections.OrderedDict((f, [0, 0.0]) for f in list(FAM) + ["other"])
 for r in stats:
@@ -49,7 +51,15 @@ def pmc(name, cols):
     return tot, {f: len(v) for f, v in disp.items()}
 
 
-PMC_STEPS = 6          # 3 eager sizing + 1 warm-up + 2 timed, all eager
+def pmc_steps():
+    seen = set()
+    for r in csv.DictReader(open(pmc_dir / "FETCH_SIZE_counter_collection.csv")):
+        if "k_adamw" in r["Kernel_Name"]:
+            seen.add(r["Dispatch_Id"])
+    return len(seen)
+
+
+PMC_STEPS = pmc_steps()          # eager sizing + warm-up + timed steps of the counter runs, all eager launches
 fs, nd = pmc("FETCH_SIZE", None)
 ws, _ = pmc("WRITE_SIZE", None)
 rd, _ = pmc("TCC_EA0_RDREQ_sum", None)
@@ -72,35 +82,79 @@ doc = {"_about": "HBM traffic per kernel family and training step (EfficientNet-
                  "gives twice its bytes — so read traffic = ea_read. WRITE_SIZE agrees with TCC_EA0_WRREQ.",
        "steps": PMC_STEPS, "families": traffic}
 (out / f"{tag}_pmc_traffic.json").write_text(json.dumps(doc, indent=1))
-shutil.copy(next(prof_dir.glob("*kernel_stats.csv")), out / f"{tag}_bench_kernel_stats.csv")
+# ---- SQ / GRBM group: MFMA busy cycles, effective clock, how waves spend their life
+N_SIMD = 256 * 4
+sq = collections.defaultdict(lambda: collections.defaultdict(float))
+dur = collections.defaultdict(dict)
+sq_file = pmc_dir / "SQ_counter_collection.csv"
+if sq_file.exists():
+    for r in csv.DictReader(open(sq_file)):
+        f = family(r["Kernel_Name"])
+        sq[f][r["Counter_Name"]] += float(r["Counter_Value"])
+        dur[f][r["Dispatch_Id"]] = float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
+sq_doc = {}
+for f, c in sq.items():
+    ns = sum(dur[f].values())
+    cyc = c["GRBM_GUI_ACTIVE"] / 8.0                       # rocprofv3 sums the 8 XCDs
+    if ns <= 0 or cyc <= 0:
+        continue
+    sq_doc[f] = {"ms_per_step_eager": round(ns / PMC_STEPS / 1e6, 4),
+                 "effective_clock_ghz": round(cyc / ns, 3),
+                 "mfma_busy_cycles_per_step": round(c["SQ_VALU_MFMA_BUSY_CYCLES"] / PMC_STEPS),
+                 "mfma_busy_frac": round(c["SQ_VALU_MFMA_BUSY_CYCLES"] / (cyc * N_SIMD), 4),
+                 "mfma_mops_bf16_per_step": round(c["SQ_INSTS_VALU_MFMA_MOPS_BF16"] / PMC_STEPS),
+                 "valu_busy_frac": round(c["SQ_ACTIVE_INST_VALU"] * 4.0 / (cyc * N_SIMD), 4),
+                 "waves_per_simd": round(c["SQ_WAVE_CYCLES"] * 4.0 / (cyc * N_SIMD), 2),
+                 "wave_parked_frac": round(c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"], 3) if c["SQ_WAVE_CYCLES"] else None}
+(out / f"{tag}_pmc_sq.json").write_text(json.dumps(
+    {"_about": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES "
+               "SQ_WAIT_ANY GRBM_GUI_ACTIVE over the eager bench (same command as the traffic passes), summed per kernel family. "
+               "effective clock = GRBM_GUI_ACTIVE / 8 XCDs / kernel wall time (reads high for dispatches under ~0.3 ms, per the "
+               "microarchitecture guide); mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (cycles x 1024 SIMDs); valu_busy_frac = "
+               "SQ_ACTIVE_INST_VALU x 4 / (cycles x 1024) (quad-cycle counter); wave_parked_frac = SQ_WAIT_ANY / SQ_WAVE_CYCLES "
+               "(share of wave lifetime spent in s_waitcnt / s_barrier).",
+     "steps": PMC_STEPS, "families": sq_doc}, indent=1))
+shutil.copy(stats_path, out / f"{tag}_bench_kernel_stats.csv")
 line = json.loads(bench_json.read_text().strip().splitlines()[-1])
 (out / f"{tag}_bench_default_line.json").write_text(json.dumps(line) + "\n")
 live = {k["kernel"]: k for k in line["kernels"]}
-L = [f"# Round 1, build {tag} — rocprofv3 kernel stats next to bench.py's live numbers\n",
+L = [f"# Round 2, build {tag} — rocprofv3 kernel stats next to bench.py's live numbers\n",
      "Commands (MI355X, one GPU):\n",
      f"* `python bench.py` → `profiles/{tag}_bench_default_line.json` ({line['value']} images/sec, {line['ms_per_step']} ms/step, "
      f"launch: {line['config']['launch']}; f32 eval forward {line['config'].get('eval_f32_images_per_sec_per_gpu')} images/sec).",
      f"* `rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --profile-steps 0 "
      f"--eval-steps 0` → `profiles/{tag}_bench_kernel_stats.csv` ({steps} steps executed in that process; the table divides by {steps}).",
-     f"* four `rocprofv3 --pmc` passes (one counter group each) → `profiles/{tag}_pmc_traffic.json`; `scripts/make_profile_summary.py` made this file.\n",
-     "| family | launches/step | avg launch µs (rocprofv3) | ms/step (rocprofv3) | ms/step (bench.py live) | algorithmic GB/s (live) | HBM read GB/step | HBM write GB/step | traffic ÷ algorithmic |",
-     "|---|---|---|---|---|---|---|---|---|"]
+     f"* five `rocprofv3 --pmc` passes (one counter group each, `scripts/profile_pmc.sh`) → `profiles/{tag}_pmc_traffic.json`, "
+     f"`profiles/{tag}_pmc_sq.json`; `scripts/make_profile_summary.py` made this file.\n",
+     "Algorithmic bytes are SURVEY §8(d)'s (every tensor of the layer once; the engine's extra fusion operands — the second operand of the "
+     "BN-backward map, residuals — are NOT counted); `traffic ÷ algorithmic` therefore includes them.\n",
+     "| family | launches/step | avg launch µs (rocprofv3) | ms/step (rocprofv3) | ms/step (bench.py live) | §8(d) GB/s (rocprofv3 time) | frac of 8 TB/s | HBM read GB/step | HBM write GB/step | traffic ÷ §8(d) bytes | MFMA busy | VALU busy | waves/SIMD | wave parked | eff. clock GHz |",
+     "|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|"]
 total = 0.0
 for f, (calls, ns) in agg.items():
     if not calls:
         continue
     lv = live.get(f)
     t = traffic[f]
-    ratio = ""
+    ratio = gbps = frac = ""
     if lv and lv["GBps"] > 100 and lv["ms_per_step"]:
-        algo = lv["GBps"] * lv["ms_per_step"] / 1e3
+        algo = lv["GBps"] * lv["ms_per_step"] / 1e3                  # GB per step, SURVEY 8(d) accounting
         ratio = f"{(t['ea_read_gb_per_step'] + t['ea_write_gb_per_step']) / algo:.2f}"
+        g = algo / (ns / steps / 1e9) / 1e0
+        gbps, frac = f"{g:.0f}", f"{g / 8000.0:.3f}"
+    q = sq_doc.get(f, {})
     total += ns / steps / 1e6
     L.append(f"| {f} | {calls / steps:.1f} | {ns / calls / 1e3:.1f} | {ns / steps / 1e6:.3f} | {lv['ms_per_step'] if lv else ''} | "
-             f"{lv['GBps'] if lv else ''} | {t['ea_read_gb_per_step']:.2f} | {t['ea_write_gb_per_step']:.2f} | {ratio} |")
+             f"{gbps} | {frac} | {t['ea_read_gb_per_step']:.2f} | {t['ea_write_gb_per_step']:.2f} | {ratio} | "
+             f"{q.get('mfma_busy_frac', '')} | {q.get('valu_busy_frac', '')} | {q.get('waves_per_simd', '')} | {q.get('wave_parked_frac', '')} | "
+             f"{q.get('effective_clock_ghz', '')} |")
 r = line["roofline"]
 top = agg[r["kernel"]]
-L.append(f"\nSum of kernel durations: {total:.2f} ms per step (hipGraph step: {line['ms_per_step']} ms).")
+tot_rd = sum(t["ea_read_gb_per_step"] for t in traffic.values())
+tot_wr = sum(t["ea_write_gb_per_step"] for t in traffic.values())
+L.append(f"\nSum of kernel durations: {total:.2f} ms per step, {sum(c for c, _ in agg.values()) / steps:.0f} launches per step "
+         f"(hipGraph step: {line['ms_per_step']} ms).  HBM traffic of the whole step: {tot_rd:.1f} GB read + {tot_wr:.1f} GB written "
+         f"= {tot_rd + tot_wr:.1f} GB ({(tot_rd + tot_wr) / line['config']['per_gpu_batch'] * 1e3:.0f} MB per image).")
 L.append(f"\nDominant family (`roofline` of the bench line): **{r['kernel']}**, bound hbm, {r['achieved']} GB/s of {r['peak']} "
          f"(frac {r['frac']}); live average launch {r['avg_launch_us']} µs vs rocprofv3 {top[1] / top[0] / 1e3:.1f} µs; "
          f"traffic {r['traffic'] / 1e6 if r['traffic'] else float('nan'):.1f} MB per launch against {r['avg_launch_bytes'] / 1e6:.1f} MB algorithmic.")

@@ -9,6 +9,8 @@ compatibility is exercised as well.
 
 from __future__ import annotations
 
+import os
+
 import pytest
 import torch
 
@@ -103,15 +105,29 @@ def test_train_step_f32(variant, flavour, size):
     # a BN bias that feeds (through a 1x1 conv) another training-mode BN has an exactly-zero
     # gradient; both sides then hold rounding noise (~1e-8), so errors are floored at 1e-5 of
     # the largest gradient in the network
-    floor = 1e-5 * max(float(p.grad.abs().max()) for p in ref.parameters())
+    gmax = max(float(p.grad.abs().max()) for p in ref.parameters())
+    floor = 1e-5 * gmax
+    report = []
     for name, prm in hip.named_parameters():
         assert prm.grad is not None, name
         want = ref_params[name].grad
         err = float((prm.grad.float().cpu() - want).abs().max())
-        if err > 5e-3 * float(want.abs().max()) + floor:
-            bad.append((name, err, float(want.abs().max())))
+        wmax = float(want.abs().max())
+        report.append((err / max(wmax, 1e-30), wmax / gmax, name))
+        if err > 5e-3 * wmax + floor:
+            bad.append((name, err, wmax))
     # f32 vs f32, different summation orders through ~80 layers of BN backward
     assert not bad, (len(bad), bad[-12:])
+    # per-tensor report ("what's weak" 4): every tensor whose gradient carries signal (largest entry at
+    # least 1e-4 of the network's largest) is within 5e-3 of its OWN scale, squeeze-excite weights included; the
+    # floor above only ever decides for tensors below that share (structurally zero gradients)
+    loud = [(r, share, n) for r, share, n in report if share >= 1e-4]
+    assert loud and all(r <= 5e-3 for r, _, n in loud), sorted(loud, reverse=True)[:8]
+    quiet = [n for _, share, n in report if share < 1e-4]
+    if os.environ.get("DFD_GRAD_REPORT"):
+        print("\n[grad report]", variant, flavour, "tensors", len(report), "quiet", quiet)
+        for r, share, n in sorted(report, reverse=True)[:12]:
+            print(f"   rel {r:.2e}  share {share:.2e}  {n}")
     ref_bufs = dict(ref.named_buffers())
     for name, buf in hip.named_buffers():
         if buf.dtype.is_floating_point:
