@@ -151,22 +151,34 @@ static inline ChanMap make_chanmap(int C, int vec) {
     return m;
 }
 
-// block reduction of NQ*VEC per-thread f32 partial sums over the row lanes that
-// share a channel vector; the result lands in the rl == 0 threads. red must hold
-// DFD_THREADS * NV floats.
+// block reduction of NV per-thread f32 partial sums over the row lanes that share a channel vector; the result
+// lands in the rl == 0 threads.  red must hold DFD_THREADS * NV floats.
+// Value i of channel vector vl is summed over the row lanes in ascending order (fixed order: bitwise reproducible)
+// by the thread (vl, rl = i mod rpb), so the NV * rpb dependent LDS reads the rl == 0 threads used to do alone
+// (up to 512 per thread, ~20 us at the end of EVERY workgroup with statistics) are spread over the whole workgroup.
 template <int NV>
 __device__ __forceinline__ void reduce_rowlanes(float (&acc)[NV], float* red, int cvb, int rpb, int vl, int rl, bool active) {
     const int t = threadIdx.x;
 #pragma unroll
     for (int i = 0; i < NV; ++i) red[i * DFD_THREADS + t] = active ? acc[i] : 0.f;
     __syncthreads();
+    if (active) {
+        for (int i = rl; i < NV; i += rpb) {
+            const float* col = red + i * DFD_THREADS + vl;
+            float s = 0.f;
+            int r = 0;
+            for (; r + 4 <= rpb; r += 4) {                    // four loads in flight, added in row order
+                const float a0 = col[r * cvb], a1 = col[(r + 1) * cvb], a2 = col[(r + 2) * cvb], a3 = col[(r + 3) * cvb];
+                s += a0; s += a1; s += a2; s += a3;
+            }
+            for (; r < rpb; ++r) s += col[r * cvb];
+            red[i * DFD_THREADS + vl] = s;                    // slot (i, row lane 0, vl): this thread was its only reader
+        }
+    }
+    __syncthreads();
     if (rl == 0 && active) {
 #pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            float s = 0.f;
-            for (int r = 0; r < rpb; ++r) s += red[i * DFD_THREADS + r * cvb + vl];
-            acc[i] = s;
-        }
+        for (int i = 0; i < NV; ++i) acc[i] = red[i * DFD_THREADS + vl];
     }
     __syncthreads();
 }

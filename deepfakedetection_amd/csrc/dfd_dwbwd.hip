@@ -394,16 +394,16 @@ k_dw_bwd_weight_q(const T* __restrict__ dz, const T* __restrict__ yraw, const fl
             }
     }
     __syncthreads();
-    if (lane_on && prl == 0 && cvalid) {
+    // every run lane takes its share of the K * V (tap column, channel) sums of its kernel row; each sum runs over the
+    // run lanes in ascending order (fixed order), and no thread is left summing K * V * NPR values alone
+    if (lane_on && cvalid) {
         float* p = partials + (long)by * g.C * K * K;
-#pragma unroll
-        for (int kw = 0; kw < K; ++kw)
-#pragma unroll
-            for (int j = 0; j < V; ++j) {
-                float s = 0.f;
-                for (int r = 0; r < NPR; ++r) s += red[(((r * K + kh) * K + kw) * cvb + vl) * V + j];
-                p[(long)(c0 + j) * K * K + kh * K + kw] = s;
-            }
+        for (int e = prl; e < K * V; e += NPR) {
+            const int kw = e / V, j = e - kw * V;
+            float s = 0.f;
+            for (int r = 0; r < NPR; ++r) s += red[(((r * K + kh) * K + kw) * cvb + vl) * V + j];
+            p[(long)(c0 + j) * K * K + kh * K + kw] = s;
+        }
     }
 }
 

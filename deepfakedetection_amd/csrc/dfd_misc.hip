@@ -764,10 +764,11 @@ __global__ void k_linear_bwd_w(const float* __restrict__ dout, const float* __re
         float* p = dw + (long)j * K + k;
         *p = (accumulate ? *p : 0.f) + s;
     }
-    if (db && blockIdx.x == 0 && threadIdx.x == 0) {
+    if (db && blockIdx.x == 0) {                      // the workgroup is one wave: lanes stride over the rows
         float s = 0.f;
-        for (int n = 0; n < N; ++n) s += dout[(long)n * J + j];
-        db[j] = (accumulate ? db[j] : 0.f) + s;
+        for (int n = threadIdx.x; n < N; n += 64) s += dout[(long)n * J + j];
+        s = wave_sum(s);
+        if (threadIdx.x == 0) db[j] = (accumulate ? db[j] : 0.f) + s;
     }
 }
 extern "C" int dfd_linear_bwd(const float* dout, const float* x, const float* w, float* dx, float* dw, float* db,
