@@ -94,10 +94,24 @@ k_dw_bwd_data_q(const T* __restrict__ dz, const T* __restrict__ yraw, const floa
     const int c0 = vglob * V;
     const int chunk_c0 = bx * cvbV;
 
-    for (int i = t; i < K * K * cvbV; i += DFD_THREADS) {
-        const int tap = i / cvbV, cc = i - tap * cvbV;
-        const int c = chunk_c0 + cc;
-        wl[i] = c < g.C ? round_to<T>(w[(long)c * K * K + tap]) : 0.f;
+    {   // every weight load of the lane in flight at once (see dfd_dwfwd.hip)
+        constexpr int NW = (K * K * 16 * V + DFD_THREADS - 1) / DFD_THREADS;       // cvb <= 16
+        float wr[NW];
+#pragma unroll
+        for (int u = 0; u < NW; ++u) {
+            const int i = t + u * DFD_THREADS;
+            wr[u] = 0.f;
+            if (i < K * K * cvbV) {
+                const int tap = i / cvbV, cc = i - tap * cvbV;
+                const int c = chunk_c0 + cc;
+                if (c < g.C) wr[u] = w[(long)c * K * K + tap];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < NW; ++u) {
+            const int i = t + u * DFD_THREADS;
+            if (i < K * K * cvbV) wl[i] = round_to<T>(wr[u]);
+        }
     }
     for (int i = t; i < 5 * cvbV; i += DFD_THREADS) {
         const int which = i / cvbV, cc = i - which * cvbV;

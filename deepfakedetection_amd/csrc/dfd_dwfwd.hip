@@ -33,10 +33,26 @@ k_dw_fwd_q(const T* __restrict__ x, const float* __restrict__ bnstate, const flo
     const bool cvalid = vglob < g.CV;                  // neighbouring chunks of one tile run together
     const int c0 = vglob * V;
 
-    for (int i = t; i < K * K * cvb * V; i += DFD_THREADS) {
-        const int tap = i / (cvb * V), cc = i - tap * (cvb * V);
-        const int c = bx * cvb * V + cc;
-        wl[i] = c < g.C ? round_to<T>(w[(long)c * K * K + tap]) : 0.f;
+    // all of a lane's (strided, cache-line-per-lane) weight loads are requested before the first is stored: a plain
+    // loop pays one memory round trip per pass at the head of every workgroup
+    {
+        constexpr int NW = (K * K * 16 * V + DFD_THREADS - 1) / DFD_THREADS;       // cvb <= 16
+        float wr[NW];
+#pragma unroll
+        for (int u = 0; u < NW; ++u) {
+            const int i = t + u * DFD_THREADS;
+            wr[u] = 0.f;
+            if (i < K * K * cvb * V) {
+                const int tap = i / (cvb * V), cc = i - tap * (cvb * V);
+                const int c = bx * cvb * V + cc;
+                if (c < g.C) wr[u] = w[(long)c * K * K + tap];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < NW; ++u) {
+            const int i = t + u * DFD_THREADS;
+            if (i < K * K * cvb * V) wl[i] = round_to<T>(wr[u]);
+        }
     }
     float* cf = wl + K * K * cvb * V;                              // scale, shift : [2][cvb*V]
     for (int i = t; i < 2 * cvb * V; i += DFD_THREADS) {

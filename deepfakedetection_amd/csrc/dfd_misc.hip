@@ -227,7 +227,15 @@ k_se_fwd_img(const float* __restrict__ parts, int splits, float mul, float* __re
     __syncthreads();
     for (int c = t; c < C; c += SE_IMG_THREADS) {
         float s = b2 ? b2[c] : 0.f;
-        for (int r = 0; r < R; ++r) s = fmaf(w2t[(long)r * C + c], sh[r], s);
+        int r = 0;
+        for (; r + 8 <= R; r += 8) {                          // eight weight rows in flight, same FMA order
+            float wv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) wv[u] = w2t[(long)(r + u) * C + c];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s = fmaf(wv[u], sh[r + u], s);
+        }
+        for (; r < R; ++r) s = fmaf(w2t[(long)r * C + c], sh[r], s);
         gate[(long)n * C + c] = sigmoid_f(s);
     }
 }
@@ -278,7 +286,15 @@ k_se_bwd_img(const float* __restrict__ parts, int splits, const float* __restric
     __syncthreads();
     for (int c = t; c < C; c += SE_IMG_THREADS) {
         float s = 0.f;
-        for (int r = 0; r < R; ++r) s = fmaf(sd[r], w1[(long)r * C + c], s);
+        int r = 0;
+        for (; r + 8 <= R; r += 8) {
+            float wv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) wv[u] = w1[(long)(r + u) * C + c];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s = fmaf(sd[r + u], wv[u], s);
+        }
+        for (; r < R; ++r) s = fmaf(sd[r], w1[(long)r * C + c], s);
         dpooled[(long)n * C + c] = s;
     }
 }

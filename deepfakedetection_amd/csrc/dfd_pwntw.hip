@@ -54,11 +54,28 @@ k_pw_ntw(const T* __restrict__ a, ProArgs pa, const T* __restrict__ w, T* __rest
     // ---- weight panel -> LDS (once)
     {
         const int chunks = nk * KSN * 4;
-        for (int idx = t; idx < BN * nchunks * chunks; idx += DFD_THREADS) {
-            const int n = idx / chunks, c = idx - n * chunks;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (n0 + n < Nout && c * E < K) v = *reinterpret_cast<const uint4*>(w + (long)(n0 + n) * K + c * E);
-            *reinterpret_cast<uint4*>(smem + n * wstride + c * 16) = v;
+        // eight 16-byte loads per lane in flight: the panel is up to 16 passes of the workgroup, and a load-store loop
+        // pays one memory round trip per pass before the first MFMA of every workgroup
+        const int total = BN * nchunks * chunks;
+        for (int base = t; base < total; base += DFD_THREADS * 8) {
+            uint4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int idx = base + u * DFD_THREADS;
+                v[u] = make_uint4(0, 0, 0, 0);
+                if (idx < total) {
+                    const int n = idx / chunks, c = idx - n * chunks;
+                    if (n0 + n < Nout && c * E < K) v[u] = *reinterpret_cast<const uint4*>(w + (long)(n0 + n) * K + c * E);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int idx = base + u * DFD_THREADS;
+                if (idx < total) {
+                    const int n = idx / chunks, c = idx - n * chunks;
+                    *reinterpret_cast<uint4*>(smem + n * wstride + c * 16) = v[u];
+                }
+            }
         }
         // per-channel prologue coefficients, zero padded to the K tiles: rows of nk*BK floats
         if constexpr (PRO != DFD_PRO_NONE) {

@@ -284,13 +284,24 @@ __device__ __forceinline__ void fin_reduce(const float* __restrict__ partials, i
             a1 += partials[(long)p * 2 * C + C + c];
         }
     }
-    const int cl = threadIdx.x & (FIN_CH - 1);
-    sm[(q * FIN_CH + cl) * 2] = (double)a0;
-    sm[(q * FIN_CH + cl) * 2 + 1] = (double)a1;
+    // the 32 lane sums of a channel: butterfly over the eight lanes of each wave (lanes FIN_CH apart), then the four
+    // wave totals in wave order — a fixed tree in double instead of 64 dependent LDS reads on the q == 0 lanes
+    const int cl = threadIdx.x & (FIN_CH - 1), wave = threadIdx.x >> 6;
+    double v0 = (double)a0, v1 = (double)a1;
+#pragma unroll
+    for (int o = FIN_CH; o < 64; o <<= 1) {
+        v0 += __shfl_xor(v0, o);
+        v1 += __shfl_xor(v1, o);
+    }
+    if ((threadIdx.x & 63) < FIN_CH) {
+        sm[(wave * FIN_CH + cl) * 2] = v0;
+        sm[(wave * FIN_CH + cl) * 2 + 1] = v1;
+    }
     __syncthreads();
     s0 = 0.0; s1 = 0.0;
     if (q == 0) {
-        for (int i = 0; i < FIN_LANES; ++i) { s0 += sm[(i * FIN_CH + cl) * 2]; s1 += sm[(i * FIN_CH + cl) * 2 + 1]; }
+#pragma unroll
+        for (int i = 0; i < FIN_CH * FIN_LANES / 64; ++i) { s0 += sm[(i * FIN_CH + cl) * 2]; s1 += sm[(i * FIN_CH + cl) * 2 + 1]; }
     }
 }
 
