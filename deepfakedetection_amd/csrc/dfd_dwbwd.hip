@@ -261,7 +261,7 @@ static int dw_bwd_data_q_t(const void* dz, const void* y, const float* coef, con
     if (epi && (!in_bnstate || !partials || !nparts || pcap < 1)) return DFD_EINVAL;
     if (hc && !y) return DFD_EINVAL;
     int cap = epi ? (pcap < DFD_MAX_PARTIALS ? pcap : DFD_MAX_PARTIALS) : DFD_MAX_PARTIALS;
-    int gy = 2048 / nchunks;
+    int gy = DFD_DW_GRID / nchunks;
     if (gy < 64) gy = 64;
     if (gy > cap) gy = cap;
     if (gy > g.nwork) gy = g.nwork;
@@ -430,7 +430,7 @@ static bool dw_wgrad_q_geom(const dfd_dwconv_shape* s, int vec, DwQGeom* g, int*
 }
 
 static int dw_wgrad_q_parts(const DwQGeom& g, int k, int nchunks) {
-    int want = 2048 / (nchunks > 0 ? nchunks : 1);
+    int want = DFD_DW_GRID / (nchunks > 0 ? nchunks : 1);
     if (want < 32) want = 32;
     const long per = (long)g.C * k * k * 4;
     long cap = (16l << 20) / per;

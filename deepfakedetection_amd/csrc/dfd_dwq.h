@@ -4,6 +4,11 @@
 
 typedef float f2 __attribute__((ext_vector_type(2)));
 
+// workgroups a depthwise launch aims for (all channel chunks together); 1024 are co-resident at 4 per CU
+#ifndef DFD_DW_GRID
+#define DFD_DW_GRID 2048
+#endif
+
 // 16-byte vectors a lane requests before it touches the first one while staging a tile (a tile is at most ~10
 // vectors per lane and tensor).  Measured per layer on MI355X (scripts/bench_layers.py): the 3x3 kernels gain up
 // to 30 % from 6-8 in flight (fewer exposed memory round trips per work item); the 5x5 kernels sit at the
