@@ -176,10 +176,7 @@ k_dw_bwd_data_q(const T* __restrict__ dz, const T* __restrict__ yraw, const floa
                 const uint4* row = tile + (((r * g.IW) + qx * (S == 1 ? 4 : 2)) << g.cvb_log2) + vl;
                 f2 wv[K][N2];
 #pragma unroll
-                for (int kw = 0; kw < K; ++kw)
-#pragma unroll
-                    for (int j = 0; j < N2; ++j)
-                        wv[kw][j] = *reinterpret_cast<const f2*>(wl + (kh * K + kw) * cvbV + vl * V + 2 * j);
+                for (int kw = 0; kw < K; ++kw) lds_row<N2>(wl + (kh * K + kw) * cvbV + vl * V, wv[kw]);
 #pragma unroll
                 for (int c = 0; c < NCOL; ++c) {
                     f2 xc[N2];

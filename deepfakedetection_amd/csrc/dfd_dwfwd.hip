@@ -96,10 +96,7 @@ k_dw_fwd_q(const T* __restrict__ x, const float* __restrict__ bnstate, const flo
                 const uint4* row = tile + ((((qy * S + kh) * g.IW) + qx * 4 * S) << g.cvb_log2) + vl;
                 f2 wv[K][N2];
 #pragma unroll
-                for (int kw = 0; kw < K; ++kw)
-#pragma unroll
-                    for (int j = 0; j < N2; ++j)
-                        wv[kw][j] = *reinterpret_cast<const f2*>(wl + ((kh * K + kw) * cvb + vl) * V + 2 * j);
+                for (int kw = 0; kw < K; ++kw) lds_row<N2>(wl + ((kh * K + kw) * cvb + vl) * V, wv[kw]);
                 // walk the INPUT columns of the quad's window: one vector is unpacked at a time and
                 // feeds every (output, tap) pair it belongs to (keeps the live set at acc + weights)
                 constexpr int NCOL = 3 * S + K;

@@ -50,6 +50,22 @@ __device__ __forceinline__ void dwq_block(int& chunk, int& slot, int remap) {
 
 template <typename T> struct V2 { static constexpr int N = Vec<T>::N / 2; };
 
+// A lane's V consecutive floats of a per-channel LDS table (tap weights, BN coefficients) as 16-byte reads.  Read as
+// float2 pairs the compiler emits ds_read2_b64 (8 LDS cycles per wave instruction, 32-bank modulus: the 32-byte lane
+// stride is a 4-way conflict); ds_read_b128 takes 4 cycles and is conflict-free at this stride for <= 8 lanes per pixel.
+template <int N2>
+__device__ __forceinline__ void lds_row(const float* p, f2 (&v)[N2]) {
+    static_assert(N2 == 2 || N2 == 4, "V is 4 (f32) or 8 (bf16)");
+    const float4 a = *reinterpret_cast<const float4*>(p);
+    v[0] = (f2){a.x, a.y};
+    v[1] = (f2){a.z, a.w};
+    if constexpr (N2 == 4) {
+        const float4 b = *reinterpret_cast<const float4*>(p + 4);
+        v[2] = (f2){b.x, b.y};
+        v[3] = (f2){b.z, b.w};
+    }
+}
+
 __device__ __forceinline__ void unpack2(const uint4& q, f2 (&v)[4]) {       // 8 x bf16
     v[0] = (f2){__uint_as_float(q.x << 16), __uint_as_float(q.x & 0xffff0000u)};
     v[1] = (f2){__uint_as_float(q.y << 16), __uint_as_float(q.y & 0xffff0000u)};
