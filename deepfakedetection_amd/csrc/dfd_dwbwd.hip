@@ -24,12 +24,9 @@ __device__ __forceinline__ void stage_dy(uint4* __restrict__ tile, const T* __re
     constexpr int V = Vec<T>::N, N2 = V / 2;
     f2 ka[N2], kb[N2], kc[N2];
     if constexpr (COEF) {
-#pragma unroll
-        for (int j = 0; j < N2; ++j) {
-            ka[j] = *reinterpret_cast<const f2*>(cf + vl * V + 2 * j);
-            kb[j] = *reinterpret_cast<const f2*>(cf + cvbV + vl * V + 2 * j);
-            kc[j] = *reinterpret_cast<const f2*>(cf + 2 * cvbV + vl * V + 2 * j);
-        }
+        lds_row<N2>(cf + vl * V, ka);
+        lds_row<N2>(cf + cvbV + vl * V, kb);
+        lds_row<N2>(cf + 2 * cvbV + vl * V, kc);
     }
     const int total = (IH * IW) << cvb_log2;
     for (int base = threadIdx.x; base < total; base += DFD_THREADS * U) {
@@ -193,6 +190,11 @@ k_dw_bwd_data_q(const T* __restrict__ dz, const T* __restrict__ yraw, const floa
                     }
                 }
             }
+            f2 scv[N2], shv[N2];                     // BN(scale, shift) of the producer: two 16-byte LDS reads each
+            if constexpr (EPI) {
+                lds_row<N2>(cf + 3 * cvbV + vl * V, scv);
+                lds_row<N2>(cf + 4 * cvbV + vl * V, shv);
+            }
 #pragma unroll
             for (int o = 0; o < 4; ++o) {
                 if (wq + o < g.W) {
@@ -201,9 +203,7 @@ k_dw_bwd_data_q(const T* __restrict__ dz, const T* __restrict__ yraw, const floa
                         unpack2(xr[o], xv);
 #pragma unroll
                         for (int j = 0; j < N2; ++j) {
-                            const f2 sc = *reinterpret_cast<const f2*>(cf + 3 * cvbV + vl * V + 2 * j);
-                            const f2 sh = *reinterpret_cast<const f2*>(cf + 4 * cvbV + vl * V + 2 * j);
-                            const f2 z = __builtin_elementwise_fma(sc, xv[j], sh);
+                            const f2 z = __builtin_elementwise_fma(scv[j], xv[j], shv[j]);
                             const f2 gr = (f2){act_grad<ACT>(z.x), act_grad<ACT>(z.y)};
                             const f2 d = round2<T>(acc[o][j] * gr);
                             acc[o][j] = d;
@@ -355,11 +355,8 @@ k_dw_bwd_weight_q(const T* __restrict__ dz, const T* __restrict__ yraw, const fl
         __syncthreads();
         {
             f2 sc[N2], sh[N2];                       // short-lived: the coefficients live in LDS
-#pragma unroll
-            for (int j = 0; j < N2; ++j) {
-                sc[j] = *reinterpret_cast<const f2*>(cf + 3 * cvbV + vl * V + 2 * j);
-                sh[j] = *reinterpret_cast<const f2*>(cf + 4 * cvbV + vl * V + 2 * j);
-            }
+            lds_row<N2>(cf + 3 * cvbV + vl * V, sc);
+            lds_row<N2>(cf + 4 * cvbV + vl * V, sh);
             stage_q<T, ACT, PRO, (K == 3 ? 8 : 4)>(tile, xin, sc, sh, (long)n * g.H * g.W * g.C, g.H, g.W, g.C, c0, cvalid, oy0 * S - g.pt,
                                  ox0 * S - g.pl, g.IH, g.IW, g.iw_magic, g.cvb_log2);
         }

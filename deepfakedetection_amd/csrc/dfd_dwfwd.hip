@@ -71,11 +71,8 @@ k_dw_fwd_q(const T* __restrict__ x, const float* __restrict__ bnstate, const flo
         __syncthreads();
         {
             f2 sc[N2], sh[N2];                       // short-lived: the coefficients live in LDS
-#pragma unroll
-            for (int j = 0; j < N2; ++j) {
-                sc[j] = *reinterpret_cast<const f2*>(cf + vl * V + 2 * j);
-                sh[j] = *reinterpret_cast<const f2*>(cf + cvb * V + vl * V + 2 * j);
-            }
+            lds_row<N2>(cf + vl * V, sc);
+            lds_row<N2>(cf + cvb * V + vl * V, sh);
             stage_q<T, ACT, PRO, StageDepth<K, S>::X>(tile, x, sc, sh, (long)n * g.H * g.W * g.C, g.H, g.W, g.C, c0, cvalid, oy0 * S - g.pt,
                                  ox0 * S - g.pl, g.IH, g.IW, g.iw_magic, g.cvb_log2);
         }
