@@ -10,6 +10,8 @@ Outputs
       surface the host side must reproduce bit for bit.
   tests/golden/effnet_logits.json — logits of the CPU oracle (oracle/effnet_ref.py) on
       seeded inputs; the oracle itself is pinned by tests/test_oracle.py.
+  tests/golden/vit_logits.json — the same for oracle/efformer_ref.py and oracle/fastervit_ref.py
+      (drift guards; their pinning is in tests/test_efformer_oracle.py / test_fastervit_oracle.py).
 Only data is written: inputs and expected outputs, no reference source text.
 """
 
@@ -107,7 +109,27 @@ def oracle_logits() -> dict:
     return {"generator": "tests/golden/make_golden.py", "torch": torch.__version__, "cases": cases}
 
 
+def vit_logits() -> dict:
+    from oracle.efformer_ref import EfficientFormerV2Ref  # noqa: PLC0415
+    from oracle.fastervit_ref import FasterViTRef  # noqa: PLC0415
+
+    cases = []
+    for family, variant, classes, size, batch in (("efficientformerv2", "s1", 2, 224, 2), ("efficientformerv2", "s0", 10, 96, 2),
+                                                  ("fastervit", "0", 2, 224, 2), ("fastervit", "1", 10, 224, 1)):
+        seed, input_seed = 13, 2
+        torch.manual_seed(seed)
+        model = (EfficientFormerV2Ref(variant, classes, img_size=size) if family == "efficientformerv2"
+                 else FasterViTRef(variant, classes, resolution=size)).eval()
+        x = torch.randn(batch, 3, size, size, generator=torch.Generator().manual_seed(input_seed))
+        with torch.no_grad():
+            logits = model(x)
+        cases.append(dict(family=family, variant=variant, classes=classes, size=size, batch=batch, seed=seed,
+                          input_seed=input_seed, logits=logits.tolist()))
+    return {"generator": "tests/golden/make_golden.py", "torch": torch.__version__, "cases": cases}
+
+
 if __name__ == "__main__":
     (OUT / "reference_contract.json").write_text(json.dumps(reference_contract(), indent=1, sort_keys=True))
     (OUT / "effnet_logits.json").write_text(json.dumps(oracle_logits(), indent=1))
+    (OUT / "vit_logits.json").write_text(json.dumps(vit_logits(), indent=1))
     print("wrote", sorted(p.name for p in OUT.glob("*.json")))

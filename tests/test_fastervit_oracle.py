@@ -94,3 +94,25 @@ def test_hip_module_has_the_oracles_state_dict(variant):
     assert sorted(torch.cat([dst_ct, dst_x]).tolist()) == list(range(8 * 53))       # the concatenation covers every row once
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         hip(torch.zeros(1, 3, 224, 224))
+
+
+def test_golden_logits_fixture_of_both_vit_oracles():
+    """Drift guard: the committed logits of oracle/efformer_ref.py and oracle/fastervit_ref.py on seeded inputs
+    (tests/golden/vit_logits.json, written by tests/golden/make_golden.py)."""
+    import json
+    from pathlib import Path
+
+    from oracle.efformer_ref import EfficientFormerV2Ref
+
+    data = json.loads((Path(__file__).parent / "golden" / "vit_logits.json").read_text())
+    assert {c["family"] for c in data["cases"]} == {"efficientformerv2", "fastervit"}
+    for case in data["cases"]:
+        torch.manual_seed(case["seed"])
+        if case["family"] == "efficientformerv2":
+            model = EfficientFormerV2Ref(case["variant"], case["classes"], img_size=case["size"]).eval()
+        else:
+            model = FasterViTRef(case["variant"], case["classes"], resolution=case["size"]).eval()
+        x = torch.randn(case["batch"], 3, case["size"], case["size"], generator=torch.Generator().manual_seed(case["input_seed"]))
+        with torch.no_grad():
+            got = model(x)
+        assert torch.allclose(got, torch.tensor(case["logits"]), rtol=1e-4, atol=1e-5), (case["family"], case["variant"])
