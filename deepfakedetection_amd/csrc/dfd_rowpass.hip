@@ -314,15 +314,20 @@ k_bn_finalize(const float* __restrict__ partials, int nparts, int C, double coun
     __shared__ double sm[FIN_CH * FIN_LANES * 2];
     const int c = blockIdx.x * FIN_CH + (threadIdx.x & (FIN_CH - 1)), q = threadIdx.x / FIN_CH;
     double s, ss;
+    // the per-channel parameters are requested before the reduction, not after it: these kernels are a chain of
+    // memory round trips (~5 us each, ~100 of them per step), and this takes one link out
+    const bool mine = c < C && q == 0;
+    const float g = (mine && gamma) ? gamma[c] : 1.f, b = (mine && beta) ? beta[c] : 0.f;
+    const float l = (mine && ls) ? ls[c] : 1.f;             // LayerScale folded into the affine map
+    const float cb = (mine && rmean && conv_bias) ? conv_bias[c] : 0.f;
+    const float rm0 = (mine && rmean) ? rmean[c] : 0.f, rv0 = (mine && rmean) ? rvar[c] : 0.f;
     fin_reduce(partials, nparts, C, c, q, sm, s, ss);
-    if (c < C && q == 0) {
+    if (mine) {
         const double mean = s / count;
         double var = ss / count - mean * mean;
         if (var < 0.0) var = 0.0;
         const float rstd = (float)(1.0 / sqrt(var + (double)eps));
-        const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
         const float scale = g * rstd;
-        const float l = ls ? ls[c] : 1.f;                  // LayerScale folded into the affine map
         bnstate[c] = l * scale;
         bnstate[C + c] = l * (b - (float)mean * scale);
         bnstate[2 * C + c] = (float)mean;
@@ -331,9 +336,9 @@ k_bn_finalize(const float* __restrict__ partials, int nparts, int C, double coun
             // the convolution's bias never enters the kernels: a constant per channel cancels in
             // batch-statistics BatchNorm and only shifts the running mean
             const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
-            const float mb = (float)mean + (conv_bias ? conv_bias[c] : 0.f);
-            rmean[c] = (1.f - momentum) * rmean[c] + momentum * mb;
-            rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unbiased;
+            const float mb = (float)mean + cb;
+            rmean[c] = (1.f - momentum) * rm0 + momentum * mb;
+            rvar[c] = (1.f - momentum) * rv0 + momentum * (float)unbiased;
         }
     }
 }
@@ -364,19 +369,23 @@ k_bn_bwd_finalize(const float* __restrict__ partials, int nparts, int C, double 
     __shared__ double sm[FIN_CH * FIN_LANES * 2];
     const int c = blockIdx.x * FIN_CH + (threadIdx.x & (FIN_CH - 1)), q = threadIdx.x / FIN_CH;
     double s1, s2;
+    const bool mine = c < C && q == 0;                       // parameters first, reduction second (see k_bn_finalize)
+    const double l = (mine && ls) ? (double)ls[c] : 1.0;
+    const double g0 = (mine && gamma) ? (double)gamma[c] : 1.0;
+    const double b0 = (mine && beta) ? (double)beta[c] : 0.0;
+    const double mean = mine ? (double)bnstate[2 * C + c] : 0.0, rstd = mine ? (double)bnstate[3 * C + c] : 1.0;
+    const float og = (mine && accumulate && dgamma) ? dgamma[c] : 0.f, ob = (mine && accumulate && dbeta) ? dbeta[c] : 0.f;
+    const float ol = (mine && accumulate && dls) ? dls[c] : 0.f, obi = (mine && accumulate && dbias) ? dbias[c] : 0.f;
     fin_reduce(partials, nparts, C, c, q, sm, s1, s2);
-    if (c < C && q == 0) {
+    if (mine) {
         // s1 = sum dz, s2 = sum dz*xhat with dz = d loss / d (ls * BN(y)); BN(y) = gamma*xhat + beta
-        const double l = ls ? (double)ls[c] : 1.0;
-        const double g0 = gamma ? (double)gamma[c] : 1.0;
-        if (dgamma) dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)(l * s2);
-        if (dbeta) dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)(l * s1);
-        if (dls) dls[c] = (accumulate ? dls[c] : 0.f) + (float)(g0 * s2 + (beta ? (double)beta[c] : 0.0) * s1);
+        if (dgamma) dgamma[c] = og + (float)(l * s2);
+        if (dbeta) dbeta[c] = ob + (float)(l * s1);
+        if (dls) dls[c] = ol + (float)(g0 * s2 + b0 * s1);
         const double g = g0 * l;
-        const double mean = bnstate[2 * C + c], rstd = bnstate[3 * C + c];
         const double a = g * rstd;
         // the producing convolution's bias: d/d bias = sum dy, exactly 0 through batch statistics
-        if (dbias) dbias[c] = (accumulate ? dbias[c] : 0.f) + (train ? 0.f : (float)(a * s1));
+        if (dbias) dbias[c] = obi + (train ? 0.f : (float)(a * s1));
         double b = 0.0, cc = 0.0;
         if (train) {
             b = -g * rstd * rstd * s2 / count;
