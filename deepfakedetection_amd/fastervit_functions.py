@@ -58,7 +58,7 @@ def lin_bwd(g, x, y, st, w_kn, w, bias, ls, act, need_dx, need_w, need_b, need_l
     """-> (dx, dw, dbias, dls)"""
     ones, _ = ident(x.device, w.shape[0])
     dx, dw, _, _, dbeta, dls = pwbn_bwd(g, x, y, st, w_kn, tuple(w.shape), w, None, ones, bias, ls, act, False, need_dx, need_w,
-                                        need_b and bias is not None, need_ls, dx_residual, row_scale)
+                                        need_b and bias is not None, need_ls, dx_residual, row_scale, identity=True)
     return dx, dw, (dbeta if need_b else None), dls
 
 

@@ -63,9 +63,12 @@ def pwbn_fwd(x, w_nk, b, gamma, beta, bn: BNRef, training, counters, act=ACT_NON
 
 
 def pwbn_bwd(g, x, y, st, w_kn, w_shape, w, b, gamma, beta, ls, act, training, need_dx, need_w, need_bn, need_ls=False,
-             dx_residual=None, row_scale=None, need_b=None):
+             dx_residual=None, row_scale=None, need_b=None, identity=False):
     """Backward of pwbn_fwd for the gradient g of its output.  Returns (dx, dw, db, dgamma, dbeta, dls); dx already
-    includes `dx_residual` (the running sum of the other consumers' gradients of x)."""
+    includes `dx_residual` (the running sum of the other consumers' gradients of x).
+    identity: the "BatchNorm" is the identity statistic of a Linear layer (fastervit_functions.ident): its backward map
+    is dy = ls * dz, so the two GEMMs take dz as it is (or scaled per channel) instead of the two-operand BN-backward
+    prologue, which would read y only to multiply it by zero."""
     if row_scale is not None:
         g = K.scale_rows(g, row_scale)
     if act == ACT_NONE:
@@ -78,14 +81,22 @@ def pwbn_bwd(g, x, y, st, w_kn, w_shape, w, b, gamma, beta, ls, act, training, n
     outs = (_slot(gamma, need_bn, (C,)), _slot(beta, need_bn, (C,)), _slot(ls, need_ls, (C,)), _slot(b, want_b, (C,)))
     coef, dgamma, dbeta, dls, db = K.bn_bwd_finalize_ex(parts, n, _rows(y), gamma, beta, ls, st, training, need_bn, need_ls,
                                                         want_b, outs)
-    pro = K.pro_affine2(y, coef)
+    if identity and not training:
+        pro_d = pro_w = None
+        if ls is not None:
+            # rows 0, 1 of coef = (ls, 0): a plain per-channel scale (the GEMM kernels add a residual only behind the
+            # prologues the EfficientNet path uses, so with one the two-operand form stays)
+            pro_w = K.pro_affine2(y, coef)
+            pro_d = K.pro_bn_act(coef, ACT_NONE) if dx_residual is None else pro_w
+    else:
+        pro_d = pro_w = K.pro_affine2(y, coef)
     dx = dx_residual
     if need_dx:
-        dx, _, _ = K.pwconv(dz, pro, w_kn, dx_residual, stats=False)
+        dx, _, _ = K.pwconv(dz, pro_d, w_kn, dx_residual, stats=False)
     dw = None
     if need_w:
         O, I = w_shape[0], w_shape[1]
-        dw = K.pwconv_wgrad(dz, pro, x, None, _slot(w, True, (O, I))).view(w_shape)
+        dw = K.pwconv_wgrad(dz, pro_w, x, None, _slot(w, True, (O, I))).view(w_shape)
     return dx, dw, db, dgamma, dbeta, dls
 
 

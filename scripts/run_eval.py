@@ -1,0 +1,22 @@
+"""The f32 evaluate() forward of EfficientNet-B0 (batch 256, 224 px), repeated — for rocprofv3 --kernel-trace --stats."""
+import sys
+from pathlib import Path
+sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+import torch
+from deepfakedetection_amd.efficientnet import HipEfficientNet
+
+reps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+torch.manual_seed(0)
+model = HipEfficientNet("b0", "timm", 2).cuda().eval()
+x = torch.randn(256, 3, 224, 224, device="cuda").to(memory_format=torch.channels_last)
+with torch.inference_mode():
+    for _ in range(3):
+        model(x)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        model(x)
+    e1.record()
+    torch.cuda.synchronize()
+print(f"eval forward: {e0.elapsed_time(e1) / reps:.3f} ms per batch of 256 ({256 * reps / e0.elapsed_time(e1) * 1e3:.0f} images/s)")
