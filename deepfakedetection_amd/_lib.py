@@ -107,6 +107,7 @@ SIGNATURES: dict[str, tuple] = {
     "dfd_bias_gather": (c_int, [P, P, P, c_int, c_int, c_long, P]),
     "dfd_bias_scatter": (c_int, [P, P, P, c_int, c_int, c_long, c_int, P]),
     "dfd_im2col": (c_int, [c_int, P, P, c_int, P, POINTER(DwShape), P]),
+    "dfd_conv_fwd": (c_int, [c_int, P, POINTER(DwShape), P, c_int, P, c_int, P, P, c_int, POINTER(c_int), P]),
     "dfd_col2im": (c_int, [c_int, P, P, POINTER(DwShape), P]),
     "dfd_conv_weight_perm": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P]),
     "dfd_layernorm_fwd": (c_int, [c_int, P, P, P, c_float, P, P, c_long, c_int, P]),

@@ -22,6 +22,26 @@ __device__ __forceinline__ int pro_image(const ProArgs& pa, int m) {
     return pa.hw_shift < 0 ? m : (int)(__umulhi((unsigned)m, pa.hw_magic) >> pa.hw_shift);
 }
 
+// exact unsigned division by a launch constant: x / d == umulhi(x, mul) >> sh  (sh < 0: d == 1), x < 2^31
+struct Magic { unsigned mul; int sh; };
+static inline Magic make_magic(int d) {
+    Magic m{0u, -1};
+    if (d > 1) {
+        int s = 0;
+        while ((1ll << s) < d) ++s;
+        m.mul = (unsigned)(((1ull << (31 + s)) + (unsigned long long)d - 1) / (unsigned long long)d);
+        m.sh = s - 1;
+    }
+    return m;
+}
+__device__ __forceinline__ int udiv(int x, const Magic& m) { return m.sh < 0 ? x : (int)(__umulhi((unsigned)x, m.mul) >> m.sh); }
+
+// implicit-GEMM view of a dense k x k convolution: row m = output pixel (n, oy, ox), column k = (tap, channel)
+struct ConvArgs {
+    int H, W, C, Ho, Wo, ks, stride, pt, pl;
+    Magic howo, wo, c, kk;          // divisions by Ho*Wo, Wo, C, ks
+};
+
 template <typename T> struct El;
 template <> struct El<bf16> { static constexpr int EPC = 8; static constexpr int BK = 64; };   // elements per 16-B chunk, K tile
 template <> struct El<float> { static constexpr int EPC = 4; static constexpr int BK = 32; };

@@ -34,10 +34,12 @@ template <typename T, int BN, int BM> struct NtLds {
 };
 
 // BM = rows of a workgroup tile: 128, or 64 when M is so small that 128-row tiles leave CUs idle
-template <typename T, int BN, int BM, int PRO, int ACT, bool RES, bool STATS>
+// CONV: the A operand is gathered from an NHWC image (implicit GEMM of a dense k x k convolution, ConvArgs): a lane's
+// 16-byte chunk is 8 channels of one tap, zero outside the image AFTER the producer's BN + activation
+template <typename T, int BN, int BM, int PRO, int ACT, bool RES, bool STATS, bool CONV = false>
 __global__ void __launch_bounds__(DFD_THREADS, 2)
 k_pw_nt(const T* __restrict__ a, ProArgs pa, const T* __restrict__ w, T* __restrict__ out, const T* __restrict__ res,
-        int M, int K, int Nout, int m_tiles, int n_tiles, int gx, float* __restrict__ partials) {
+        int M, int K, int Nout, int m_tiles, int n_tiles, int gx, float* __restrict__ partials, ConvArgs cv) {
     constexpr int E = El<T>::EPC;
     constexpr int BK = El<T>::BK;
     constexpr int NTW = BN / 32;            // 16-wide n tiles per wave
@@ -85,13 +87,32 @@ k_pw_nt(const T* __restrict__ a, ProArgs pa, const T* __restrict__ w, T* __restr
 
     // two register sets: the loads of stage s+2 are issued while stage s computes and stage s+1
     // waits in the other set for its turn through the prologue into LDS
-    struct Regs { uint4 a[AI], a2[AI], b[BN / 32]; };
+    struct Regs { uint4 a[AI], a2[AI], b[BN / 32]; unsigned ok; };
     Regs R0, R1;
     auto g_load = [&](Regs& R, int mt, int kt, bool with_b) {
         int kc, sh;
         tile_kc(kt, kc, sh);
         const int c = t & ((1 << sh) - 1), rb0 = t >> sh, rstep = DFD_THREADS >> sh;
         const int m0 = mt * BM, k0 = kt * BK;
+        if constexpr (CONV) {
+            const int k = k0 + c * E, tap = udiv(k, cv.c), ch = k - tap * cv.C;
+            const int dy = udiv(tap, cv.kk), dx = tap - dy * cv.ks;
+            R.ok = 0u;
+#pragma unroll
+            for (int i = 0; i < AI; ++i) {
+                const int r = rb0 + i * rstep, m = m0 + r;
+                R.a[i] = make_uint4(0, 0, 0, 0);
+                if (r < BM && c < kc && m < M) {
+                    const int n = udiv(m, cv.howo), rem = m - n * (cv.Ho * cv.Wo);
+                    const int oy = udiv(rem, cv.wo), ox = rem - oy * cv.Wo;
+                    const int iy = oy * cv.stride - cv.pt + dy, ix = ox * cv.stride - cv.pl + dx;
+                    if ((unsigned)iy < (unsigned)cv.H && (unsigned)ix < (unsigned)cv.W) {
+                        R.a[i] = *reinterpret_cast<const uint4*>(a + (((long)n * cv.H + iy) * cv.W + ix) * cv.C + ch);
+                        R.ok |= 1u << i;
+                    }
+                }
+            }
+        } else {
 #pragma unroll
         for (int i = 0; i < AI; ++i) {
             const int r = rb0 + i * rstep;
@@ -102,6 +123,7 @@ k_pw_nt(const T* __restrict__ a, ProArgs pa, const T* __restrict__ w, T* __restr
                 R.a[i] = *reinterpret_cast<const uint4*>(a + off);
                 if constexpr (PRO == DFD_PRO_AFFINE2) R.a2[i] = *reinterpret_cast<const uint4*>(a2 + off);
             }
+        }
         }
         if (with_b) {
 #pragma unroll
@@ -119,10 +141,11 @@ k_pw_nt(const T* __restrict__ a, ProArgs pa, const T* __restrict__ w, T* __restr
             int kc, sh;
             tile_kc(kt, kc, sh);
             const int c = t & ((1 << sh) - 1);
-            const int k = c < kc ? kt * BK + c * E : 0;
+            int k = c < kc ? kt * BK + c * E : 0, rowlen = K;
+            if constexpr (CONV) { k -= udiv(k, cv.c) * cv.C; rowlen = cv.C; }      // coefficients are per input channel
             load_f32<E>(pa.coef + k, c0);
-            load_f32<E>(pa.coef + K + k, c1);
-            if constexpr (PRO == DFD_PRO_AFFINE2) load_f32<E>(pa.coef + 2 * K + k, c2);
+            load_f32<E>(pa.coef + rowlen + k, c1);
+            if constexpr (PRO == DFD_PRO_AFFINE2) load_f32<E>(pa.coef + 2 * rowlen + k, c2);
         }
     };
     auto s_store = [&](const Regs& R, int mt, int kt, int buf, bool with_b) {
@@ -137,7 +160,7 @@ k_pw_nt(const T* __restrict__ a, ProArgs pa, const T* __restrict__ w, T* __restr
             const int r = rb0 + i * rstep;
             if (r >= BM) continue;
             uint4 q = R.a[i];
-            if (PRO != DFD_PRO_NONE && c < kc && m0 + r < M) {
+            if (PRO != DFD_PRO_NONE && c < kc && m0 + r < M && (!CONV || ((R.ok >> i) & 1u))) {
                 const float* gk = nullptr;
                 if constexpr (PRO == DFD_PRO_BN_ACT_GATE) gk = pa.gate + (long)pro_image(pa, m0 + r) * K + k0 + c * E;
                 q = apply_pro_c<T, PRO, ACT, E>(R.a[i], R.a2[i], c0, c1, c2, gk);
@@ -632,7 +655,7 @@ static int pw_nt_launch(const void* a, const dfd_prologue* pro, const void* w, v
     dim3 grid(gx * n_tiles);
 #define LAUNCH_NT(PRO, RES, STATS)                                                                                        \
     hipLaunchKernelGGL((k_pw_nt<T, BN, BM, PRO, ACT, RES, STATS>), grid, dim3(DFD_THREADS), lds, st, (const T*)a, pa, (const T*)w, \
-                       (T*)out, (const T*)residual, M, K, Nout, m_tiles, n_tiles, gx, partials)
+                       (T*)out, (const T*)residual, M, K, Nout, m_tiles, n_tiles, gx, partials, ConvArgs{})
     // combinations used by the engine: forward = {NONE, BN_ACT, BN_ACT_GATE} x stats, no residual;
     // data gradient = AFFINE2 (+ residual), no stats; plain = NONE
     if (mode == DFD_PRO_AFFINE2) {
@@ -670,6 +693,55 @@ static int pw_nt_t(const void* a, const dfd_prologue* pro, const void* w, void* 
     if (Nout <= 64) PW_NT_GO(64);
     PW_NT_GO(128);
 #undef PW_NT_GO
+}
+
+// ---- dense k x k convolution as an implicit GEMM on the NT kernel (the A operand is gathered, nothing is materialised)
+template <typename T, int BN, int BM>
+static int conv_nt_launch(const void* x, const dfd_dwconv_shape* s, const float* in_bnstate, int in_act, const void* w,
+                          void* out, int Cout, float* partials, int pcap, int* nparts, hipStream_t st) {
+    const int M = s->N * s->Ho * s->Wo, K = s->k * s->k * s->C, Nout = Cout;
+    const int m_tiles = (M + BM - 1) / BM, n_tiles = (Nout + BN - 1) / BN;
+    int cap = partials ? (pcap < DFD_MAX_PARTIALS ? pcap : DFD_MAX_PARTIALS) : DFD_MAX_PARTIALS;
+    int gx = 2048 / n_tiles;
+    if (gx < 32) gx = 32;
+    if (gx > cap) gx = cap;
+    if (gx > m_tiles) gx = m_tiles;
+    if (partials) *nparts = gx;
+    constexpr int RED = DFD_THREADS * 2 * El<T>::EPC * 4;
+    int lds = NtLds<T, BN, BM>::TOTAL;
+    if (lds < RED) lds = RED;
+    ProArgs pa{nullptr, in_bnstate, nullptr, 1, 0u, -1};
+    ConvArgs cv{s->H, s->W, s->C, s->Ho, s->Wo, s->k, s->stride, s->pad_top, s->pad_left,
+                make_magic(s->Ho * s->Wo), make_magic(s->Wo), make_magic(s->C), make_magic(s->k)};
+    const bool stats = partials != nullptr;
+    dim3 grid(gx * n_tiles);
+#define LAUNCH_CV(PRO, STATS)                                                                                               \
+    hipLaunchKernelGGL((k_pw_nt<T, BN, BM, PRO, ACT, false, STATS, true>), grid, dim3(DFD_THREADS), lds, st, (const T*)x, pa,   \
+                       (const T*)w, (T*)out, (const T*)nullptr, M, K, Nout, m_tiles, n_tiles, gx, partials, cv)
+    if (!in_bnstate) {
+        constexpr int ACT = DFD_ACT_NONE;
+        if (stats) LAUNCH_CV(DFD_PRO_NONE, true); else LAUNCH_CV(DFD_PRO_NONE, false);
+    } else {
+        DISPATCH_ACT_PW(in_act, { if (stats) LAUNCH_CV(DFD_PRO_BN_ACT, true); else LAUNCH_CV(DFD_PRO_BN_ACT, false); });
+    }
+#undef LAUNCH_CV
+    return DFD_CHECK_LAUNCH();
+}
+
+extern "C" int dfd_conv_fwd(int dtype, const void* x, const dfd_dwconv_shape* s, const float* in_bnstate, int in_act,
+                            const void* w_nk, int Cout, void* y, float* partials, int pcap, int* nparts, dfd_stream stream) {
+    if (!x || !s || !w_nk || !y || Cout < 8 || Cout % 8 || s->C < 8 || s->C % 8 || s->k < 1 || s->k > 7 || s->stride < 1) return DFD_EINVAL;
+    if (s->N < 1 || s->Ho < 1 || s->Wo < 1 || (long)s->N * s->Ho * s->Wo > (1l << 30)) return DFD_EINVAL;
+    if (partials && (!nparts || pcap < 1)) return DFD_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const long M = (long)s->N * s->Ho * s->Wo;
+    const bool small = ((M + 127) / 128) * ((Cout + 127) / 128) < 256;
+#define CONV_GO(TT, BNV) return small ? conv_nt_launch<TT, BNV, 64>(x, s, in_bnstate, in_act, w_nk, y, Cout, partials, pcap, nparts, st) \
+                                      : conv_nt_launch<TT, BNV, 128>(x, s, in_bnstate, in_act, w_nk, y, Cout, partials, pcap, nparts, st)
+    if (dtype == DFD_BF16) { if (Cout <= 64) CONV_GO(bf16, 64); CONV_GO(bf16, 128); }
+    if (dtype == DFD_F32) { if (Cout <= 64) CONV_GO(float, 64); CONV_GO(float, 128); }
+#undef CONV_GO
+    return DFD_EINVAL;
 }
 
 extern "C" int dfd_pwconv_fwd(int dtype, const void* a, const dfd_prologue* pro, const void* w, void* out,

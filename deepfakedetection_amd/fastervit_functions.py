@@ -404,14 +404,10 @@ class ConvBlockFunction(torch.autograd.Function):
         N, H, W, C = x.shape
         need_bwd = any(ctx.needs_input_grad)
         w1_nk, w1_kn = _gemm_weight(w1, x.dtype, need_bwd)
-        col1 = K.im2col(x, None, ACT_NONE, 3, 1, 1, H, W)
-        y1, parts, n = K.pwconv(col1, None, w1_nk, None, stats=tr)
-        del col1
+        y1, parts, n = K.conv_fwd(x, None, ACT_NONE, w1_nk, 3, 1, 1, H, W, stats=tr)
         st1 = _bn_state(parts, n, N * H * W, cfg.bn1, g1, be1, tr, cfg.counters, conv_bias=b1)
         w2_nk, w2_kn = _gemm_weight(w2, x.dtype, need_bwd)
-        col2 = K.im2col(y1, st1, ACT_GELU, 3, 1, 1, H, W)
-        y2, parts, n = K.pwconv(col2, None, w2_nk, None, stats=tr)
-        del col2
+        y2, parts, n = K.conv_fwd(y1, st1, ACT_GELU, w2_nk, 3, 1, 1, H, W, stats=tr)
         st2 = _bn_state(parts, n, N * H * W, cfg.bn2, g2, be2, tr, cfg.counters, conv_bias=b2, ls=gamma)
         out = K.bn_act_apply(y2, st2, ACT_NONE, x, row_scale)
         ctx.cfg = cfg
@@ -469,8 +465,7 @@ class FVDownsampleFunction(torch.autograd.Function):
         xn, lnst = K.layernorm_fwd(x, ln_w, ln_b, 1e-6)
         w_nk, w_kn = _gemm_weight(w, x.dtype, need_bwd)
         Ho, Wo = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
-        col = K.im2col(xn, None, ACT_NONE, 3, 2, 1, Ho, Wo)
-        y, _, _ = K.pwconv(col, None, w_nk, None, stats=False)
+        y, _, _ = K.conv_fwd(xn, None, ACT_NONE, w_nk, 3, 2, 1, Ho, Wo, stats=False)
         ctx.save_for_backward(x, xn, lnst, w_kn, ln_w, ln_b, w)
         return y
 

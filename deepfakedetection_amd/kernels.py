@@ -748,6 +748,21 @@ def im2col(x: torch.Tensor, in_state: torch.Tensor | None, in_act: int, k: int, 
     return col
 
 
+def conv_fwd(x: torch.Tensor, in_state: torch.Tensor | None, in_act: int, w_nk: torch.Tensor, k: int, stride: int, pad: int,
+             Ho: int, Wo: int, stats: bool = False):
+    """Dense k x k convolution of act(bn(x)) (or x) with w_nk [Cout, k*k*C] as an implicit GEMM: (y, partials, nparts)."""
+    _chk_nhwc(x)
+    N, H, W, C = x.shape
+    Cout = w_nk.shape[0]
+    y = torch.empty((N, Ho, Wo, Cout), dtype=x.dtype, device=x.device)
+    parts = partials_buf(x.device, Cout) if stats else None
+    n = ctypes.c_int(0)
+    shp = _dw_shape(x.shape, Ho, Wo, k, stride, pad, pad)
+    check(_L().dfd_conv_fwd(_dt(x), _p(x), ctypes.byref(shp), _p(in_state), in_act, _p(w_nk), Cout, _p(y), _p(parts),
+                            MAX_PARTIALS, ctypes.byref(n), _stream()), "dfd_conv_fwd", f"{tuple(x.shape)} k{k}s{stride} -> {Cout}")
+    return y, parts, n.value
+
+
 def col2im(dcol: torch.Tensor, in_shape, k: int, stride: int, pad: int) -> torch.Tensor:
     N, H, W, C = in_shape
     Ho, Wo = dcol.shape[1], dcol.shape[2]

@@ -276,8 +276,7 @@ def dense_conv_fwd(x, wg_nk, b, gamma, beta, bn: BNRef, training, counters, k, s
     N, H, W, C = x.shape
     p = k // 2
     Ho, Wo = (H + 2 * p - k) // stride + 1, (W + 2 * p - k) // stride + 1
-    col = K.im2col(x, None, ACT_NONE, k, stride, p, Ho, Wo)
-    y, parts, n = K.pwconv(col, None, wg_nk, None, stats=training)
+    y, parts, n = K.conv_fwd(x, None, ACT_NONE, wg_nk, k, stride, p, Ho, Wo, stats=training)
     st = _bn_state(parts, n, N * Ho * Wo, bn, gamma, beta, training, counters, conv_bias=b)
     return y, st
 

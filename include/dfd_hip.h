@@ -66,7 +66,8 @@ typedef void* dfd_stream;          /* a hipStream_t */
  * 110 = the EfficientFormerV2 / FasterViT set (section "token mixers" below), the *_ex BatchNorm entry
  * points (convolution bias and LayerScale folded into the BatchNorm coefficients), GELU in every
  * prologue, and the bookkeeping kernels (dfd_rand, dfd_step_tick, dfd_axpby, dfd_add);
- * 111 = dfd_se_fwd / dfd_se_bwd (squeeze-excite in two / three launches); dfd_rowtable_grad takes a workspace. */
+ * 111 = dfd_se_fwd / dfd_se_bwd (squeeze-excite in two / three launches); dfd_rowtable_grad takes a workspace;
+ * dfd_conv_fwd (implicit-GEMM dense convolution). */
 int dfd_version(void);
 
 /* ---------------------------------------------------------------- BatchNorm ---
@@ -339,7 +340,16 @@ int dfd_bias_gather(const float* table, const int* idx, float* full, int H, int 
 int dfd_bias_scatter(const float* dfull, const int* idx, float* dtable, int H, int T, long L, int accumulate,
                      dfd_stream stream);
 
-/* Dense k x k convolution = im2col + the 1x1 GEMM entry points.  Shapes use dfd_dwconv_shape (C = input
+/* Dense k x k convolution, forward, as an implicit GEMM: the NT GEMM kernel gathers its A operand from the NHWC image
+ * (row = output pixel, column = (tap, input channel)), applying the producer's BN + activation to the gathered values
+ * (zero padding in the activated domain); nothing is materialised.  w_nk [Cout][k*k*C] in the activation dtype, column
+ * (kh*k + kw)*C + c (dfd_conv_weight_perm + dfd_pw_prep_weights).  C % 8 == 0, Cout % 8 == 0.  Output, partials and
+ * nparts as dfd_pwconv_fwd.  Reference call sites: the 3x3 convolutions of timm's EfficientFormerV2 stem and of
+ * NVlabs FasterViT's PatchEmbed / ConvBlock / Downsample, reached from trainers/*.py `model(x)`.                  */
+int dfd_conv_fwd(int dtype, const void* x, const dfd_dwconv_shape* s, const float* in_bnstate, int in_act,
+                 const void* w_nk, int Cout, void* y, float* partials, int pcap, int* nparts, dfd_stream stream);
+
+/* Dense k x k convolution = im2col + the 1x1 GEMM entry points (backward passes; forward: dfd_conv_fwd).  Shapes use dfd_dwconv_shape (C = input
  * channels).  col [N*Ho*Wo][k*k*C] with column index (kh*k + kw)*C + c; zero padding in the activated domain. */
 int dfd_im2col(int dtype, const void* x, const float* in_bnstate, int in_act, void* col,
                const dfd_dwconv_shape* s, dfd_stream stream);

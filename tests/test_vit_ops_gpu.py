@@ -488,3 +488,29 @@ def test_wave_autonomous_wgrad_with_bn_act_prologue(act):
     dp2, dcoef, dst = p2.cuda(), coef3.cuda(), st.cuda()
     got = K.pwconv_wgrad(p.cuda(), K.pro_affine2(dp2, dcoef), q.cuda(), K.pro_bn_act(dst, act))
     close(got, want.float(), 4e-3, "wgrad affine2 x bn_act")
+
+
+@pytest.mark.parametrize("rd", DT)
+@pytest.mark.parametrize("cfg", [(3, 1, 1, 64, 64, 28, 6), (3, 2, 1, 24, 48, 15, 3), (3, 1, 1, 128, 128, 9, 5), (3, 2, 1, 96, 192, 14, 2)])
+def test_dense_conv_as_implicit_gemm(rd, cfg):
+    """dfd_conv_fwd (the GEMM kernel gathers its A operand from the image) against the im2col + GEMM pair it
+    replaces (same kernel, same summation order: identical) and against torch's conv2d; with and without the
+    producer's BN + GELU, with BN statistics."""
+    K = _k()
+    k, s, p, C, Co, H, N = cfg
+    Ho = (H + 2 * p - k) // s + 1
+    x = gen((N, H, H, C), 1, rd).cuda()
+    st = rand_state(C, 2).cuda()
+    w = gen((Co, C, k, k), 3, torch.float32, C ** -0.5)
+    w_nk, _ = K.prep_weights(K.conv_weight_to_gemm(w.cuda()), rd, True, False)
+    for state, act in ((None, R.ACT_NONE), (st, R.ACT_GELU)):
+        col = K.im2col(x, state, act, k, s, p, Ho, Ho)
+        y0, parts0, n0 = K.pwconv(col, None, w_nk, None, stats=True)
+        y1, parts1, n1 = K.conv_fwd(x, state, act, w_nk, k, s, p, Ho, Ho, stats=True)
+        assert torch.equal(y0, y1), float((y0.float() - y1.float()).abs().max())
+        assert n0 == n1 and torch.equal(parts0[:n0 * 2 * Co], parts1[:n1 * 2 * Co])
+        y2, _, _ = K.conv_fwd(x, state, act, w_nk, k, s, p, Ho, Ho, stats=False)
+        assert torch.equal(y1, y2)
+        a = x.float().cpu() if state is None else R.rnd(F.gelu(st.cpu()[0] * x.float().cpu() + st.cpu()[1]), rd)
+        want = F.conv2d(a.permute(0, 3, 1, 2), R.rnd(w, rd), stride=s, padding=p).permute(0, 2, 3, 1)
+        close(y1, want, tol(rd), "implicit-GEMM conv vs conv2d")
