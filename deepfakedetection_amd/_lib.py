@@ -108,6 +108,8 @@ SIGNATURES: dict[str, tuple] = {
     "dfd_bias_scatter": (c_int, [P, P, P, c_int, c_int, c_long, c_int, P]),
     "dfd_im2col": (c_int, [c_int, P, P, c_int, P, POINTER(DwShape), P]),
     "dfd_conv_fwd": (c_int, [c_int, P, POINTER(DwShape), P, c_int, P, c_int, P, P, c_int, POINTER(c_int), P]),
+    "dfd_conv_wgrad_ws": (c_size_t, [POINTER(DwShape), c_int]),
+    "dfd_conv_wgrad": (c_int, [c_int, P, P, c_int, P, POINTER(DwShape), P, c_int, P, c_int, P, c_size_t, P]),
     "dfd_col2im": (c_int, [c_int, P, P, POINTER(DwShape), P]),
     "dfd_conv_weight_perm": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P]),
     "dfd_layernorm_fwd": (c_int, [c_int, P, P, P, c_float, P, P, c_long, c_int, P]),

@@ -325,10 +325,12 @@ k_pw_nt(const T* __restrict__ a, ProArgs pa, const T* __restrict__ w, T* __restr
 
 #define TN_F32_ROW 576  // (128 + 16) floats: kq rows land on disjoint bank halves
 
-template <typename T, int PROP, int PROQ, int ACT>
+// CONV: q is gathered from an NHWC image as the im2col matrix of a dense k x k convolution would hold it (row m = output
+// pixel, column = (tap, channel)); its prologue coefficients are per input channel
+template <typename T, int PROP, int PROQ, int ACT, bool CONV = false>
 __global__ void __launch_bounds__(DFD_THREADS, 2)
 k_pw_tn(const T* __restrict__ p, ProArgs pp, int Ni, const T* __restrict__ q, ProArgs pq, int Nj, int M,
-        int i_tiles, int j_tiles, int rows_per_split, int gate_imgs, float* __restrict__ ws) {
+        int i_tiles, int j_tiles, int rows_per_split, int gate_imgs, float* __restrict__ ws, ConvArgs cv) {
     constexpr int E = El<T>::EPC;
     constexpr int BMK = (sizeof(T) == 2) ? 64 : 32;         // reduction rows per step
     constexpr int ROWB = (sizeof(T) == 2) ? 256 : TN_F32_ROW;
@@ -390,7 +392,10 @@ k_pw_tn(const T* __restrict__ p, ProArgs pp, int Ni, const T* __restrict__ q, Pr
             const int r = i / TN_B, c = i - r * TN_B;
             float v = 0.f;
             if (r < 3) { if (PROP == DFD_PRO_AFFINE2 && i0 + c < Ni) v = pp.coef[r * Ni + i0 + c]; }
-            else if (PROQ != DFD_PRO_NONE && j0 + c < Nj) v = pq.coef[(r - 3) * Nj + j0 + c];
+            else if (PROQ != DFD_PRO_NONE && j0 + c < Nj) {
+                if constexpr (CONV) { const int k = j0 + c; v = pq.coef[(r - 3) * cv.C + (k - udiv(k, cv.c) * cv.C)]; }
+                else v = pq.coef[(r - 3) * Nj + j0 + c];
+            }
             ctab[i] = v;
         }
         if constexpr (PROQ == DFD_PRO_BN_ACT_GATE) {
@@ -413,7 +418,9 @@ k_pw_tn(const T* __restrict__ p, ProArgs pp, int Ni, const T* __restrict__ q, Pr
         for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
     uint4 rp[MAXI], rp2[MAXI], rq[MAXI];
+    unsigned qok = 0u;                                          // CONV: which of this step's q chunks lie inside the image
     auto g_load = [&](int mb) {
+        if constexpr (CONV) qok = 0u;
 #pragma unroll
         for (int i = 0; i < MAXI; ++i) {
             rp[i] = make_uint4(0, 0, 0, 0); rq[i] = make_uint4(0, 0, 0, 0);
@@ -425,8 +432,21 @@ k_pw_tn(const T* __restrict__ p, ProArgs pp, int Ni, const T* __restrict__ q, Pr
                 rp[i] = *reinterpret_cast<const uint4*>(p + off);
                 if constexpr (PROP == DFD_PRO_AFFINE2) rp2[i] = *reinterpret_cast<const uint4*>(p2 + off);
             }
-            if ((b_ >> 16) && mbq < mend)
-                rq[i] = *reinterpret_cast<const uint4*>(q + (long)mbq * Nj + j0 + ((b_ >> 8) & 255) * E);
+            if ((b_ >> 16) && mbq < mend) {
+                if constexpr (CONV) {
+                    const int k = j0 + ((b_ >> 8) & 255) * E, tap = udiv(k, cv.c), ch = k - tap * cv.C;
+                    const int dy = udiv(tap, cv.kk), dx = tap - dy * cv.ks;
+                    const int n = udiv(mbq, cv.howo), rem = mbq - n * (cv.Ho * cv.Wo);
+                    const int oy = udiv(rem, cv.wo), ox = rem - oy * cv.Wo;
+                    const int iy = oy * cv.stride - cv.pt + dy, ix = ox * cv.stride - cv.pl + dx;
+                    if ((unsigned)iy < (unsigned)cv.H && (unsigned)ix < (unsigned)cv.W) {
+                        rq[i] = *reinterpret_cast<const uint4*>(q + (((long)n * cv.H + iy) * cv.W + ix) * cv.C + ch);
+                        qok |= 1u << i;
+                    }
+                } else {
+                    rq[i] = *reinterpret_cast<const uint4*>(q + (long)mbq * Nj + j0 + ((b_ >> 8) & 255) * E);
+                }
+            }
         }
     };
     auto s_store = [&](int mb, int buf) {
@@ -451,7 +471,7 @@ k_pw_tn(const T* __restrict__ p, ProArgs pp, int Ni, const T* __restrict__ q, Pr
             if (b_ >> 16) {
                 const int r = b_ & 255, chk = (b_ >> 8) & 255, m = mb + r;
                 uint4 v = rq[i];
-                if (PROQ != DFD_PRO_NONE && m < mend) {
+                if (PROQ != DFD_PRO_NONE && m < mend && (!CONV || ((qok >> i) & 1u))) {
                     float c0[E], c1[E], gt[E];
                     load_f32<E>(ctab + 3 * TN_B + chk * E, c0);
                     load_f32<E>(ctab + 4 * TN_B + chk * E, c1);
@@ -816,7 +836,7 @@ static int pw_tn_t(const void* p, const dfd_prologue* pro_p, int Ni, const void*
     dim3 grid(it * jt, splits);
 #define LAUNCH_TN(PP, PQ)                                                                                                \
     hipLaunchKernelGGL((k_pw_tn<T, PP, PQ, ACT>), grid, dim3(DFD_THREADS), lds, st, (const T*)p, pp, Ni, (const T*)q, pq, Nj, \
-                       M, it, jt, rps, gate_imgs, ws)
+                       M, it, jt, rps, gate_imgs, ws, ConvArgs{})
     if (mq == DFD_PRO_NONE) {
         constexpr int ACT = DFD_ACT_NONE;
         if (mp == DFD_PRO_AFFINE2) LAUNCH_TN(DFD_PRO_AFFINE2, DFD_PRO_NONE); else LAUNCH_TN(DFD_PRO_NONE, DFD_PRO_NONE);
@@ -828,6 +848,54 @@ static int pw_tn_t(const void* p, const dfd_prologue* pro_p, int Ni, const void*
 #undef LAUNCH_TN
     if (hipGetLastError() != hipSuccess) return DFD_ELAUNCH;
     return dfd_launch_sum_partials(ws, splits, (long)Ni * Nj, dw, accumulate, st);
+}
+
+// ---- weight gradient of a dense k x k convolution: dw[Cout][k*k*C] = sum_m P(p)[m][co] * im2col(Q(x))[m][(tap, c)],
+// the im2col operand gathered inside the TN kernel
+template <typename T>
+static int conv_tn_t(const void* p, const dfd_prologue* pro_p, int Cout, const void* x, const dfd_dwconv_shape* s,
+                     const float* in_bnstate, int in_act, float* dw, int accumulate, float* ws, size_t ws_bytes, hipStream_t st) {
+    const int M = s->N * s->Ho * s->Wo, Ni = Cout, Nj = s->k * s->k * s->C;
+    int it, jt, splits, rps;
+    tn_plan(sizeof(T) == 2 ? DFD_BF16 : DFD_F32, M, Ni, Nj, &it, &jt, &splits, &rps);
+    if ((size_t)(splits + splits / 32 + 2) * Ni * Nj * 4 > ws_bytes) return DFD_EWORKSPACE;
+    constexpr int BMK = (sizeof(T) == 2) ? 64 : 32;
+    constexpr int ROWB = (sizeof(T) == 2) ? 256 : TN_F32_ROW;
+    const int lds = 2 * 2 * BMK * ROWB + 5 * TN_B * 4;
+    const ProArgs pp = pro_args(pro_p);
+    ProArgs pq{nullptr, in_bnstate, nullptr, 1, 0u, -1};
+    const int mp = pro_p ? pro_p->mode : DFD_PRO_NONE;
+    if (!(mp == DFD_PRO_NONE || mp == DFD_PRO_AFFINE2)) return DFD_EUNSUPPORTED;
+    ConvArgs cv{s->H, s->W, s->C, s->Ho, s->Wo, s->k, s->stride, s->pad_top, s->pad_left,
+                make_magic(s->Ho * s->Wo), make_magic(s->Wo), make_magic(s->C), make_magic(s->k)};
+    dim3 grid(it * jt, splits);
+#define LAUNCH_CTN(PP, PQ)                                                                                                  \
+    hipLaunchKernelGGL((k_pw_tn<T, PP, PQ, ACT, true>), grid, dim3(DFD_THREADS), lds, st, (const T*)p, pp, Ni, (const T*)x, pq, \
+                       Nj, M, it, jt, rps, 0, ws, cv)
+    if (!in_bnstate) {
+        constexpr int ACT = DFD_ACT_NONE;
+        if (mp == DFD_PRO_AFFINE2) LAUNCH_CTN(DFD_PRO_AFFINE2, DFD_PRO_NONE); else LAUNCH_CTN(DFD_PRO_NONE, DFD_PRO_NONE);
+    } else {
+        DISPATCH_ACT_PW(in_act, { if (mp == DFD_PRO_AFFINE2) LAUNCH_CTN(DFD_PRO_AFFINE2, DFD_PRO_BN_ACT); else LAUNCH_CTN(DFD_PRO_NONE, DFD_PRO_BN_ACT); });
+    }
+#undef LAUNCH_CTN
+    if (hipGetLastError() != hipSuccess) return DFD_ELAUNCH;
+    return dfd_launch_sum_partials(ws, splits, (long)Ni * Nj, dw, accumulate, st);
+}
+
+extern "C" size_t dfd_conv_wgrad_ws(const dfd_dwconv_shape* s, int Cout) {
+    if (!s || Cout < 1) return 0;
+    return dfd_pwconv_wgrad_ws(s->N * s->Ho * s->Wo, Cout, s->k * s->k * s->C);
+}
+extern "C" int dfd_conv_wgrad(int dtype, const void* p, const dfd_prologue* pro_p, int Cout, const void* x,
+                              const dfd_dwconv_shape* s, const float* in_bnstate, int in_act, float* dw, int accumulate,
+                              float* ws, size_t ws_bytes, dfd_stream stream) {
+    if (!p || !x || !s || !dw || !ws || Cout < 8 || Cout % 8 || s->C < 8 || s->C % 8 || !pro_ok(pro_p)) return DFD_EINVAL;
+    if (s->N < 1 || s->Ho < 1 || s->Wo < 1 || (long)s->N * s->Ho * s->Wo > (1l << 30)) return DFD_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == DFD_BF16) return conv_tn_t<bf16>(p, pro_p, Cout, x, s, in_bnstate, in_act, dw, accumulate, ws, ws_bytes, st);
+    if (dtype == DFD_F32) return conv_tn_t<float>(p, pro_p, Cout, x, s, in_bnstate, in_act, dw, accumulate, ws, ws_bytes, st);
+    return DFD_EINVAL;
 }
 
 extern "C" int dfd_pwconv_wgrad(int dtype, const void* p, const dfd_prologue* pro_p, int Ni, const void* q,

@@ -432,9 +432,7 @@ class ConvBlockFunction(torch.autograd.Function):
         pro2 = K.pro_affine2(y2, coef2)
         dw2 = None
         if need[5]:
-            col2 = K.im2col(y1, st1, ACT_GELU, 3, 1, 1, H, W)
-            dwg = K.pwconv_wgrad(gb, pro2, col2, None)
-            del col2
+            dwg = K.conv_wgrad(gb, pro2, y1, st1, ACT_GELU, 3, 1, 1)
             dw2 = K.conv_wgrad_from_gemm(dwg, tuple(w2.shape), _slot(w2, True, tuple(w2.shape)))
         dcol2, _, _ = K.pwconv(gb, pro2, w2_kn, None, stats=False)
         da1 = K.col2im(dcol2, (N, H, W, C), 3, 1, 1)
@@ -446,9 +444,7 @@ class ConvBlockFunction(torch.autograd.Function):
         pro1 = K.pro_affine2(y1, coef1)
         dw1 = dx = None
         if need[1]:
-            col1 = K.im2col(x, None, ACT_NONE, 3, 1, 1, H, W)
-            dwg = K.pwconv_wgrad(dz1, pro1, col1, None)
-            del col1
+            dwg = K.conv_wgrad(dz1, pro1, x, None, ACT_NONE, 3, 1, 1)
             dw1 = K.conv_wgrad_from_gemm(dwg, tuple(w1.shape), _slot(w1, True, tuple(w1.shape)))
         if need[0]:
             dcol1, _, _ = K.pwconv(dz1, pro1, w1_kn, None, stats=False)
@@ -477,9 +473,7 @@ class FVDownsampleFunction(torch.autograd.Function):
         g = _c(g)
         dw = dx = dlw = dlb = None
         if need[3]:
-            col = K.im2col(xn, None, ACT_NONE, 3, 2, 1, g.shape[1], g.shape[2])
-            dwg = K.pwconv_wgrad(g, None, col, None)
-            del col
+            dwg = K.conv_wgrad(g, None, xn, None, ACT_NONE, 3, 2, 1)
             dw = K.conv_wgrad_from_gemm(dwg, tuple(w.shape), _slot(w, True, tuple(w.shape)))
         if need[0] or need[1] or need[2]:
             dcol, _, _ = K.pwconv(g, None, w_kn, None, stats=False)

@@ -763,6 +763,23 @@ def conv_fwd(x: torch.Tensor, in_state: torch.Tensor | None, in_act: int, w_nk: 
     return y, parts, n.value
 
 
+def conv_wgrad(p: torch.Tensor, pro_p: Prologue | None, x: torch.Tensor, in_state: torch.Tensor | None, in_act: int, k: int,
+               stride: int, pad: int, out: torch.Tensor | None = None) -> torch.Tensor:
+    """dw[Cout, k*k*C] (GEMM column order) = sum_m P(p)[m, co] * im2col(act(bn(x)))[m, :], the im2col operand gathered."""
+    _chk_nhwc(x)
+    Cout = p.shape[-1]
+    _, Ho, Wo, _ = p.shape
+    C = x.shape[-1]
+    shp = _dw_shape(x.shape, Ho, Wo, k, stride, pad, pad)
+    nbytes = int(_L().dfd_conv_wgrad_ws(ctypes.byref(shp), Cout))
+    ws = scratch(p.device, "wgrad_ws", nbytes)
+    dw = _dst(out, (Cout, k * k * C), p.device)
+    check(_L().dfd_conv_wgrad(_dt(p), _p(p), ctypes.byref(pro_p) if pro_p is not None else None, Cout, _p(x), ctypes.byref(shp),
+                              _p(in_state), in_act, _p(dw), 0, _p(ws), ws.numel() * 4, _stream()), "dfd_conv_wgrad",
+          f"{tuple(x.shape)} k{k}s{stride} Cout={Cout}")
+    return dw
+
+
 def col2im(dcol: torch.Tensor, in_shape, k: int, stride: int, pad: int) -> torch.Tensor:
     N, H, W, C = in_shape
     Ho, Wo = dcol.shape[1], dcol.shape[2]

@@ -294,8 +294,7 @@ def dense_conv_bwd(dz, parts, n, x, y, st, wg_kn, w, b, gamma, beta, training, k
         dcol, _, _ = K.pwconv(dz, pro, wg_kn, None, stats=False)
         dx = K.col2im(dcol, tuple(x.shape), k, stride, p)
     if need_w:
-        col = K.im2col(x, None, ACT_NONE, k, stride, p, y.shape[1], y.shape[2])
-        dwg = K.pwconv_wgrad(dz, pro, col, None)
+        dwg = K.conv_wgrad(dz, pro, x, None, ACT_NONE, k, stride, p)
         dw = K.conv_wgrad_from_gemm(dwg, tuple(w.shape), _slot(w, True, tuple(w.shape)))
     return dx, dw, db, dgamma, dbeta
 

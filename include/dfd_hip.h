@@ -67,7 +67,7 @@ typedef void* dfd_stream;          /* a hipStream_t */
  * points (convolution bias and LayerScale folded into the BatchNorm coefficients), GELU in every
  * prologue, and the bookkeeping kernels (dfd_rand, dfd_step_tick, dfd_axpby, dfd_add);
  * 111 = dfd_se_fwd / dfd_se_bwd (squeeze-excite in two / three launches); dfd_rowtable_grad takes a workspace;
- * dfd_conv_fwd (implicit-GEMM dense convolution). */
+ * dfd_conv_fwd / dfd_conv_wgrad (implicit-GEMM dense convolution). */
 int dfd_version(void);
 
 /* ---------------------------------------------------------------- BatchNorm ---
@@ -349,7 +349,15 @@ int dfd_bias_scatter(const float* dfull, const int* idx, float* dtable, int H, i
 int dfd_conv_fwd(int dtype, const void* x, const dfd_dwconv_shape* s, const float* in_bnstate, int in_act,
                  const void* w_nk, int Cout, void* y, float* partials, int pcap, int* nparts, dfd_stream stream);
 
-/* Dense k x k convolution = im2col + the 1x1 GEMM entry points (backward passes; forward: dfd_conv_fwd).  Shapes use dfd_dwconv_shape (C = input
+/* Weight gradient of the same convolution: dw[Cout][k*k*C] (f32, GEMM column order) = sum over output pixels of
+ * P(p)[m][co] * im2col(act(bn(x)))[m][(tap, c)], the im2col operand gathered inside the TN kernel.  p / pro_p as for
+ * dfd_pwconv_wgrad (DFD_PRO_NONE or the BN-backward map DFD_PRO_AFFINE2); ws: dfd_conv_wgrad_ws() bytes.            */
+size_t dfd_conv_wgrad_ws(const dfd_dwconv_shape* s, int Cout);
+int dfd_conv_wgrad(int dtype, const void* p, const dfd_prologue* pro_p, int Cout, const void* x,
+                   const dfd_dwconv_shape* s, const float* in_bnstate, int in_act, float* dw, int accumulate,
+                   float* ws, size_t ws_bytes, dfd_stream stream);
+
+/* Dense k x k convolution = im2col + the 1x1 GEMM entry points (data gradient; forward: dfd_conv_fwd).  Shapes use dfd_dwconv_shape (C = input
  * channels).  col [N*Ho*Wo][k*k*C] with column index (kh*k + kw)*C + c; zero padding in the activated domain. */
 int dfd_im2col(int dtype, const void* x, const float* in_bnstate, int in_act, void* col,
                const dfd_dwconv_shape* s, dfd_stream stream);

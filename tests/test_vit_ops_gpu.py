@@ -514,3 +514,24 @@ def test_dense_conv_as_implicit_gemm(rd, cfg):
         a = x.float().cpu() if state is None else R.rnd(F.gelu(st.cpu()[0] * x.float().cpu() + st.cpu()[1]), rd)
         want = F.conv2d(a.permute(0, 3, 1, 2), R.rnd(w, rd), stride=s, padding=p).permute(0, 2, 3, 1)
         close(y1, want, tol(rd), "implicit-GEMM conv vs conv2d")
+
+
+@pytest.mark.parametrize("rd", DT)
+@pytest.mark.parametrize("cfg", [(3, 1, 1, 64, 64, 28, 6), (3, 2, 1, 24, 48, 15, 3), (3, 1, 1, 128, 128, 9, 5), (3, 2, 1, 96, 192, 14, 2)])
+def test_dense_conv_weight_gradient_as_implicit_gemm(rd, cfg):
+    """dfd_conv_wgrad (the TN kernel gathers the im2col operand) against im2col + dfd_pwconv_wgrad: same kernel, same
+    split of the rows, same summation order -> identical; with the BN-backward map on the gradient operand and the
+    producer's BN + GELU on the gathered one."""
+    K = _k()
+    k, s, p, C, Co, H, N = cfg
+    Ho = (H + 2 * p - k) // s + 1
+    x = gen((N, H, H, C), 1, rd).cuda()
+    st = rand_state(C, 2).cuda()
+    dz, y = gen((N, Ho, Ho, Co), 3, rd).cuda(), gen((N, Ho, Ho, Co), 4, rd).cuda()
+    coef = rand_state(Co, 5)[:3].contiguous().cuda()
+    for pro_p in (None, K.pro_affine2(y, coef)):
+        for state, act in ((None, R.ACT_NONE), (st, R.ACT_GELU)):
+            col = K.im2col(x, state, act, k, s, p, Ho, Ho)
+            want = K.pwconv_wgrad(dz, pro_p, col, None)
+            got = K.conv_wgrad(dz, pro_p, x, state, act, k, s, p)
+            assert torch.equal(want, got), float((want - got).abs().max())
