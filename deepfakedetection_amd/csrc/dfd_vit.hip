@@ -1087,6 +1087,7 @@ extern "C" int dfd_col2im(int dtype, const void* dcol, void* dx, const dfd_dwcon
 }
 // torch conv weight [O][I][k][k] f32 <-> GEMM layout [O][(kh,kw,i)]:
 //   to_gemm = 1: dst[o][(kh*k+kw)*I + i] = src[o][i][kh][kw];   to_gemm = 0: the inverse (weight gradient back to torch's layout)
+//   to_gemm = 2: dst[i][((k-1-kh)*k + (k-1-kw))*O + o] = src[o][i][kh][kw]  (transposed + flipped: data gradient of a stride-1 conv)
 __global__ void k_conv_weight_perm(const float* __restrict__ src, float* __restrict__ dst, int O, int I, int k, int to_gemm, int accumulate) {
     const long tot = (long)O * I * k * k;
     const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1098,7 +1099,11 @@ __global__ void k_conv_weight_perm(const float* __restrict__ src, float* __restr
     const int i = (int)(tq % I);
     const long o = tq / I;
     const long g = (o * k * k + (long)kh * k + kw) * I + i;
-    if (to_gemm) dst[g] = src[e];
+    if (to_gemm == 2) {
+        // data-gradient operand of a stride-1 convolution: [I][(flipped tap, o)], i.e. the weight of the forward
+        // convolution that maps the output gradient (O channels) back to the input (I channels)
+        dst[((long)i * k * k + (long)(k - 1 - kh) * k + (k - 1 - kw)) * O + o] = src[e];
+    } else if (to_gemm) dst[g] = src[e];
     else dst[e] = (accumulate ? dst[e] : 0.f) + src[g];
 }
 extern "C" int dfd_conv_weight_perm(const float* src, float* dst, int O, int I, int k, int to_gemm, int accumulate, dfd_stream stream) {

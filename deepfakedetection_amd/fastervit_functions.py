@@ -403,10 +403,12 @@ class ConvBlockFunction(torch.autograd.Function):
         tr = cfg.training
         N, H, W, C = x.shape
         need_bwd = any(ctx.needs_input_grad)
-        w1_nk, w1_kn = _gemm_weight(w1, x.dtype, need_bwd)
+        w1_nk, _ = _gemm_weight(w1, x.dtype, False)
+        w1_kn = _dgrad_weight(w1, x.dtype) if need_bwd else None          # [C][(flipped tap, co)]: stride-1 data gradient
         y1, parts, n = K.conv_fwd(x, None, ACT_NONE, w1_nk, 3, 1, 1, H, W, stats=tr)
         st1 = _bn_state(parts, n, N * H * W, cfg.bn1, g1, be1, tr, cfg.counters, conv_bias=b1)
-        w2_nk, w2_kn = _gemm_weight(w2, x.dtype, need_bwd)
+        w2_nk, _ = _gemm_weight(w2, x.dtype, False)
+        w2_kn = _dgrad_weight(w2, x.dtype) if need_bwd else None
         y2, parts, n = K.conv_fwd(y1, st1, ACT_GELU, w2_nk, 3, 1, 1, H, W, stats=tr)
         st2 = _bn_state(parts, n, N * H * W, cfg.bn2, g2, be2, tr, cfg.counters, conv_bias=b2, ls=gamma)
         out = K.bn_act_apply(y2, st2, ACT_NONE, x, row_scale)
@@ -434,9 +436,9 @@ class ConvBlockFunction(torch.autograd.Function):
         if need[5]:
             dwg = K.conv_wgrad(gb, pro2, y1, st1, ACT_GELU, 3, 1, 1)
             dw2 = K.conv_wgrad_from_gemm(dwg, tuple(w2.shape), _slot(w2, True, tuple(w2.shape)))
-        dcol2, _, _ = K.pwconv(gb, pro2, w2_kn, None, stats=False)
-        da1 = K.col2im(dcol2, (N, H, W, C), 3, 1, 1)
-        del dcol2
+        # data gradient of a stride-1 convolution = the forward (implicit-GEMM) convolution of the BN-backward-mapped
+        # gradient with the flipped, transposed weight: no [M][9C] column matrix, no col2im
+        da1, _, _ = K.conv_fwd(K.affine2_apply(gb, y2, coef2), None, ACT_NONE, w2_kn, 3, 1, 1, H, W, stats=False)
         dz1, parts, n = K.act_bn_bwd(da1, y1, None, None, st1, ACT_GELU)
         nb1 = need[3] or need[4]
         outs = (_slot(g1, nb1, (C,)), _slot(be1, nb1, (C,)), None, _slot(b1, need[2], (C,)))
@@ -447,9 +449,14 @@ class ConvBlockFunction(torch.autograd.Function):
             dwg = K.conv_wgrad(dz1, pro1, x, None, ACT_NONE, 3, 1, 1)
             dw1 = K.conv_wgrad_from_gemm(dwg, tuple(w1.shape), _slot(w1, True, tuple(w1.shape)))
         if need[0]:
-            dcol1, _, _ = K.pwconv(dz1, pro1, w1_kn, None, stats=False)
-            dx = K.add(K.col2im(dcol1, (N, H, W, C), 3, 1, 1), g)
+            dx0, _, _ = K.conv_fwd(K.affine2_apply(dz1, y1, coef1), None, ACT_NONE, w1_kn, 3, 1, 1, H, W, stats=False)
+            dx = K.add(dx0, g)
         return (dx, dw1, db1 if need[2] else None, dg1, dbe1, dw2, db2 if need[6] else None, dg2, dbe2, dgam, None, None)
+
+
+def _dgrad_weight(w: torch.Tensor, dt: torch.dtype):
+    w_nk, _ = K.prep_weights(K.conv_weight_to_dgrad_gemm(w), dt, True, False)
+    return w_nk
 
 
 # =========================================================================== Downsample (LayerNorm2d + conv3x3 s2)

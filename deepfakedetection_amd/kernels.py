@@ -797,6 +797,15 @@ def conv_weight_to_gemm(w: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def conv_weight_to_dgrad_gemm(w: torch.Tensor) -> torch.Tensor:
+    """torch [O, I, k, k] f32 -> [I, k*k*O] f32, taps flipped: the forward-convolution weight that carries the output
+    gradient of a stride-1 convolution back to its input (dfd_conv_fwd on the gradient tensor)."""
+    O, I, k, _ = w.shape
+    out = torch.empty((I, k * k * O), dtype=torch.float32, device=w.device)
+    check(_L().dfd_conv_weight_perm(_p(w), _p(out), O, I, k, 2, 0, _stream()), "dfd_conv_weight_perm")
+    return out
+
+
 def conv_wgrad_from_gemm(dw_gemm: torch.Tensor, shape, out: torch.Tensor | None = None) -> torch.Tensor:
     O, I, k, _ = shape
     dw = _dst(out, (O, I, k, k), dw_gemm.device)

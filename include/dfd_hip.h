@@ -362,7 +362,8 @@ int dfd_conv_wgrad(int dtype, const void* p, const dfd_prologue* pro_p, int Cout
 int dfd_im2col(int dtype, const void* x, const float* in_bnstate, int in_act, void* col,
                const dfd_dwconv_shape* s, dfd_stream stream);
 int dfd_col2im(int dtype, const void* dcol, void* dx, const dfd_dwconv_shape* s, dfd_stream stream);
-/* torch's [O][I][k][k] f32 <-> the GEMM's [O][(kh,kw,i)]; to_gemm = 0 maps a weight gradient back            */
+/* torch's [O][I][k][k] f32 <-> the GEMM's [O][(kh,kw,i)]; to_gemm = 0 maps a weight gradient back; to_gemm = 2 writes
+ * [I][(flipped tap, o)]: with it the data gradient of a stride-1 convolution is dfd_conv_fwd on the output gradient   */
 int dfd_conv_weight_perm(const float* src, float* dst, int O, int I, int k, int to_gemm, int accumulate,
                          dfd_stream stream);
 

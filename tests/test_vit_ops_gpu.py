@@ -535,3 +535,25 @@ def test_dense_conv_weight_gradient_as_implicit_gemm(rd, cfg):
             want = K.pwconv_wgrad(dz, pro_p, col, None)
             got = K.conv_wgrad(dz, pro_p, x, state, act, k, s, p)
             assert torch.equal(want, got), float((want - got).abs().max())
+
+
+@pytest.mark.parametrize("rd", DT)
+@pytest.mark.parametrize("cfg", [(3, 64, 96, 14, 3), (3, 128, 128, 9, 2), (5, 32, 48, 11, 2)])
+def test_stride1_conv_data_gradient_is_a_forward_conv_with_the_flipped_weight(rd, cfg):
+    """dx of a stride-1 'same' convolution = dfd_conv_fwd of the output gradient with the [I][(flipped tap, o)] weight
+    (dfd_conv_weight_perm mode 2): against torch autograd and against the column-matrix path it replaces."""
+    K = _k()
+    k, C, Co, H, N = cfg
+    p = k // 2
+    w = gen((Co, C, k, k), 1, torch.float32, (C * k * k) ** -0.5)
+    g = gen((N, H, H, Co), 2, rd)
+    x = torch.zeros((N, C, H, H), requires_grad=True)
+    F.conv2d(x, R.rnd(w, rd), padding=p).backward(g.float().permute(0, 3, 1, 2))
+    want = x.grad.permute(0, 2, 3, 1)
+    wd_nk, _ = K.prep_weights(K.conv_weight_to_dgrad_gemm(w.cuda()), rd, True, False)
+    got, _, _ = K.conv_fwd(g.cuda(), None, R.ACT_NONE, wd_nk, k, 1, p, H, H, stats=False)
+    close(got, want, tol(rd), "dgrad as forward conv")
+    _, w_kn = K.prep_weights(K.conv_weight_to_gemm(w.cuda()), rd, False, True)
+    dcol, _, _ = K.pwconv(g.cuda(), None, w_kn, None, stats=False)
+    old = K.col2im(dcol, (N, H, H, C), k, 1, p)
+    close(got, old.float().cpu(), tol(rd), "dgrad: implicit GEMM vs column matrix + col2im")
