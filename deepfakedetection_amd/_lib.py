@@ -84,6 +84,8 @@ SIGNATURES: dict[str, tuple] = {
     "dfd_softmax_argmax": (c_int, [P, c_int, c_int, P, P, P]),
     "dfd_adamw_step": (c_int, [P, c_int, P, P]),
     # ---- ABI 111
+    "dfd_sum_batch_begin": (c_int, []),
+    "dfd_sum_batch_end": (c_int, []),
     "dfd_se_fwd": (c_int, [c_int, P, P, c_int, c_int, c_int, c_int, P, P, P, P, c_int, c_int, P, P, P, P, P, c_size_t, P]),
     "dfd_se_bwd": (c_int, [c_int, P, P, P, c_int, c_int, c_int, c_int, P, P, P, P, P, c_int, c_int, P, P, P, P, P, P, c_int,
                            P, c_size_t, P, P]),

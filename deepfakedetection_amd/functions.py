@@ -186,6 +186,13 @@ class MBConvFunction(torch.autograd.Function):
         geom = cfg.dw
         N, H, W, Cin = ctx.in_shape
         _, Ho, Wo, Cmid = y2.shape
+        with K.sum_batch():        # the three weight gradients' final sums: one pair of launches at the end of the block
+            return MBConvFunction._backward(ctx, g, cfg, x, y1, y2, y3, st1, st2, st3, pooled, hpre, gate, wexp_kn, wproj_kn,
+                                            w_dw, w1, w2t, g_exp, g_dw, g_proj, row_scale, need, tr, geom, N, H, W, Cin, Ho, Wo, Cmid)
+
+    @staticmethod
+    def _backward(ctx, g, cfg, x, y1, y2, y3, st1, st2, st3, pooled, hpre, gate, wexp_kn, wproj_kn, w_dw, w1, w2t, g_exp, g_dw,
+                  g_proj, row_scale, need, tr, geom, N, H, W, Cin, Ho, Wo, Cmid):
         g = _c(g)
         gb = K.scale_rows(g, row_scale) if ctx.has_rs else g
         # ---- project BN backward, folded into the two GEMMs that consume dy3

@@ -8,6 +8,7 @@ is no fallback: a CPU tensor or a missing library raises.
 
 from __future__ import annotations
 
+import contextlib
 import ctypes
 from dataclasses import dataclass
 
@@ -111,13 +112,43 @@ def scratch(device: torch.device, name: str, nbytes: int) -> torch.Tensor:
     could later be replaced (grown) and freed by code outside the graph while replays still write to it."""
     need = (nbytes + 3) // 4
     if torch.cuda.is_current_stream_capturing():
-        return torch.empty(max(need, 1), dtype=torch.float32, device=device)
+        buf = torch.empty(max(need, 1), dtype=torch.float32, device=device)
+        if _sum_batch["open"]:
+            _sum_batch["keep"].append(buf)                  # the recorded sums read it at sum_batch's exit
+        return buf
+    if _sum_batch["open"]:
+        # every weight gradient of an open batch keeps its own workspace until the batch is summed
+        name = f"{name}#{_sum_batch['count']}"
+        _sum_batch["count"] += 1
     key = (device.index if device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream, name)
     buf = _scratch.get(key)
     if buf is None or buf.numel() < need:
         buf = torch.empty(max(need, 1), dtype=torch.float32, device=device)
         _scratch[key] = buf
     return buf
+
+
+_sum_batch = {"open": False, "count": 0, "keep": []}
+
+
+@contextlib.contextmanager
+def sum_batch():
+    """Weight gradients computed inside the block leave their final partial-row summation to the block's exit, where
+    one pair of launches adds them all (dfd_sum_batch_begin / _end): the returned gradient tensors are valid only after
+    the block.  Nothing inside may read them, and nothing else that sums partial rows may run inside.  No-op when
+    nested or when the side stream is enabled (the sums would be launched on the wrong stream)."""
+    if _sum_batch["open"] or _side_enabled:
+        yield
+        return
+    check(_L().dfd_sum_batch_begin(), "dfd_sum_batch_begin")
+    _sum_batch["open"], _sum_batch["count"] = True, 0
+    try:
+        yield
+    finally:
+        _sum_batch["open"] = False
+        rc = _L().dfd_sum_batch_end()
+        _sum_batch["keep"].clear()
+        check(rc, "dfd_sum_batch_end")
 
 
 def _nbytes(t: torch.Tensor | None) -> int:

@@ -383,6 +383,11 @@ class ConvMlpFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
+        with K.sum_batch():        # the three weight gradients' final sums in one pair of launches at the end
+            return ConvMlpFunction._backward(ctx, g)
+
+    @staticmethod
+    def _backward(ctx, g):
         cfg: ConvMlpCtx = ctx.cfg
         (x, y1, y2, y3, st1, st2, st3, w1_kn, w2_kn, w1, b1, g1, be1, wd, bd, gd, bed, w2, b2, g2, be2, ls,
          row_scale) = ctx.saved_tensors

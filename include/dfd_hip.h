@@ -67,8 +67,18 @@ typedef void* dfd_stream;          /* a hipStream_t */
  * points (convolution bias and LayerScale folded into the BatchNorm coefficients), GELU in every
  * prologue, and the bookkeeping kernels (dfd_rand, dfd_step_tick, dfd_axpby, dfd_add);
  * 111 = dfd_se_fwd / dfd_se_bwd (squeeze-excite in two / three launches); dfd_rowtable_grad takes a workspace;
- * dfd_conv_fwd / dfd_conv_wgrad (implicit-GEMM dense convolution). */
+ * dfd_conv_fwd / dfd_conv_wgrad (implicit-GEMM dense convolution); dfd_sum_batch_begin / _end. */
 int dfd_version(void);
+
+/* Batched final summation of weight gradients.  Every weight-gradient entry point (dfd_pwconv_wgrad,
+ * dfd_dwconv_bwd_weight, dfd_conv_wgrad, dfd_stem_conv_wgrad, ...) ends with a fixed-order sum of its workspace's
+ * partial rows into dw.  Between dfd_sum_batch_begin() and dfd_sum_batch_end() ON THE CALLING HOST THREAD these sums are
+ * recorded instead of launched, and _end() (or the ninth recorded sum) adds them all up with one pair of launches —
+ * same order, same bits.  Contract while a batch is open: each call gets its OWN workspace, which must stay untouched
+ * until _end(); dw is valid only after _end(); all calls use one stream.  The state is thread-local: other threads are
+ * unaffected (the ABI stays re-entrant).  begin inside an open batch / end without one: DFD_EINVAL.                   */
+int dfd_sum_batch_begin(void);
+int dfd_sum_batch_end(void);
 
 /* ---------------------------------------------------------------- BatchNorm ---
  * F.batch_norm inside every conv-bn(-act) triple of the reference's modules

@@ -573,3 +573,27 @@ def test_prep_weights_multi_matches_per_layer(rd):
             assert nk is None
         assert torch.equal(kn, ref_kn)
     assert dw.valid_for([w for w, *_ in items], rd) and not dw.valid_for([w for w, *_ in items][:-1], rd)
+
+
+def test_batched_partial_sums_are_the_unbatched_ones():
+    """kernels.sum_batch(): the final summations of the weight gradients launched inside are recorded and added by one
+    pair of launches at the exit (dfd_sum_batch_begin / _end) — same bits as without; more than eight jobs flush early;
+    a nested batch is a no-op; an unmatched end is refused."""
+    K = _k()
+    rd = torch.bfloat16
+    cases = [(4096, 16, 96), (12544, 192, 1152), (50176, 80, 480), (300, 8, 8), (8192, 24, 144)] * 2     # ten jobs
+    ops = [(dev(gen((1, M, 1, Ni), 10 + i, rd)), dev(gen((1, M, 1, Nj), 30 + i, rd))) for i, (M, Ni, Nj) in enumerate(cases)]
+    dz, y = dev(gen((3, 14, 14, 48), 50, rd)), dev(gen((3, 14, 14, 48), 51, rd))
+    x = dev(gen((3, 14, 14, 48), 52, rd))
+    want = [K.pwconv_wgrad(p, None, q, None) for p, q in ops]
+    want_dw = K.dwconv_bwd_weight(dz, None, None, x, None, R.ACT_NONE, 3, 1, 1, 1)
+    with K.sum_batch():
+        with K.sum_batch():                                   # nested: no-op
+            got = [K.pwconv_wgrad(p, None, q, None) for p, q in ops]
+        got_dw = K.dwconv_bwd_weight(dz, None, None, x, None, R.ACT_NONE, 3, 1, 1, 1)
+    for a, b in zip(want, got):
+        assert torch.equal(a, b)
+    assert torch.equal(want_dw, got_dw)
+    assert K._L().dfd_sum_batch_end() != 0                   # nothing open
+    again = K.pwconv_wgrad(*ops[1][:1], None, ops[1][1], None)
+    assert torch.equal(again, want[1])                       # the unbatched path is untouched afterwards
