@@ -40,12 +40,17 @@ class HipAdamW(torch.optim.Optimizer):
         super().__init__(params, defaults)
         self._tables: dict[int, tuple[tuple[int, ...], torch.Tensor, torch.Tensor]] = {}
         self._hp: dict[int, torch.Tensor] = {}
+        self._shared_step: dict[int, torch.Tensor] = {}
         # gradients of the trainable parameters live at fixed addresses (see arena.py): the
         # pointer table below is then built once and the backward kernels write in place
         self.arena: GradArena | None = None
         trainable = [p for g in self.param_groups for p in g["params"] if p.requires_grad and p.is_cuda]
         if use_arena and trainable:
             self.arena = GradArena(trainable)
+
+    def load_state_dict(self, state_dict) -> None:
+        super().load_state_dict(state_dict)
+        self._shared_step.clear()                  # the loaded per-parameter counters are re-shared at the next step
 
     def zero_grad(self, set_to_none: bool = True) -> None:
         """Drop the gradients (always set-to-none: an arena slot must not be both the
@@ -87,15 +92,23 @@ class HipAdamW(torch.optim.Optimizer):
         captured hipGraph, call prepare_step() before every replay: the kernel reads the
         values from memory, so the replayed launch sees the new learning rate / step."""
         for gi, group in enumerate(self.param_groups):
-            step_no, device = None, None
+            # one step counter per group: every trainable parameter's state["step"] is the SAME CPU tensor, advanced by
+            # one in-place add per optimizer step (per-parameter counters were 2 x len(params) host-side tensor ops per
+            # step).  After load_state_dict the entries are separate tensors again: they are re-shared here.
+            shared, device = self._shared_step.get(gi), None
             for p in group["params"]:
                 if not p.requires_grad:
                     continue
                 st = self._ensure_state(p)
-                st["step"] += 1
-                step_no, device = float(st["step"]), p.device
-            if step_no is None:
+                if shared is None:
+                    shared = self._shared_step[gi] = st["step"] if isinstance(st["step"], torch.Tensor) else torch.tensor(float(st["step"]))
+                if st["step"] is not shared:
+                    st["step"] = shared
+                device = p.device
+            if device is None:
                 continue
+            shared += 1
+            step_no = float(shared)
             b1, b2 = group["betas"]
             hp_vals = [group["lr"], b1, b2, group["eps"], group["weight_decay"], 1.0 - b1 ** step_no,
                        1.0 - b2 ** step_no, group["grad_scale"]]
