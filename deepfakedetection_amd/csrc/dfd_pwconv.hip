@@ -322,6 +322,9 @@ k_pw_nt(const T* __restrict__ a, ProArgs pa, const T* __restrict__ w, T* __restr
 // tile rows are m (the reduction index); bf16: 64 rows x 256 B, f32: 32 rows x (512+64) B
 // ===========================================================================
 #define TN_B 128   // output tile edge (channels of p and of q)
+#ifndef TN_MIN_STEPS
+#define TN_MIN_STEPS 8   // reduction steps a row split must have (fewer splits = fewer partial rows, less parallelism)
+#endif
 
 #define TN_F32_ROW 576  // (128 + 16) floats: kq rows land on disjoint bank halves
 
@@ -790,7 +793,7 @@ static void tn_plan(int dtype, int M, int Ni, int Nj, int* i_tiles, int* j_tiles
     long cap = (64l << 20) / per;
     if (cap < 1) cap = 1;
     if (s > cap) s = (int)cap;
-    int max_s = (M + bmk * 8 - 1) / (bmk * 8);
+    int max_s = (M + bmk * TN_MIN_STEPS - 1) / (bmk * TN_MIN_STEPS);
     if (max_s < 1) max_s = 1;
     if (s > max_s) s = max_s;
     int rps = (M + s - 1) / s;
