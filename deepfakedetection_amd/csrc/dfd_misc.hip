@@ -452,10 +452,18 @@ k_stem_fwd(const float* __restrict__ x, const float* __restrict__ w, T* __restri
                     for (int ci = 0; ci < 3; ++ci) {
                         const float xv = round_to<T>(xr[kw * 3 + ci]);
                         const f2v xx = (f2v){xv, xv};
+                        // the lane's V weights as 16-byte LDS reads (float2 pairs become ds_read2_b64: twice the LDS
+                        // cycles and a bank conflict at this 32-byte lane stride, see dfd_dwq.h)
                         const float* wp = wl + ((ci * K + kh) * K + kw) * Co + c0;
+                        f2v wv[V / 2];
 #pragma unroll
-                        for (int j = 0; j < V / 2; ++j)
-                            acc2[j] = __builtin_elementwise_fma(xx, *reinterpret_cast<const f2v*>(wp + 2 * j), acc2[j]);
+                        for (int j4 = 0; j4 < V / 4; ++j4) {
+                            const float4 q = *reinterpret_cast<const float4*>(wp + 4 * j4);
+                            wv[2 * j4] = (f2v){q.x, q.y};
+                            wv[2 * j4 + 1] = (f2v){q.z, q.w};
+                        }
+#pragma unroll
+                        for (int j = 0; j < V / 2; ++j) acc2[j] = __builtin_elementwise_fma(xx, wv[j], acc2[j]);
                     }
             }
             float acc[V];
