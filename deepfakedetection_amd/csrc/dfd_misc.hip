@@ -525,6 +525,16 @@ k_stem_wgrad(const float* __restrict__ x, const T* __restrict__ dz, const T* __r
     for (int i = t; i < STEM_CHUNK * STEM_TAPP; i += DFD_THREADS) sx[i] = 0.f;      // pad taps stay zero
     const long npix = (long)s.N * s.Ho * s.Wo;
     const int CV = Co / V;
+    // a lane's channel vector is the same for every item it stages (256 % CV == 0): its BN-backward coefficients are
+    // loaded once, not three dependent global loads per item inside the staging loop
+    const bool fixed_v = coef != nullptr && DFD_THREADS % CV == 0;
+    float ka0[V], kb0[V], kc0[V];
+    if (fixed_v) {
+        const int v = t % CV;
+        load_f32<V>(coef + v * V, ka0);
+        load_f32<V>(coef + Co + v * V, kb0);
+        load_f32<V>(coef + 2 * Co + v * V, kc0);
+    }
     for (long base = (long)blockIdx.x * STEM_CHUNK; base < npix; base += (long)gridDim.x * STEM_CHUNK) {
         const int ox_b = (int)(base % s.Wo);
         const long tq_b = base / s.Wo;
@@ -542,9 +552,14 @@ k_stem_wgrad(const float* __restrict__ x, const T* __restrict__ dz, const T* __r
                 if (coef) {
                     float yv[V], ka[V], kb[V], kc[V];
                     Vec<T>::load(yraw + pix * Co + v * V, yv);
-                    load_f32<V>(coef + v * V, ka);
-                    load_f32<V>(coef + Co + v * V, kb);
-                    load_f32<V>(coef + 2 * Co + v * V, kc);
+                    if (fixed_v) {
+#pragma unroll
+                        for (int j = 0; j < V; ++j) { ka[j] = ka0[j]; kb[j] = kb0[j]; kc[j] = kc0[j]; }
+                    } else {
+                        load_f32<V>(coef + v * V, ka);
+                        load_f32<V>(coef + Co + v * V, kb);
+                        load_f32<V>(coef + 2 * Co + v * V, kc);
+                    }
 #pragma unroll
                     for (int j = 0; j < V; ++j) d[j] = round_to<T>(fmaf(ka[j], d[j], fmaf(kb[j], yv[j], kc[j])));
                 }
