@@ -20,7 +20,7 @@ FAM = collections.OrderedDict([
     ("pwconv", ("k_pw_ntw", "k_pw_nt<")), ("pwconv_wgrad", ("k_pw_tnw", "k_pw_tn<")),
     ("dwconv_bwd_data", ("k_dw_bwd_data_q",)), ("dwconv_bwd_weight", ("k_dw_bwd_weight_q",)), ("dwconv_fwd", ("k_dw_fwd_q",)),
     ("act_bn_bwd", ("k_act_bn_bwd",)), ("pool", ("k_pool",)), ("bn_finalize", ("k_bn_finalize", "k_bn_bwd_finalize")),
-    ("sum_partials", ("k_sum_partials",)), ("bn_bwd_reduce", ("k_bn_bwd_reduce",)), ("bn_act_apply", ("k_bn_act_apply",)),
+    ("sum_partials", ("k_sum_partials", "k_sum_multi")), ("bn_bwd_reduce", ("k_bn_bwd_reduce",)), ("bn_act_apply", ("k_bn_act_apply",)),
     ("stem", ("k_stem",)), ("se_mlp", ("k_se_", "k_transpose")), ("prep_weights", ("k_prep_weights",)), ("adamw", ("k_adamw",))])
 
 
