@@ -84,6 +84,7 @@ SIGNATURES: dict[str, tuple] = {
     "dfd_softmax_argmax": (c_int, [P, c_int, c_int, P, P, P]),
     "dfd_adamw_step": (c_int, [P, c_int, P, P]),
     # ---- ABI 111
+    "dfd_bn_eval_coeffs_multi": (c_int, [P, c_int, P]),
     "dfd_sum_batch_begin": (c_int, []),
     "dfd_sum_batch_end": (c_int, []),
     "dfd_se_fwd": (c_int, [c_int, P, P, c_int, c_int, c_int, c_int, P, P, P, P, c_int, c_int, P, P, P, P, P, c_size_t, P]),
@@ -129,6 +130,12 @@ SIGNATURES: dict[str, tuple] = {
     "dfd_rand": (c_int, [P, c_uint32, c_float, P, c_long, P]),
     "dfd_step_tick": (c_int, [P, c_int, P, P]),
 }
+
+class BnEvalJob(Structure):
+    """dfd_bn_eval_job"""
+    _fields_ = [("gamma", c_void_p), ("beta", c_void_p), ("conv_bias", c_void_p), ("ls", c_void_p), ("running_mean", c_void_p),
+                ("running_var", c_void_p), ("bnstate", c_void_p), ("eps", c_float), ("C", c_int)]
+
 
 class PrepJob(Structure):
     """struct dfd_prep_job (include/dfd_hip.h)."""

@@ -625,6 +625,36 @@ extern "C" int dfd_bn_eval_coeffs_ex(const float* gamma, const float* beta, cons
                        running_mean, running_var, eps, C, bnstate);
     return DFD_CHECK_LAUNCH();
 }
+// every BatchNorm of a network in eval mode in one (or two) launches: jobs travel as kernel arguments
+#define BN_EVAL_JOBS_PER_LAUNCH 40
+struct BnEvalJobs { dfd_bn_eval_job j[BN_EVAL_JOBS_PER_LAUNCH]; };
+__global__ void k_bn_eval_coeffs_multi(BnEvalJobs J) {
+    const dfd_bn_eval_job& b = J.j[blockIdx.y];
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= b.C) return;
+    const float rstd = 1.0f / sqrtf(b.running_var[c] + b.eps);
+    const float g = b.gamma ? b.gamma[c] : 1.f, be = b.beta ? b.beta[c] : 0.f;
+    const float m = b.running_mean[c] - (b.conv_bias ? b.conv_bias[c] : 0.f);
+    const float l = b.ls ? b.ls[c] : 1.f;
+    const float scale = g * rstd;
+    b.bnstate[c] = l * scale;
+    b.bnstate[b.C + c] = l * (be - m * scale);
+    b.bnstate[2 * b.C + c] = m;
+    b.bnstate[3 * b.C + c] = rstd;
+}
+extern "C" int dfd_bn_eval_coeffs_multi(const dfd_bn_eval_job* jobs, int njobs, dfd_stream stream) {
+    if (!jobs || njobs < 1) return DFD_EINVAL;
+    for (int i = 0; i < njobs; ++i)
+        if (!jobs[i].running_mean || !jobs[i].running_var || !jobs[i].bnstate || jobs[i].C < 1) return DFD_EINVAL;
+    for (int base = 0; base < njobs; base += BN_EVAL_JOBS_PER_LAUNCH) {
+        BnEvalJobs J;
+        const int cnt = njobs - base < BN_EVAL_JOBS_PER_LAUNCH ? njobs - base : BN_EVAL_JOBS_PER_LAUNCH;
+        int maxC = 0;
+        for (int i = 0; i < cnt; ++i) { J.j[i] = jobs[base + i]; if (J.j[i].C > maxC) maxC = J.j[i].C; }
+        hipLaunchKernelGGL(k_bn_eval_coeffs_multi, dim3((maxC + 255) / 256, cnt), dim3(256), 0, (hipStream_t)stream, J);
+    }
+    return DFD_CHECK_LAUNCH();
+}
 extern "C" int dfd_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean,
                                   const float* running_var, float eps, int C, float* bnstate, dfd_stream stream) {
     return dfd_bn_eval_coeffs_ex(gamma, beta, nullptr, nullptr, running_mean, running_var, eps, C, bnstate, stream);

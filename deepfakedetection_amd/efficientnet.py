@@ -57,7 +57,11 @@ _TIMM_DS_NAMES = dict(dw="conv_dw", dw_bn="bn1", se_reduce="se.conv_reduce", se_
 
 
 def _bnref(bn: nn.BatchNorm2d) -> BNRef:
-    return BNRef(bn.running_mean, bn.running_var, bn.num_batches_tracked, bn.momentum, bn.eps)
+    pre = None
+    held = bn.__dict__.get("_dfd_eval")               # (kernels.EvalBNStates, this layer's block), set by the owning network
+    if held is not None and held[0].fresh and not bn.training:
+        pre = held[1]
+    return BNRef(bn.running_mean, bn.running_var, bn.num_batches_tracked, bn.momentum, bn.eps, pre)
 
 
 def compute_dtype(device_type: str = "cuda") -> torch.dtype:
@@ -279,9 +283,33 @@ class HipEfficientNet(nn.Module):
         out.append(cache.out[at])
         return out
 
+    def _eval_bn_states(self):
+        """Eval / inference forward: every BatchNorm's coefficient block from one batched launch (kernels.EvalBNStates)."""
+        from . import kernels as K
+
+        bns = [m for m in self.modules() if isinstance(m, nn.BatchNorm2d)]
+        cache = self.__dict__.get("_eval_bn_cache")
+        if cache is None or not cache.valid_for(bns):
+            with torch.inference_mode(False):
+                cache = self.__dict__["_eval_bn_cache"] = K.EvalBNStates(bns)
+            for bn, st in zip(bns, cache.states):
+                bn.__dict__["_dfd_eval"] = (cache, st)
+        cache.refresh()
+        return cache
+
     def forward(self, x: torch.Tensor, drop_masks=None, dropout_u: torch.Tensor | None = None) -> torch.Tensor:
         """drop_masks / dropout_u let a test inject the stochastic-depth masks (already
         1/keep scaled, one [N] tensor or None per block) and the dropout uniforms."""
+        if not self.training and x.is_cuda:
+            states = self._eval_bn_states()
+            states.fresh = True
+            try:
+                return self._forward(x, drop_masks, dropout_u)
+            finally:
+                states.fresh = False
+        return self._forward(x, drop_masks, dropout_u)
+
+    def _forward(self, x: torch.Tensor, drop_masks=None, dropout_u: torch.Tensor | None = None) -> torch.Tensor:
         _, _, _, head, head_bn, fc = self._parts()
         counters: list = []                 # owned by this call: num_batches_tracked of every BatchNorm that ran
         h = self.forward_features_nhwc(x, drop_masks, counters)

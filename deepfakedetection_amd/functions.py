@@ -35,6 +35,7 @@ class BNRef:
     num_batches_tracked: torch.Tensor | None
     momentum: float
     eps: float
+    pre: torch.Tensor | None = None       # eval mode: this layer's coefficient block, already computed (kernels.EvalBNStates)
 
     def params(self, weight: torch.Tensor, bias: torch.Tensor) -> K.BNParams:
         return K.BNParams(weight, bias, self.running_mean, self.running_var, self.momentum, self.eps)
@@ -54,6 +55,8 @@ def _bn_state(parts, nparts, count: int, bn: BNRef, weight, bias, training: bool
             else:
                 bn.num_batches_tracked.add_(1)
         return K.bn_finalize(parts, nparts, count, params)
+    if bn.pre is not None and conv_bias is None and ls is None:
+        return bn.pre
     return K.bn_eval_coeffs(params)
 
 

@@ -508,6 +508,38 @@ class DerivedWeights:
         check(_L().dfd_prep_weights_multi(self._jobs, len(self._jobs), _stream()), "dfd_prep_weights_multi")
 
 
+class EvalBNStates:
+    """The eval-mode coefficient blocks [4][C] of every BatchNorm of a network, refreshed by one batched launch per
+    forward pass (dfd_bn_eval_coeffs_multi) instead of one small kernel per layer.  `fresh` is raised by the owning
+    network for the duration of its own forward pass: a layer run on its own never sees a stale block."""
+
+    def __init__(self, bns: list) -> None:
+        from ._lib import BnEvalJob
+
+        self.ptrs = [(bn.weight.data_ptr(), bn.bias.data_ptr(), bn.running_mean.data_ptr(), bn.running_var.data_ptr()) for bn in bns]
+        dev = bns[0].running_mean.device
+        total = sum(4 * bn.running_mean.numel() for bn in bns)
+        self.flat = torch.empty(total, dtype=torch.float32, device=dev)
+        self.states, jobs, at = [], (BnEvalJob * len(bns))(), 0
+        for i, bn in enumerate(bns):
+            C = bn.running_mean.numel()
+            st = self.flat[at:at + 4 * C].view(4, C)
+            at += 4 * C
+            self.states.append(st)
+            jobs[i] = BnEvalJob(bn.weight.data_ptr(), bn.bias.data_ptr(), None, None, bn.running_mean.data_ptr(),
+                                bn.running_var.data_ptr(), st.data_ptr(), float(bn.eps), C)
+        self._jobs = jobs
+        self.fresh = False
+
+    def valid_for(self, bns: list) -> bool:
+        return len(bns) == len(self.ptrs) and all(
+            (bn.weight.data_ptr(), bn.bias.data_ptr(), bn.running_mean.data_ptr(), bn.running_var.data_ptr()) == p
+            for bn, p in zip(bns, self.ptrs))
+
+    def refresh(self) -> None:
+        check(_L().dfd_bn_eval_coeffs_multi(self._jobs, len(self._jobs), _stream()), "dfd_bn_eval_coeffs_multi")
+
+
 def pwconv(a: torch.Tensor, pro: Prologue | None, w_nk: torch.Tensor, residual: torch.Tensor | None = None,
            stats: bool = False):
     """out[..., Nout] = P(a)[..., K] @ w_nk[Nout, K]^T (+ residual). Returns (out, partials, nparts)."""

@@ -67,7 +67,8 @@ typedef void* dfd_stream;          /* a hipStream_t */
  * points (convolution bias and LayerScale folded into the BatchNorm coefficients), GELU in every
  * prologue, and the bookkeeping kernels (dfd_rand, dfd_step_tick, dfd_axpby, dfd_add);
  * 111 = dfd_se_fwd / dfd_se_bwd (squeeze-excite in two / three launches); dfd_rowtable_grad takes a workspace;
- * dfd_conv_fwd / dfd_conv_wgrad (implicit-GEMM dense convolution); dfd_sum_batch_begin / _end. */
+ * dfd_conv_fwd / dfd_conv_wgrad (implicit-GEMM dense convolution); dfd_sum_batch_begin / _end;
+ * dfd_bn_eval_coeffs_multi. */
 int dfd_version(void);
 
 /* Batched final summation of weight gradients.  Every weight-gradient entry point (dfd_pwconv_wgrad,
@@ -93,6 +94,15 @@ int dfd_bn_finalize(const float* partials, int nparts, int C, double count,
 int dfd_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean,
                        const float* running_var, float eps, int C, float* bnstate,
                        dfd_stream stream);
+/* The same for every BatchNorm of a network at once (eval / inference forward: 49 launches of EfficientNet-B0 become 2).
+ * jobs: host array, copied into kernel arguments; all pointers are device pointers, bnstate float[4][C] each.        */
+typedef struct {
+    const float *gamma, *beta, *conv_bias, *ls, *running_mean, *running_var;   /* gamma .. ls may be NULL */
+    float* bnstate;
+    float eps;
+    int C;
+} dfd_bn_eval_job;
+int dfd_bn_eval_coeffs_multi(const dfd_bn_eval_job* jobs, int njobs, dfd_stream stream);
 /* backward: partial (sum g, sum g*xhat) slabs -> dgamma, dbeta, coef.  train==0:
  * statistics were constants (eval-mode BN), so dy = gamma*rstd*g.               */
 int dfd_bn_bwd_finalize(const float* partials, int nparts, int C, double count,

@@ -308,3 +308,29 @@ def test_grad_cam_hooks_on_head_conv(variant, flavour, attr):
     assert rel_err(kept["hip_grad"], kept["ref_grad"]) <= 2e-3
     # without hooks the fused path is back
     assert rel_err(hip(x.cuda()), ref_logits) <= 1e-3
+
+
+@pytest.mark.gpu
+def test_eval_batchnorm_coefficients_from_one_batched_launch_track_the_buffers():
+    """Eval forward: all 49 BatchNorm coefficient blocks come from one batched launch (kernels.EvalBNStates); the result
+    is the per-layer path's, also after running statistics and affine parameters changed in place (no stale cache),
+    and a block run on its own never uses the network's precomputed blocks."""
+    HipEfficientNet, _, _ = _hip()
+    torch.manual_seed(5)
+    m = HipEfficientNet("b0", "timm", 2).cuda().eval()
+    x = torch.randn(4, 3, 96, 96, device="cuda")
+    with torch.inference_mode():
+        a, b = m(x), m._forward(x)                        # batched coefficients vs one kernel per layer
+        assert torch.equal(a, b)
+    with torch.no_grad():
+        for bn in [mod for mod in m.modules() if isinstance(mod, torch.nn.BatchNorm2d)][::5]:
+            bn.running_mean.add_(0.3)
+            bn.running_var.mul_(1.7)
+            bn.weight.mul_(0.9)
+    with torch.inference_mode():
+        c, d = m(x), m._forward(x)
+        assert torch.equal(c, d) and not torch.equal(a, c)
+        assert m.__dict__["_eval_bn_cache"].fresh is False
+        blk = m.block_list()[3]
+        h = torch.randn(2, 12, 12, blk.plan.cin, device="cuda")
+        assert torch.isfinite(blk(h)).all()               # standalone: per-layer path
