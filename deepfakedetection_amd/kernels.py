@@ -10,6 +10,7 @@ from __future__ import annotations
 
 import contextlib
 import ctypes
+import threading
 from dataclasses import dataclass
 
 import os
@@ -113,13 +114,13 @@ def scratch(device: torch.device, name: str, nbytes: int) -> torch.Tensor:
     need = (nbytes + 3) // 4
     if torch.cuda.is_current_stream_capturing():
         buf = torch.empty(max(need, 1), dtype=torch.float32, device=device)
-        if _sum_batch["open"]:
-            _sum_batch["keep"].append(buf)                  # the recorded sums read it at sum_batch's exit
+        if _sum_batch.open:
+            _sum_batch.keep.append(buf)                     # the recorded sums read it at sum_batch's exit
         return buf
-    if _sum_batch["open"]:
+    if _sum_batch.open:
         # every weight gradient of an open batch keeps its own workspace until the batch is summed
-        name = f"{name}#{_sum_batch['count']}"
-        _sum_batch["count"] += 1
+        name = f"{name}#{_sum_batch.count}"
+        _sum_batch.count += 1
     key = (device.index if device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream, name)
     buf = _scratch.get(key)
     if buf is None or buf.numel() < need:
@@ -128,7 +129,14 @@ def scratch(device: torch.device, name: str, nbytes: int) -> torch.Tensor:
     return buf
 
 
-_sum_batch = {"open": False, "count": 0, "keep": []}
+class _SumBatchState(threading.local):
+    """Per host thread, like the library's own batch state (dfd_sum_batch_begin is thread-local)."""
+
+    def __init__(self) -> None:
+        self.open, self.count, self.keep = False, 0, []
+
+
+_sum_batch = _SumBatchState()
 
 
 @contextlib.contextmanager
@@ -137,17 +145,17 @@ def sum_batch():
     one pair of launches adds them all (dfd_sum_batch_begin / _end): the returned gradient tensors are valid only after
     the block.  Nothing inside may read them, and nothing else that sums partial rows may run inside.  No-op when
     nested or when the side stream is enabled (the sums would be launched on the wrong stream)."""
-    if _sum_batch["open"] or _side_enabled:
+    if _sum_batch.open or _side_enabled:
         yield
         return
     check(_L().dfd_sum_batch_begin(), "dfd_sum_batch_begin")
-    _sum_batch["open"], _sum_batch["count"] = True, 0
+    _sum_batch.open, _sum_batch.count = True, 0
     try:
         yield
     finally:
-        _sum_batch["open"] = False
+        _sum_batch.open = False
         rc = _L().dfd_sum_batch_end()
-        _sum_batch["keep"].clear()
+        _sum_batch.keep.clear()
         check(rc, "dfd_sum_batch_end")
 
 
