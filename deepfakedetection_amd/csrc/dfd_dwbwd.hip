@@ -204,7 +204,17 @@ k_dw_bwd_data_q(const T* __restrict__ dz, const T* __restrict__ yraw, const floa
 #pragma unroll
                         for (int j = 0; j < N2; ++j) {
                             const f2 z = __builtin_elementwise_fma(scv[j], xv[j], shv[j]);
-                            const f2 gr = (f2){act_grad<ACT>(z.x), act_grad<ACT>(z.y)};
+                            f2 gr;
+                            if constexpr (ACT == DFD_ACT_SILU) {
+                                // act_grad<SILU> on the pair: only exp and rcp are per element, the rest is packed math
+                                // (same operations in the same order as the scalar form: identical bits)
+                                const f2 e = (f2){__expf(-z.x), __expf(-z.y)};
+                                const f2 d1 = e + (f2){1.f, 1.f};
+                                const f2 sg = (f2){__builtin_amdgcn_rcpf(d1.x), __builtin_amdgcn_rcpf(d1.y)};
+                                gr = sg * ((f2){1.f, 1.f} + z * ((f2){1.f, 1.f} - sg));
+                            } else {
+                                gr = (f2){act_grad<ACT>(z.x), act_grad<ACT>(z.y)};
+                            }
                             const f2 d = round2<T>(acc[o][j] * gr);
                             acc[o][j] = d;
                             s1[j] += d;
