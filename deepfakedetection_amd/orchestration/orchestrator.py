@@ -288,9 +288,10 @@ def build_inference_loader(*, dataset, batch_size: int, num_workers: int) -> Dat
                       persistent_workers=num_workers > 0, **extra)
 
 
-def class_probabilities(model: nn.Module, images: torch.Tensor, device: torch.device):
-    """logits -> (softmax probabilities, arg-max) for one batch (orchestrator.py:589-592)."""
-    with torch.inference_mode():
+def class_probabilities(model: nn.Module, images: torch.Tensor, device: torch.device, amp: bool = False):
+    """logits -> (softmax probabilities, arg-max) for one batch (orchestrator.py:589-592).  amp: run the forward in a
+    bf16 autocast region (opt-in `inference.amp: bf16`; the reference's inference is f32, which stays the default)."""
+    with torch.inference_mode(), torch.autocast(device_type=device.type, dtype=torch.bfloat16, enabled=amp and device.type == "cuda"):
         logits = model(images.to(device, non_blocking=True))
         if logits.is_cuda:
             from .. import kernels  # HIP softmax/argmax epilogue
@@ -398,6 +399,7 @@ def _run_inference_job(*, config_path: Path, config: dict[str, Any], model_cfg: 
     infer_cfg = model_cfg.get("inference") or {}        # reference uses .get("inference", {}) and breaks on None
     split = infer_cfg.get("split") or data_cfg.get("test_split", "test")
     batch_size = int(infer_cfg.get("batch_size", 64))
+    amp = str(infer_cfg.get("amp", "")).lower() in ("bf16", "bfloat16", "true", "1")       # extra key, default: f32 as the reference
     out.print(f"[bold]Model[/]: {name} | split={split} | batch={batch_size}")
     num_classes = int(model_cfg.get("num_classes", data_cfg.get("num_classes", 2)))
     image_size = int(_first_set(infer_cfg.get("img_size"), data_cfg.get("img_size"), spec.default_image_size))
@@ -423,7 +425,7 @@ def _run_inference_job(*, config_path: Path, config: dict[str, Any], model_cfg: 
             if len(val_set) > 0:
                 scores, truth = [], []
                 for images, targets in build_inference_loader(dataset=val_set, batch_size=batch_size, num_workers=num_workers):
-                    probs, _ = class_probabilities(model, images, device)
+                    probs, _ = class_probabilities(model, images, device, amp)
                     scores.append(probs[:, 1].cpu())
                     truth.append(targets.cpu())
                 s, t = torch.cat(scores).numpy(), torch.cat(truth).numpy()
@@ -447,7 +449,7 @@ def _run_inference_job(*, config_path: Path, config: dict[str, Any], model_cfg: 
     with progress:
         task = progress.add_task("inference", total=len(loader), speed="")
         for images, targets in loader:
-            probs, preds = class_probabilities(model, images, device)
+            probs, preds = class_probabilities(model, images, device, amp)
             all_probs.append(probs.cpu())
             all_preds.append(preds.cpu())
             all_targets.append(targets.cpu())

@@ -64,6 +64,13 @@ def test_orchestrated_training_and_inference_on_gpu(tmp_path, monkeypatch, model
     run2 = sorted(Path(out_dir).iterdir())[-1]
     row = json.loads((run2 / "logs" / "metrics.jsonl").read_text().splitlines()[0])
     assert row["model"] == model_name and 0.0 <= row["accuracy"] <= 1.0 and "threshold" in row
+    # opt-in bf16 inference (`inference.amp: bf16`, an extra key of this engine): same plumbing
+    infer_cfg["models"][model_name]["inference"]["amp"] = "bf16"
+    path2.write_text(yaml.safe_dump(infer_cfg))
+    orchestrate(path2, mode="inference")
+    run3 = sorted(Path(out_dir).iterdir())[-1]
+    row3 = json.loads((run3 / "logs" / "metrics.jsonl").read_text().splitlines()[-1])
+    assert row3["model"] == model_name and 0.0 <= row3["accuracy"] <= 1.0
     assert sum(map(sum, row["confusion_matrix"])) == 16
 
 
