@@ -22,7 +22,7 @@ import torch
 from torch import nn
 
 from .efficientnet import compute_dtype
-from .functions import BNRef
+from .functions import BNRef, bn_eval_batch
 from .vit_functions import (AttentionCtx, AttentionFunction, AttnGeom, ConvMlpCtx, ConvMlpFunction, ConvStemCtx, ConvStemFunction,
                             DenseConvBNFunction, DenseConvCtx, DownsampleCtx, DownsampleFunction, TailCtx, TailFunction)
 from ._lib import ACT_GELU
@@ -306,6 +306,10 @@ class HipEfficientFormerV2(nn.Module):
         return {w.data_ptr(): pair for w, pair in zip(weights, cache.out)}
 
     def forward(self, x: torch.Tensor, dropout_u: torch.Tensor | None = None) -> torch.Tensor:
+        with bn_eval_batch(self.__dict__, (self.training, compute_dtype())):     # eval-mode BN blocks: one batched launch per pass
+            return self._forward(x, dropout_u)
+
+    def _forward(self, x: torch.Tensor, dropout_u: torch.Tensor | None = None) -> torch.Tensor:
         counters: list = []
         h = self.forward_features_nhwc(x, counters)
         u = dropout_u

@@ -21,7 +21,7 @@ from ._lib import ACT_RELU
 from .efficientnet import compute_dtype
 from .fastervit_functions import (AttnSpec, ConvBlockCtx, ConvBlockFunction, FVDownsampleFunction, HATCtx, HATFunction,
                                   TokenInitFunction)
-from .functions import BNRef
+from .functions import BNRef, bn_eval_batch
 from .vit_functions import ConvStemCtx, ConvStemFunction, DenseConvBNFunction, DenseConvCtx, TailCtx, TailFunction
 
 _CONFIGS = {
@@ -348,6 +348,12 @@ class HipFasterViT(nn.Module):
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         if not x.is_cuda:
             raise RuntimeError("HipFasterViT runs on a HIP device only (no CPU fallback); move the input with .to('cuda')")
+        # the coefficient blocks of every eval-mode BatchNorm and of every Linear's identity statistics (bias, LayerScale):
+        # one batched launch per pass instead of ~70 small ones
+        with bn_eval_batch(self.__dict__, (self.training, compute_dtype())):
+            return self._forward(x)
+
+    def _forward(self, x: torch.Tensor) -> torch.Tensor:
         if x.shape[2] != self.resolution or x.shape[3] != self.resolution:
             raise ValueError(f"FasterViT was built for {self.resolution}x{self.resolution} inputs, got {tuple(x.shape[2:])}")
         dt = compute_dtype()

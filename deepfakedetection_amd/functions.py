@@ -16,6 +16,8 @@ trainers/efficientnet.py:297,302; orchestration/orchestrator.py:529,590).
 
 from __future__ import annotations
 
+import contextlib
+import threading
 from dataclasses import dataclass
 
 import torch
@@ -57,7 +59,31 @@ def _bn_state(parts, nparts, count: int, bn: BNRef, weight, bias, training: bool
         return K.bn_finalize(parts, nparts, count, params)
     if bn.pre is not None and conv_bias is None and ls is None:
         return bn.pre
+    batch = getattr(_bn_batch_tls, "batch", None)
+    if batch is not None:
+        return batch.request(params)
     return K.bn_eval_coeffs(params)
+
+
+_bn_batch_tls = threading.local()
+
+
+@contextlib.contextmanager
+def bn_eval_batch(owner: dict, tag):
+    """Inside the block, eval-mode BatchNorm coefficient blocks come from `owner`'s kernels.BNEvalBatch for `tag` (one per
+    network and mode): recorded on the first pass, one batched launch from the second pass on."""
+    batches = owner.setdefault("_bn_eval_batches", {})
+    batch = batches.get(tag)
+    if batch is None:
+        batch = batches[tag] = K.BNEvalBatch()
+    prev = getattr(_bn_batch_tls, "batch", None)
+    _bn_batch_tls.batch = batch
+    batch.begin()
+    try:
+        yield batch
+    finally:
+        _bn_batch_tls.batch = prev
+        batch.end()
 
 
 def _c(t: torch.Tensor) -> torch.Tensor:

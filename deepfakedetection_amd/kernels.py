@@ -516,6 +516,69 @@ class DerivedWeights:
         check(_L().dfd_prep_weights_multi(self._jobs, len(self._jobs), _stream()), "dfd_prep_weights_multi")
 
 
+class BNEvalBatch:
+    """The eval-mode BatchNorm coefficient requests of one forward pass of a network (kernels.bn_eval_coeffs: real
+    BatchNorms in eval mode, and the identity statistics that carry a Linear layer's bias / LayerScale), recorded in call
+    order on the first pass and from then on computed by ONE batched launch at the start of the pass and handed out in
+    the same order.  Every hand-out is checked against the recorded pointers; any mismatch falls back to the per-layer
+    kernel and re-records.  Use through functions.bn_eval_batch()."""
+
+    def __init__(self) -> None:
+        self.keys: list[tuple] | None = None
+        self.states: list[torch.Tensor] = []
+        self._jobs = None
+        self._flat = None
+        self._rec: list[tuple[tuple, BNParams]] = []
+        self.pos = 0
+        self.ok = True
+
+    @staticmethod
+    def _key(p: "BNParams") -> tuple:
+        return (_p(p.weight), _p(p.bias), _p(p.conv_bias), _p(p.ls), _p(p.running_mean), _p(p.running_var), float(p.eps),
+                int(p.running_mean.numel()))
+
+    def begin(self) -> None:
+        self.pos, self.ok, self._rec = 0, True, []
+        if self.keys is not None:
+            check(_L().dfd_bn_eval_coeffs_multi(self._jobs, len(self._jobs), _stream()), "dfd_bn_eval_coeffs_multi")
+
+    def request(self, p: "BNParams") -> torch.Tensor:
+        key = self._key(p)
+        if self.keys is None:
+            self._rec.append((key, p))
+            return bn_eval_coeffs(p)
+        if self.ok and self.pos < len(self.keys) and self.keys[self.pos] == key:
+            st = self.states[self.pos]
+            self.pos += 1
+            return st
+        self.ok = False
+        return bn_eval_coeffs(p)
+
+    def end(self) -> None:
+        if self.keys is None:
+            if self._rec:
+                self._build()
+        elif not self.ok or self.pos != len(self.keys):
+            self.keys, self.states, self._jobs, self._flat = None, [], None, None      # the pass changed: record again
+        self._rec = []
+
+    def _build(self) -> None:
+        from ._lib import BnEvalJob
+
+        recs = self._rec
+        dev = recs[0][1].running_mean.device
+        with torch.inference_mode(False):
+            self._flat = torch.empty(sum(4 * k[-1] for k, _ in recs), dtype=torch.float32, device=dev)
+        jobs, at, self.states = (BnEvalJob * len(recs))(), 0, []
+        for i, (key, _) in enumerate(recs):
+            C = key[-1]
+            st = self._flat[at:at + 4 * C].view(4, C)
+            at += 4 * C
+            self.states.append(st)
+            jobs[i] = BnEvalJob(key[0], key[1], key[2], key[3], key[4], key[5], st.data_ptr(), key[6], C)
+        self._jobs, self.keys = jobs, [k for k, _ in recs]
+
+
 class EvalBNStates:
     """The eval-mode coefficient blocks [4][C] of every BatchNorm of a network, refreshed by one batched launch per
     forward pass (dfd_bn_eval_coeffs_multi) instead of one small kernel per layer.  `fresh` is raised by the owning

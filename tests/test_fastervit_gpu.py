@@ -240,3 +240,35 @@ def test_refuses_cpu():
     Hip, _, _, _ = _imports()
     with pytest.raises(RuntimeError, match="HIP device"):
         Hip("0", 2)(torch.zeros(1, 3, 224, 224))
+
+
+@pytest.mark.gpu
+def test_batched_eval_coefficients_replay_equals_per_layer_path():
+    """functions.bn_eval_batch: the first pass records the eval-mode coefficient requests (per-layer kernels), later
+    passes compute them with one batched launch; results are those of the per-layer path, also after biases, LayerScale-free
+    Linear parameters and running statistics changed in place, in eval and in training mode."""
+    _, hip = make_pair("0", 2, seed=3)
+    x = torch.randn(2, 3, 224, 224, generator=torch.Generator().manual_seed(4)).cuda()
+    hip.eval()
+    with torch.inference_mode():
+        first, replay, plain = hip(x), hip(x), hip._forward(x)
+        assert torch.equal(first, replay) and torch.equal(first, plain)
+        batch = hip.__dict__["_bn_eval_batches"][(False, torch.float32)]
+        assert batch.keys is not None and len(batch.keys) > 40
+    with torch.no_grad():
+        for name, p in hip.named_parameters():
+            if name.endswith("bias"):
+                p.add_(0.05)
+        for name, b in hip.named_buffers():
+            if name.endswith("running_var"):
+                b.mul_(1.3)
+    with torch.inference_mode():
+        again, plain2 = hip(x), hip._forward(x)
+        assert torch.equal(again, plain2) and not torch.equal(again, first)
+    hip.train()
+    torch.manual_seed(0)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        a = hip(x)                          # records the training pass's requests (the Linear layers' identity statistics)
+        b = hip(x)                          # replays them
+    assert torch.isfinite(a).all() and torch.isfinite(b).all()
+    assert (True, torch.bfloat16) in hip.__dict__["_bn_eval_batches"]
