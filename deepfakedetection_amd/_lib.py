@@ -90,6 +90,11 @@ SIGNATURES: dict[str, tuple] = {
     "dfd_se_fwd": (c_int, [c_int, P, P, c_int, c_int, c_int, c_int, P, P, P, P, c_int, c_int, P, P, P, P, P, c_size_t, P]),
     "dfd_se_bwd": (c_int, [c_int, P, P, P, c_int, c_int, c_int, c_int, P, P, P, P, P, c_int, c_int, P, P, P, P, P, P, c_int,
                            P, c_size_t, P, P]),
+    # ---- ABI 112 (eval form of the MBConv block)
+    "dfd_pwconv_fwd_eval": (c_int, [c_int, P, P, P, c_int, P, c_int, c_int, c_int, P]),
+    "dfd_dwconv_fwd_eval_tiles": (c_int, [c_int, P]),
+    "dfd_dwconv_fwd_eval": (c_int, [c_int, P, P, P, c_int, P, P, P, P, P]),
+    "dfd_se_fwd_parts": (c_int, [P, c_int, c_int, c_int, c_int, P, P, P, P, c_int, c_int, P, P, P, P, P]),
     # ---- ABI 110
     "dfd_bn_finalize_ex": (c_int, [P, c_int, c_int, c_double, P, P, P, P, P, P, c_float, c_float, P, P]),
     "dfd_bn_eval_coeffs_ex": (c_int, [P, P, P, P, P, P, c_float, c_int, P, P]),

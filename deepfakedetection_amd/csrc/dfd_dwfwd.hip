@@ -17,10 +17,15 @@
 #include "dfd_dwq.h"
 #include <climits>
 
-template <typename T, int K, int S, int ACT, bool PRO, bool STATS>
+// EACT >= 0 (eval / inference, where this layer's own BatchNorm is an affine map known up front): the epilogue stores
+// act(BN(y)) instead of the raw output and leaves per-(tile, image) channel sums of it for the squeeze-excite pooling
+// (pool_parts [tiles][N][C], the layout dfd_se_fwd's per-image kernel adds up) — the consumer needs no prologue and
+// the pooling pass disappears.
+template <typename T, int K, int S, int ACT, bool PRO, bool STATS, int EACT = -1>
 __global__ void __launch_bounds__(DFD_THREADS, 4)
 k_dw_fwd_q(const T* __restrict__ x, const float* __restrict__ bnstate, const float* __restrict__ w, T* __restrict__ y,
-           DwQGeom g, float* __restrict__ partials, int tile_bytes) {
+           DwQGeom g, float* __restrict__ partials, int tile_bytes, const float* __restrict__ ebn = nullptr,
+           float* __restrict__ pool_parts = nullptr) {
     constexpr int V = Vec<T>::N, N2 = V / 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint4* tile = reinterpret_cast<uint4*>(smem);
@@ -62,6 +67,15 @@ k_dw_fwd_q(const T* __restrict__ x, const float* __restrict__ bnstate, const flo
     f2 s1[N2], s2[N2];
 #pragma unroll
     for (int j = 0; j < N2; ++j) { s1[j] = (f2){0.f, 0.f}; s2[j] = (f2){0.f, 0.f}; }
+    f2 esc[N2], esh[N2], pool[N2];
+    if constexpr (EACT >= 0) {
+#pragma unroll
+        for (int j = 0; j < N2; ++j) {
+            esc[j] = cvalid ? *reinterpret_cast<const f2*>(ebn + c0 + 2 * j) : (f2){0.f, 0.f};
+            esh[j] = cvalid ? *reinterpret_cast<const f2*>(ebn + g.C + c0 + 2 * j) : (f2){0.f, 0.f};
+            pool[j] = (f2){0.f, 0.f};
+        }
+    }
 
     const int tiles = g.tiles_y * g.tiles_x, TW = 4 * g.QW;
     for (int work = by; work < g.nwork; work += gridDim.y) {
@@ -77,9 +91,9 @@ k_dw_fwd_q(const T* __restrict__ x, const float* __restrict__ bnstate, const flo
                                  ox0 * S - g.pl, g.IH, g.IW, g.iw_magic, g.cvb_log2);
         }
         __syncthreads();
-        if (!cvalid) continue;
+        if (EACT < 0 && !cvalid) continue;
 #pragma unroll 1
-        for (int q = lane; q < g.NQ; q += PL) {
+        for (int q = cvalid ? lane : g.NQ; q < g.NQ; q += PL) {
             const int qy = (int)(((unsigned)q * g.qw_magic) >> 20), qx = q - qy * g.QW;
             const int oy = oy0 + qy, ox = ox0 + 4 * qx;
             if (oy >= g.Ho || ox >= g.Wo) continue;
@@ -117,13 +131,27 @@ k_dw_fwd_q(const T* __restrict__ x, const float* __restrict__ bnstate, const flo
                 if (ox + o < g.Wo) {
 #pragma unroll
                     for (int j = 0; j < N2; ++j) {
-                        const f2 r = round2<T>(acc[o][j]);
+                        f2 r = round2<T>(acc[o][j]);
+                        if constexpr (EACT >= 0) {
+                            const f2 z = __builtin_elementwise_fma(esc[j], r, esh[j]);
+                            r = round2<T>((f2){act_fwd<EACT>(z.x), act_fwd<EACT>(z.y)});
+                            pool[j] += r;
+                        }
                         acc[o][j] = r;
                         if constexpr (STATS) { s1[j] += r; s2[j] = __builtin_elementwise_fma(r, r, s2[j]); }
                     }
                     *reinterpret_cast<uint4*>(dst + (long)o * g.C) = pack2(acc[o]);
                 }
             }
+        }
+        if constexpr (EACT >= 0) {
+            // this work item's channel sums of the activated output: row lanes combined in a fixed order, one row per
+            // (tile, image) — the per-image squeeze-excite kernel adds the tiles of an image in tile order
+            float pa[V];
+#pragma unroll
+            for (int j = 0; j < N2; ++j) { pa[2 * j] = pool[j].x; pa[2 * j + 1] = pool[j].y; pool[j] = (f2){0.f, 0.f}; }
+            reduce_rowlanes<V>(pa, cf + 2 * cvb * V, cvb, PL, vl, lane, cvalid);        // its own region: the weights stay put
+            if (lane == 0 && cvalid) store_f32<V>(pool_parts + ((long)tr * g.N + n) * g.C + c0, pa);
         }
     }
     if constexpr (STATS) {
@@ -241,7 +269,7 @@ static int dw_fwd_q_t(const void* x, const float* in_bnstate, int in_act, const 
                ((s->C * (int)sizeof(T)) % 128 != 0 || (cvb * 16) % 128 != 0)) ? 1 : 0;
     const bool stats = partials != nullptr;
     int cap = stats ? (pcap < DFD_MAX_PARTIALS ? pcap : DFD_MAX_PARTIALS) : DFD_MAX_PARTIALS;
-    int gy = 2048 / nchunks;
+    int gy = DFD_DW_GRID / nchunks;
     if (gy < 64) gy = 64;
     if (gy > cap) gy = cap;
     if (gy > g.nwork) gy = g.nwork;
@@ -264,6 +292,45 @@ static int dw_fwd_q_t(const void* x, const float* in_bnstate, int in_act, const 
     });
 #undef LAUNCH_FWD
     return DFD_CHECK_LAUNCH();
+}
+
+// ---- eval / inference form: y = act(BN(conv(x))) stored, per-(tile, image) channel sums for the SE pooling
+template <typename T>
+static int dw_fwd_eval_t(const void* x, const float* w, const float* out_bnstate, int out_act, void* y,
+                         const dfd_dwconv_shape* s, float* pool_parts, int* ntiles, hipStream_t st) {
+    constexpr int V = Vec<T>::N;
+    DwQGeom g; int tile_bytes;
+    if (!dfd_dwq_geom(s, V, 16, false, (size_t)(s ? s->k * s->k + 2 : 0) * 16 * V * 4 + (size_t)DFD_THREADS * V * 4, 0, 1, &g, &tile_bytes)) return DFD_EINVAL;
+    const int cvb = 1 << g.cvb_log2, nchunks = (g.CV + cvb - 1) / cvb;
+    g.remap = (nchunks > 1 && g.tiles_y * g.tiles_x >= 2 &&
+               ((s->C * (int)sizeof(T)) % 128 != 0 || (cvb * 16) % 128 != 0)) ? 1 : 0;
+    int gy = DFD_DW_GRID / nchunks;
+    if (gy < 64) gy = 64;
+    if (gy > DFD_MAX_PARTIALS) gy = DFD_MAX_PARTIALS;
+    if (gy > g.nwork) gy = g.nwork;
+    *ntiles = g.tiles_y * g.tiles_x;
+    const size_t lds = (size_t)tile_bytes + (size_t)(s->k * s->k + 2) * cvb * V * 4 + (size_t)DFD_THREADS * V * 4;
+    dim3 grid(nchunks, gy);
+    if (out_act != DFD_ACT_SILU) return DFD_EUNSUPPORTED;          // the EfficientNet blocks; widen when another net needs it
+    DISPATCH_KS(s->k, s->stride, {
+        hipLaunchKernelGGL((k_dw_fwd_q<T, K, S, DFD_ACT_NONE, false, false, DFD_ACT_SILU>), grid, dim3(DFD_THREADS), lds, st,
+                           (const T*)x, (const float*)nullptr, w, (T*)y, g, (float*)nullptr, tile_bytes, out_bnstate, pool_parts);
+    });
+    return DFD_CHECK_LAUNCH();
+}
+extern "C" int dfd_dwconv_fwd_eval_tiles(int dtype, const dfd_dwconv_shape* s) {
+    DwQGeom g; int tile_bytes;
+    const int V = dtype == DFD_BF16 ? Vec<bf16>::N : Vec<float>::N;
+    if (!dfd_dwq_geom(s, V, 16, false, (size_t)(s ? s->k * s->k + 2 : 0) * 16 * V * 4 + (size_t)DFD_THREADS * V * 4, 0, 1, &g, &tile_bytes)) return 0;
+    return g.tiles_y * g.tiles_x;
+}
+extern "C" int dfd_dwconv_fwd_eval(int dtype, const void* x, const float* w, const float* out_bnstate, int out_act, void* y,
+                                   const dfd_dwconv_shape* s, float* pool_parts, int* ntiles, dfd_stream stream) {
+    if (!x || !w || !out_bnstate || !y || !s || !pool_parts || !ntiles) return DFD_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == DFD_BF16) return dw_fwd_eval_t<bf16>(x, w, out_bnstate, out_act, y, s, pool_parts, ntiles, st);
+    if (dtype == DFD_F32) return dw_fwd_eval_t<float>(x, w, out_bnstate, out_act, y, s, pool_parts, ntiles, st);
+    return DFD_EINVAL;
 }
 
 extern "C" int dfd_dwconv_fwd(int dtype, const void* x, const float* in_bnstate, int in_act, const float* w, void* y,

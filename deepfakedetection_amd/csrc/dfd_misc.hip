@@ -198,7 +198,7 @@ k_se_fwd_img(const float* __restrict__ parts, int splits, float mul, float* __re
     constexpr int NW = SE_IMG_THREADS / 64;
     for (int c = t; c < C; c += SE_IMG_THREADS) {
         float v;
-        if (splits > 1) {
+        if (parts) {
             float s = 0.f;
             for (int z = 0; z < splits; ++z) s += parts[((long)z * N + n) * C + c];
             v = s * mul;
@@ -334,7 +334,22 @@ extern "C" int dfd_se_fwd(int dtype, const void* y, const float* bnstate, int ac
     const int rc = dfd_pool_launch(dtype, false, nullptr, y, bnstate, act_in, pooled, N, HW, C, ws, ws_bytes, st, &splits, &mul);
     if (rc != DFD_OK) return rc;
     DISPATCH_ACT(act, {
-        hipLaunchKernelGGL((k_se_fwd_img<ACT>), dim3(N), dim3(SE_IMG_THREADS), 0, st, (const float*)ws, splits, mul, pooled, w1, b1,
+        hipLaunchKernelGGL((k_se_fwd_img<ACT>), dim3(N), dim3(SE_IMG_THREADS), 0, st, splits > 1 ? (const float*)ws : nullptr, splits,
+                           mul, pooled, w1, b1, w2t, b2, N, C, R, hpre, gate);
+    });
+    return DFD_CHECK_LAUNCH();
+}
+
+// the same branch from per-tile channel sums that the producer already formed (dfd_dwconv_fwd_eval): no pooling pass
+extern "C" int dfd_se_fwd_parts(const float* parts, int splits, int N, int HW, int C, const float* w1, const float* b1,
+                                const float* w2, const float* b2, int R, int act, float* pooled, float* hpre, float* gate,
+                                float* w2t, dfd_stream stream) {
+    if (!parts || splits < 1 || !w1 || !pooled || !hpre || !gate || !w2t || N < 1 || HW < 1 || C < 1 || R < 1 || C % 4) return DFD_EINVAL;
+    if (C > SE_MAX_C || R > SE_MAX_R) return DFD_EUNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    if (w2) hipLaunchKernelGGL(k_transpose_f32, dim3((C * R + 255) / 256), dim3(256), 0, st, w2, w2t, C, R);
+    DISPATCH_ACT(act, {
+        hipLaunchKernelGGL((k_se_fwd_img<ACT>), dim3(N), dim3(SE_IMG_THREADS), 0, st, parts, splits, 1.f / (float)HW, pooled, w1, b1,
                            w2t, b2, N, C, R, hpre, gate);
     });
     return DFD_CHECK_LAUNCH();

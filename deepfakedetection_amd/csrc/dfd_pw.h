@@ -184,7 +184,8 @@ __device__ __forceinline__ int tn_off_bf16(int m, int ch) {
 // wave-autonomous NT kernel for layers whose weight panel stays resident in LDS (dfd_pwntw.hip);
 // returns DFD_EUNSUPPORTED when the shape does not qualify (the caller then uses the tiled kernel)
 int dfd_pw_ntw(int dtype, const void* a, const dfd_prologue* pro, const void* w, void* out, const void* residual, int M,
-               int K, int Nout, float* partials, int pcap, int* nparts, hipStream_t st);
+               int K, int Nout, float* partials, int pcap, int* nparts, hipStream_t st, const float* ebn = nullptr,
+               int eact = DFD_ACT_NONE);
 
 // wave-autonomous TN (weight-gradient) kernel for large-M layers with a narrow and a wide operand
 // (dfd_pwtnw.hip, bf16 only); DFD_EUNSUPPORTED when the shape does not qualify

@@ -36,10 +36,13 @@ template <typename T, int BN, int BM> struct NtLds {
 // BM = rows of a workgroup tile: 128, or 64 when M is so small that 128-row tiles leave CUs idle
 // CONV: the A operand is gathered from an NHWC image (implicit GEMM of a dense k x k convolution, ConvArgs): a lane's
 // 16-byte chunk is 8 channels of one tap, zero outside the image AFTER the producer's BN + activation
-template <typename T, int BN, int BM, int PRO, int ACT, bool RES, bool STATS, bool CONV = false>
+// EACT >= 0 (eval / inference): the epilogue stores act(scale * y + shift) with this layer's own BatchNorm coefficients
+// (ebn: float[2+][Nout]) instead of the raw output, so that the consumer needs no prologue
+template <typename T, int BN, int BM, int PRO, int ACT, bool RES, bool STATS, bool CONV = false, int EACT = -1>
 __global__ void __launch_bounds__(DFD_THREADS, 2)
 k_pw_nt(const T* __restrict__ a, ProArgs pa, const T* __restrict__ w, T* __restrict__ out, const T* __restrict__ res,
-        int M, int K, int Nout, int m_tiles, int n_tiles, int gx, float* __restrict__ partials, ConvArgs cv) {
+        int M, int K, int Nout, int m_tiles, int n_tiles, int gx, float* __restrict__ partials, ConvArgs cv,
+        const float* __restrict__ ebn = nullptr) {
     constexpr int E = El<T>::EPC;
     constexpr int BK = El<T>::BK;
     constexpr int NTW = BN / 32;            // 16-wide n tiles per wave
@@ -249,12 +252,18 @@ k_pw_nt(const T* __restrict__ a, ProArgs pa, const T* __restrict__ w, T* __restr
                 __syncthreads();
                 const int n = n0 + ec * E;
                 if (n < Nout) {
+                    float es[E], eh[E];
+                    if constexpr (EACT >= 0) { load_f32<E>(ebn + n, es); load_f32<E>(ebn + Nout + n, eh); }
 #pragma unroll 4
                     for (int r = er; r < BM; r += RL) {
                         const int m = m0 + r;
                         if (m >= M) break;
                         float v[E];
                         q_to_f(*reinterpret_cast<const uint4*>(smem + r * OROW + ec * 16), v);
+                        if constexpr (EACT >= 0) {
+#pragma unroll
+                            for (int j = 0; j < E; ++j) v[j] = round_to<T>(act_fwd<EACT>(fmaf(es[j], v[j], eh[j])));
+                        }
                         if constexpr (RES) {
                             float q[E];
                             Vec<T>::load(res + (long)m * Nout + n, q);
@@ -660,7 +669,8 @@ extern "C" int dfd_prep_weights_multi(const dfd_prep_job* jobs, int njobs, dfd_s
 // ===========================================================================
 template <typename T, int BN, int BM>
 static int pw_nt_launch(const void* a, const dfd_prologue* pro, const void* w, void* out, const void* residual, int M,
-                        int K, int Nout, float* partials, int pcap, int* nparts, hipStream_t st) {
+                        int K, int Nout, float* partials, int pcap, int* nparts, hipStream_t st, const float* ebn = nullptr,
+                        int eact = DFD_ACT_NONE) {
     const int m_tiles = (M + BM - 1) / BM, n_tiles = (Nout + BN - 1) / BN;
     int cap = partials ? (pcap < DFD_MAX_PARTIALS ? pcap : DFD_MAX_PARTIALS) : DFD_MAX_PARTIALS;
     int gx = 2048 / n_tiles;
@@ -676,9 +686,16 @@ static int pw_nt_launch(const void* a, const dfd_prologue* pro, const void* w, v
     const int act = (pro && (mode == DFD_PRO_BN_ACT || mode == DFD_PRO_BN_ACT_GATE)) ? pro->act : DFD_ACT_NONE;
     const bool has_res = residual != nullptr, stats = partials != nullptr;
     dim3 grid(gx * n_tiles);
+    if (ebn) {          // eval epilogue: plain operand, no residual, no statistics (the EfficientNet expand convolution)
+        if (mode != DFD_PRO_NONE || has_res || stats || eact != DFD_ACT_SILU) return DFD_EUNSUPPORTED;
+        hipLaunchKernelGGL((k_pw_nt<T, BN, BM, DFD_PRO_NONE, DFD_ACT_NONE, false, false, false, DFD_ACT_SILU>), grid, dim3(DFD_THREADS),
+                           lds, st, (const T*)a, pa, (const T*)w, (T*)out, (const T*)nullptr, M, K, Nout, m_tiles, n_tiles, gx,
+                           (float*)nullptr, ConvArgs{}, ebn);
+        return DFD_CHECK_LAUNCH();
+    }
 #define LAUNCH_NT(PRO, RES, STATS)                                                                                        \
     hipLaunchKernelGGL((k_pw_nt<T, BN, BM, PRO, ACT, RES, STATS>), grid, dim3(DFD_THREADS), lds, st, (const T*)a, pa, (const T*)w, \
-                       (T*)out, (const T*)residual, M, K, Nout, m_tiles, n_tiles, gx, partials, ConvArgs{})
+                       (T*)out, (const T*)residual, M, K, Nout, m_tiles, n_tiles, gx, partials, ConvArgs{}, (const float*)nullptr)
     // combinations used by the engine: forward = {NONE, BN_ACT, BN_ACT_GATE} x stats, no residual;
     // data gradient = AFFINE2 (+ residual), no stats; plain = NONE
     if (mode == DFD_PRO_AFFINE2) {
@@ -705,13 +722,14 @@ static int pw_nt_launch(const void* a, const dfd_prologue* pro, const void* w, v
 
 template <typename T>
 static int pw_nt_t(const void* a, const dfd_prologue* pro, const void* w, void* out, const void* residual, int M, int K,
-                   int Nout, float* partials, int pcap, int* nparts, hipStream_t st) {
+                   int Nout, float* partials, int pcap, int* nparts, hipStream_t st, const float* ebn = nullptr,
+                   int eact = DFD_ACT_NONE) {
     // 128-row tiles unless they would leave most CUs without a workgroup (the 7x7 / 14x14 layers)
     const long tiles128 = (long)((M + 127) / 128) * ((Nout + 127) / 128);
     const bool small = tiles128 < 256;      // measured: a win below one tile per CU, a loss above
 #define PW_NT_GO(BNV)                                                                                                   \
-    return small ? pw_nt_launch<T, BNV, 64>(a, pro, w, out, residual, M, K, Nout, partials, pcap, nparts, st)            \
-                 : pw_nt_launch<T, BNV, 128>(a, pro, w, out, residual, M, K, Nout, partials, pcap, nparts, st)
+    return small ? pw_nt_launch<T, BNV, 64>(a, pro, w, out, residual, M, K, Nout, partials, pcap, nparts, st, ebn, eact)  \
+                 : pw_nt_launch<T, BNV, 128>(a, pro, w, out, residual, M, K, Nout, partials, pcap, nparts, st, ebn, eact)
     if (Nout <= 32) PW_NT_GO(32);
     if (Nout <= 64) PW_NT_GO(64);
     PW_NT_GO(128);
@@ -740,7 +758,7 @@ static int conv_nt_launch(const void* x, const dfd_dwconv_shape* s, const float*
     dim3 grid(gx * n_tiles);
 #define LAUNCH_CV(PRO, STATS)                                                                                               \
     hipLaunchKernelGGL((k_pw_nt<T, BN, BM, PRO, ACT, false, STATS, true>), grid, dim3(DFD_THREADS), lds, st, (const T*)x, pa,   \
-                       (const T*)w, (T*)out, (const T*)nullptr, M, K, Nout, m_tiles, n_tiles, gx, partials, cv)
+                       (const T*)w, (T*)out, (const T*)nullptr, M, K, Nout, m_tiles, n_tiles, gx, partials, cv, (const float*)nullptr)
     if (!in_bnstate) {
         constexpr int ACT = DFD_ACT_NONE;
         if (stats) LAUNCH_CV(DFD_PRO_NONE, true); else LAUNCH_CV(DFD_PRO_NONE, false);
@@ -778,6 +796,17 @@ extern "C" int dfd_pwconv_fwd(int dtype, const void* a, const dfd_prologue* pro,
     if (rc != DFD_EUNSUPPORTED) return rc;
     if (dtype == DFD_BF16) return pw_nt_t<bf16>(a, pro, w, out, residual, M, K, Nout, partials, pcap, nparts, st);
     if (dtype == DFD_F32) return pw_nt_t<float>(a, pro, w, out, residual, M, K, Nout, partials, pcap, nparts, st);
+    return DFD_EINVAL;
+}
+
+extern "C" int dfd_pwconv_fwd_eval(int dtype, const void* a, const void* w, const float* out_bnstate, int out_act, void* out,
+                                   int M, int K, int Nout, dfd_stream stream) {
+    if (!a || !w || !out || !out_bnstate || M < 1 || K < 8 || Nout < 8 || K % 8 || Nout % 8) return DFD_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const int rc = dfd_pw_ntw(dtype, a, nullptr, w, out, nullptr, M, K, Nout, nullptr, 0, nullptr, st, out_bnstate, out_act);
+    if (rc != DFD_EUNSUPPORTED) return rc;
+    if (dtype == DFD_BF16) return pw_nt_t<bf16>(a, nullptr, w, out, nullptr, M, K, Nout, nullptr, 0, nullptr, st, out_bnstate, out_act);
+    if (dtype == DFD_F32) return pw_nt_t<float>(a, nullptr, w, out, nullptr, M, K, Nout, nullptr, 0, nullptr, st, out_bnstate, out_act);
     return DFD_EINVAL;
 }
 

@@ -22,11 +22,12 @@
 // KSN = 32-byte... k sub-steps per stage (1: K <= 4 chunks, a stage is 64 rows x 64 B per wave;
 //       2: a stage is 32 rows x 128 B per wave).  Either way a lane has 4 x 16 B in flight per stage.
 // NCH = column chunks a workgroup may carry WITH statistics (one accumulator set per chunk and lane)
-template <typename T, int BN, int KSN, int NCH, int PRO, int ACT, bool RES, bool STATS>
+// EACT >= 0: eval epilogue act(scale * y + shift) with this layer's own BatchNorm coefficients (see k_pw_nt)
+template <typename T, int BN, int KSN, int NCH, int PRO, int ACT, bool RES, bool STATS, int EACT = -1>
 __global__ void __launch_bounds__(DFD_THREADS, 2)
 k_pw_ntw(const T* __restrict__ a, ProArgs pa, const T* __restrict__ w, T* __restrict__ out, const T* __restrict__ res,
          int M, int K, int Nout, int m_tiles, int n_tiles, int gx, int wstride, int eoff, int coff, int nchunks,
-         float* __restrict__ partials) {
+         float* __restrict__ partials, const float* __restrict__ ebn = nullptr) {
     constexpr int E = El<T>::EPC;
     constexpr int BK = KSN * 4 * E;         // k elements per stage
     constexpr int JN = 4 / KSN;             // 16-row fragments per wave and stage
@@ -231,6 +232,8 @@ k_pw_ntw(const T* __restrict__ a, ProArgs pa, const T* __restrict__ w, T* __rest
             const int n = n0 + nc * BN + ec * E;
             const int mw = mt * BM + wave * WR;
             if (n < Nout) {
+                float es[E], eh[E];
+                if constexpr (EACT >= 0) { load_f32<E>(ebn + n, es); load_f32<E>(ebn + Nout + n, eh); }
 #pragma unroll
                 for (int ps = 0; ps < WR / RL; ++ps) {
                     const int r = er + ps * RL;
@@ -238,6 +241,10 @@ k_pw_ntw(const T* __restrict__ a, ProArgs pa, const T* __restrict__ w, T* __rest
                     if (m < M) {
                         float v[E];
                         q_to_f(*reinterpret_cast<const uint4*>(eb + r * OROW + ec * 16), v);
+                        if constexpr (EACT >= 0) {
+#pragma unroll
+                            for (int x = 0; x < E; ++x) v[x] = round_to<T>(act_fwd<EACT>(fmaf(es[x], v[x], eh[x])));
+                        }
                         if constexpr (RES) {
                             float q[E];
                             Vec<T>::load(res + (long)m * Nout + n, q);
@@ -344,7 +351,7 @@ static int ntw_blocks_per_cu(KernelT kern, int lds) {
 
 template <typename T, int BN, int KSN>
 static int ntw_launch(const void* a, const dfd_prologue* pro, const void* w, void* out, const void* residual, int M,
-                      int K, int Nout, float* partials, int pcap, int* nparts, hipStream_t st) {
+                      int K, int Nout, float* partials, int pcap, int* nparts, hipStream_t st, const float* ebn, int eact) {
     constexpr int E = El<T>::EPC;
     constexpr int BK = KSN * 4 * E;
     constexpr int WR = 16 * (4 / KSN), BM = 4 * WR;
@@ -385,11 +392,23 @@ static int ntw_launch(const void* a, const dfd_prologue* pro, const void* w, voi
         if (gx > m_tiles) gx = m_tiles;                                                                                   \
         if (partials) *nparts = gx;                                                                                       \
         hipLaunchKernelGGL(kern, dim3(gx * n_tiles), dim3(DFD_THREADS), lds, st, (const T*)a, pa, (const T*)w, (T*)out,   \
-                           (const T*)residual, M, K, Nout, m_tiles, n_tiles, gx, wstride, eoff, coff, nchunks, partials); \
+                           (const T*)residual, M, K, Nout, m_tiles, n_tiles, gx, wstride, eoff, coff, nchunks, partials,  \
+                           (const float*)nullptr);                                                                        \
     } while (0)
     // (statistics over several column chunks in one workgroup, NCH = 4, measured slower than
     // separate column tiles: not instantiated)
 #define LAUNCH_NTW(PRO, RES, STATS) LAUNCH_NTW_(1, PRO, RES, STATS)
+    if (ebn) {          // eval epilogue: plain operand, no residual, no statistics
+        if (mode != DFD_PRO_NONE || has_res || stats || eact != DFD_ACT_SILU) return DFD_EUNSUPPORTED;
+        auto kern = k_pw_ntw<T, BN, KSN, 1, DFD_PRO_NONE, DFD_ACT_NONE, false, false, DFD_ACT_SILU>;
+        int gx = (256 * ntw_blocks_per_cu(kern, lds)) / n_tiles;
+        if (gx < 32) gx = 32;
+        if (gx > cap) gx = cap;
+        if (gx > m_tiles) gx = m_tiles;
+        hipLaunchKernelGGL(kern, dim3(gx * n_tiles), dim3(DFD_THREADS), lds, st, (const T*)a, pa, (const T*)w, (T*)out,
+                           (const T*)nullptr, M, K, Nout, m_tiles, n_tiles, gx, wstride, eoff, coff, nchunks, (float*)nullptr, ebn);
+        return DFD_CHECK_LAUNCH();
+    }
     if (mode == DFD_PRO_AFFINE2) {
         constexpr int ACT = DFD_ACT_NONE;
         if (stats) return DFD_EUNSUPPORTED;
@@ -415,8 +434,8 @@ static int ntw_launch(const void* a, const dfd_prologue* pro, const void* w, voi
 
 template <typename T>
 static int ntw_t(const void* a, const dfd_prologue* pro, const void* w, void* out, const void* residual, int M, int K,
-                 int Nout, float* partials, int pcap, int* nparts, hipStream_t st) {
-#define NTW_GO(BN, KSN) return ntw_launch<T, BN, KSN>(a, pro, w, out, residual, M, K, Nout, partials, pcap, nparts, st)
+                 int Nout, float* partials, int pcap, int* nparts, hipStream_t st, const float* ebn, int eact) {
+#define NTW_GO(BN, KSN) return ntw_launch<T, BN, KSN>(a, pro, w, out, residual, M, K, Nout, partials, pcap, nparts, st, ebn, eact)
     constexpr int E = El<T>::EPC;
     if (K <= 4 * E) {
         // one 64-byte k sub-step covers K: 64-row stages, column tiles of at most 64
@@ -432,8 +451,8 @@ static int ntw_t(const void* a, const dfd_prologue* pro, const void* w, void* ou
 }
 
 int dfd_pw_ntw(int dtype, const void* a, const dfd_prologue* pro, const void* w, void* out, const void* residual, int M,
-               int K, int Nout, float* partials, int pcap, int* nparts, hipStream_t st) {
-    if (dtype == DFD_BF16) return ntw_t<bf16>(a, pro, w, out, residual, M, K, Nout, partials, pcap, nparts, st);
-    if (dtype == DFD_F32) return ntw_t<float>(a, pro, w, out, residual, M, K, Nout, partials, pcap, nparts, st);
+               int K, int Nout, float* partials, int pcap, int* nparts, hipStream_t st, const float* ebn, int eact) {
+    if (dtype == DFD_BF16) return ntw_t<bf16>(a, pro, w, out, residual, M, K, Nout, partials, pcap, nparts, st, ebn, eact);
+    if (dtype == DFD_F32) return ntw_t<float>(a, pro, w, out, residual, M, K, Nout, partials, pcap, nparts, st, ebn, eact);
     return DFD_EINVAL;
 }

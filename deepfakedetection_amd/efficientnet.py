@@ -141,7 +141,8 @@ class HipMBConv(nn.Module):
             w_exp, g_exp, b_exp, ref_exp = exp.weight, exp_bn.weight, exp_bn.bias, _bnref(exp_bn)
         else:
             w_exp = g_exp = b_exp = ref_exp = None
-        cfg = MBConvCtx(p.expand, p.dw, p.skip, ref_exp, _bnref(dw_bn), _bnref(proj_bn), self.training, derived, counters)
+        cfg = MBConvCtx(p.expand, p.dw, p.skip, ref_exp, _bnref(dw_bn), _bnref(proj_bn), self.training, derived, counters,
+                        torch.is_grad_enabled())
         return MBConvFunction.apply(x, w_exp, g_exp, b_exp, dw.weight, dw_bn.weight, dw_bn.bias, ser.weight, ser.bias,
                                     see.weight, see.bias, proj.weight, proj_bn.weight, proj_bn.bias, row_scale, cfg)
 

@@ -17,6 +17,7 @@ trainers/efficientnet.py:297,302; orchestration/orchestrator.py:529,590).
 from __future__ import annotations
 
 import contextlib
+import os
 import threading
 from dataclasses import dataclass
 
@@ -66,6 +67,22 @@ def _bn_state(parts, nparts, count: int, bn: BNRef, weight, bias, training: bool
 
 
 _bn_batch_tls = threading.local()
+
+
+def eval_fused_enabled(elems: int, dtype: torch.dtype) -> bool:
+    """Whether an MBConv block whose depthwise input has `elems` elements of `dtype` runs the inference form
+    (MBConvFunction._forward_eval).  Measured (profiles/r02_eval_forms.md): the SiLU of a producer epilogue is
+    exposed VALU time (two half-rate transcendentals per element), the same SiLU in a consumer's staging phase hides under
+    its loads — so the inference form only wins where launches, not VALU, bound the block: f32 tensors up to 32 M elements
+    (batch <= 64 at 224 px: -2..3 % replayed, -6 % eager); in bf16 it never does.  DFD_EVAL_FUSED=0 / 1 forces the
+    training-form chain / the inference form (A/B switch of scripts/eval_small.py and of the parity test)."""
+    flag = os.environ.get("DFD_EVAL_FUSED")
+    if flag is not None:
+        return flag != "0"
+    return dtype == torch.float32 and elems <= int(os.environ.get("DFD_EVAL_FUSED_MAX_ELEMS", EVAL_FUSED_MAX_ELEMS))
+
+
+EVAL_FUSED_MAX_ELEMS = 32 << 20
 
 
 @contextlib.contextmanager
@@ -160,6 +177,9 @@ class MBConvCtx:
     # ((wexp_nk, wexp_kn) | None, (wproj_nk, wproj_kn), se_w2t); None: prepare per layer
     derived: tuple | None = None
     counters: list | None = None          # see _bn_state
+    # autograd state at the call site (inside Function.forward grad mode is always off, and needs_input_grad reflects
+    # requires_grad alone): False under no_grad / inference_mode, where nothing has to be kept for a backward pass
+    grad_enabled: bool = True
 
 
 class MBConvFunction(torch.autograd.Function):
@@ -178,6 +198,10 @@ class MBConvFunction(torch.autograd.Function):
         geom = cfg.dw
         Ho, Wo = geom.out_size(H), geom.out_size(W)
         need_bwd = any(ctx.needs_input_grad)   # grad mode is off inside forward(); this is the autograd view
+        if not tr and not (need_bwd and cfg.grad_enabled) and eval_fused_enabled(
+                N * H * W * (w_exp.shape[0] if cfg.expand else Cin), dt):
+            return MBConvFunction._forward_eval(x, w_exp, g_exp, b_exp, w_dw, g_dw, b_dw, se_w1, se_b1, se_w2, se_b2, w_proj,
+                                                g_proj, b_proj, cfg, Ho, Wo)
         if cfg.expand:
             wexp_nk, wexp_kn = cfg.derived[0] if cfg.derived is not None else K.prep_weights(w_exp, dt, True, need_bwd)
             y1, parts, n = K.pwconv(x, None, wexp_nk, None, stats=tr)
@@ -204,6 +228,32 @@ class MBConvFunction(torch.autograd.Function):
         ctx.save_for_backward(x, y1, y2, y3, st1, st2, st3, pooled, hpre, gate, wexp_kn, wproj_kn, w_dw, w1, w2t,
                               g_exp, g_dw, g_proj, row_scale if ctx.has_rs else None)
         return out
+
+    @staticmethod
+    def _forward_eval(x, w_exp, g_exp, b_exp, w_dw, g_dw, b_dw, se_w1, se_b1, se_w2, se_b2, w_proj, g_proj, b_proj, cfg, Ho, Wo):
+        """Inference form (running statistics, nothing kept for a backward pass): every BatchNorm is an affine map known up
+        front, so each PRODUCER stores its activated output and the depthwise kernel also leaves the squeeze-excite channel
+        sums — no consumer prologues, no pooling pass.  Per stage the values are those of the reference's autocast graph
+        (conv -> bn -> SiLU each rounded to the activation dtype; timm InvertedResidual.forward / efficientnet_pytorch
+        MBConvBlock.forward)."""
+        N, H, W, Cin = x.shape
+        dt = x.dtype
+        geom = cfg.dw
+        a1 = x
+        if cfg.expand:
+            wexp_nk, _ = cfg.derived[0] if cfg.derived is not None else K.prep_weights(w_exp, dt, True, False)
+            st1 = _bn_state(None, 0, N * H * W, cfg.bn_expand, g_exp, b_exp, False, cfg.counters)
+            a1 = K.pwconv_eval(x, wexp_nk, st1, ACT_SILU)
+        st2 = _bn_state(None, 0, N * Ho * Wo, cfg.bn_dw, g_dw, b_dw, False, cfg.counters)
+        a2, pool_parts, _ = K.dwconv_eval(a1, w_dw, st2, ACT_SILU, geom.kernel, geom.stride, geom.pad_lead, geom.pad_lead, Ho, Wo)
+        w1, w2 = se_w1.reshape(se_w1.shape[0], -1), se_w2.reshape(se_w2.shape[0], -1)
+        _, gate, _ = K.se_fwd_parts(pool_parts, Ho * Wo, w1, se_b1, w2, se_b2, ACT_SILU,
+                                    cfg.derived[2] if cfg.derived is not None else None)
+        wproj_nk, _ = cfg.derived[1] if cfg.derived is not None else K.prep_weights(w_proj, dt, True, False)
+        pro = K.pro_bn_act_gate(K.identity_state(x.device, a2.shape[3]), ACT_NONE, gate, Ho * Wo)     # gate only
+        y3, _, _ = K.pwconv(a2, pro, wproj_nk, None, stats=False)
+        st3 = _bn_state(None, 0, N * Ho * Wo, cfg.bn_project, g_proj, b_proj, False, cfg.counters)
+        return K.bn_act_apply(y3, st3, ACT_NONE, x if cfg.skip else None, None)
 
     @staticmethod
     def backward(ctx, g):

@@ -470,6 +470,23 @@ def pro_bn_act_gate(state: torch.Tensor, act: int, gate: torch.Tensor, HW: int) 
     return _pro(PRO_BN_ACT_GATE, act, HW, None, state, gate)
 
 
+_identity_states: dict = {}
+
+
+def identity_state(device: torch.device, C: int) -> torch.Tensor:
+    """float[4][C] BatchNorm state of the identity map (scale 1, shift 0, mean 0, rstd 1): turns the BN_ACT_GATE prologue into
+    a gate-only one for operands that were stored activated."""
+    key = (device.type, device.index, C)
+    st = _identity_states.get(key)
+    if st is None:
+        st = torch.zeros((4, C), dtype=torch.float32, device=device)
+        st[0].fill_(1.0)
+        st[3].fill_(1.0)
+        if not (device.type == "cuda" and torch.cuda.is_current_stream_capturing()):
+            _identity_states[key] = st          # a tensor born inside a capture belongs to that graph's pool: not cached
+    return st
+
+
 def pro_affine2(a2: torch.Tensor, coef: torch.Tensor) -> Prologue:
     return _pro(PRO_AFFINE2, ACT_NONE, 1, a2, coef, None)
 
@@ -624,6 +641,52 @@ def pwconv(a: torch.Tensor, pro: Prologue | None, w_nk: torch.Tensor, residual: 
                               _p(residual), M, K, Nout, _p(parts), MAX_PARTIALS, ctypes.byref(n), _stream()),
           "dfd_pwconv_fwd", f"M={M} K={K} N={Nout}")
     return out, parts, n.value
+
+
+# ---- eval / inference form of the MBConv block (include/dfd_hip.h "eval / inference form") ---------------------
+def pwconv_eval(a: torch.Tensor, w_nk: torch.Tensor, out_state: torch.Tensor, out_act: int) -> torch.Tensor:
+    """out = act(scale * (a @ w_nk^T) + shift) with this layer's own BatchNorm coefficients, stored activated."""
+    K = a.shape[-1]
+    M = a.numel() // K
+    Nout = w_nk.shape[0]
+    out = torch.empty((*a.shape[:-1], Nout), dtype=a.dtype, device=a.device)
+    check(_L().dfd_pwconv_fwd_eval(_dt(a), _p(a), _p(w_nk), _p(out_state), out_act, _p(out), M, K, Nout, _stream()),
+          "dfd_pwconv_fwd_eval", f"M={M} K={K} N={Nout}")
+    return out
+
+
+def dwconv_eval(x: torch.Tensor, w: torch.Tensor, out_state: torch.Tensor, out_act: int, k: int, stride: int, pad_top: int,
+                pad_left: int, Ho: int, Wo: int):
+    """y = act(bn(dwconv(x))) stored activated + per-(tile, image) channel sums of y. Returns (y, pool_parts, ntiles)."""
+    _chk_nhwc(x)
+    N, H, W, C = x.shape
+    y = torch.empty((N, Ho, Wo, C), dtype=x.dtype, device=x.device)
+    shp = _dw_shape(x.shape, Ho, Wo, k, stride, pad_top, pad_left)
+    tiles = _L().dfd_dwconv_fwd_eval_tiles(_dt(x), ctypes.byref(shp))
+    if tiles < 1:
+        raise ValueError(f"dfd_dwconv_fwd_eval: unsupported shape {tuple(x.shape)} k{k}s{stride}")
+    parts = torch.empty((tiles, N, C), dtype=torch.float32, device=x.device)
+    n = ctypes.c_int(0)
+    check(_L().dfd_dwconv_fwd_eval(_dt(x), _p(x), _p(w), _p(out_state), out_act, _p(y), ctypes.byref(shp), _p(parts),
+                                   ctypes.byref(n), _stream()), "dfd_dwconv_fwd_eval", f"{tuple(x.shape)} k{k}s{stride}")
+    assert n.value == tiles
+    return y, parts, tiles
+
+
+def se_fwd_parts(parts: torch.Tensor, HW: int, w1, b1, w2, b2, act: int, w2t: torch.Tensor | None = None):
+    """The squeeze-excite branch from the producer's per-tile channel sums (no pooling pass): returns pooled, gate, w2t."""
+    tiles, N, C = parts.shape
+    R = w1.shape[0]
+    dev = parts.device
+    pooled = torch.empty((N, C), dtype=torch.float32, device=dev)
+    hpre = torch.empty((N, R), dtype=torch.float32, device=dev)
+    gate = torch.empty((N, C), dtype=torch.float32, device=dev)
+    ready = w2t is not None
+    if not ready:
+        w2t = torch.empty((R, C), dtype=torch.float32, device=dev)
+    check(_L().dfd_se_fwd_parts(_p(parts), tiles, N, HW, C, _p(w1), _p(b1), None if ready else _p(w2), _p(b2), R, act,
+                                _p(pooled), _p(hpre), _p(gate), _p(w2t), _stream()), "dfd_se_fwd_parts", f"C={C} R={R}")
+    return pooled, gate, w2t
 
 
 def pwconv_wgrad(p: torch.Tensor, pro_p: Prologue | None, q: torch.Tensor, pro_q: Prologue | None,

@@ -68,7 +68,9 @@ typedef void* dfd_stream;          /* a hipStream_t */
  * prologue, and the bookkeeping kernels (dfd_rand, dfd_step_tick, dfd_axpby, dfd_add);
  * 111 = dfd_se_fwd / dfd_se_bwd (squeeze-excite in two / three launches); dfd_rowtable_grad takes a workspace;
  * dfd_conv_fwd / dfd_conv_wgrad (implicit-GEMM dense convolution); dfd_sum_batch_begin / _end;
- * dfd_bn_eval_coeffs_multi. */
+ * dfd_bn_eval_coeffs_multi;
+ * 112 = the eval / inference form of the MBConv block: dfd_pwconv_fwd_eval, dfd_dwconv_fwd_eval(_tiles),
+ * dfd_se_fwd_parts. */
 int dfd_version(void);
 
 /* Batched final summation of weight gradients.  Every weight-gradient entry point (dfd_pwconv_wgrad,
@@ -215,6 +217,29 @@ int dfd_dwconv_bwd_weight(int dtype, const void* dz, const void* y, const float*
                           const void* xin, const float* in_bnstate, int in_act,
                           float* dw, const dfd_dwconv_shape* s, int accumulate,
                           float* ws, size_t ws_bytes, dfd_stream stream);
+
+/* ---- eval / inference form of the MBConv block -----------------------------------------------------------------
+ * With running statistics every BatchNorm is an affine map known before the layer runs, so the PRODUCER can apply
+ * its own BatchNorm + activation in the epilogue and store the activated tensor (training cannot: the batch
+ * statistics only exist once the whole layer has run).  Replaces, for `model.eval()` forwards without autograd
+ * (reference: orchestration/orchestrator.py:127-151 `class_probabilities`, evaluate.py:238-260, the validation loop
+ * trainers/efficientnet.py:333-352), the raw-output + consumer-prologue chain of the training form:
+ *   dfd_pwconv_fwd_eval : out = act(scale*(a @ w^T) + shift)               (the expand 1x1 convolution + bn1 + SiLU)
+ *   dfd_dwconv_fwd_eval : y = act(scale*dwconv(x) + shift), and pool_parts[tile][N][C] = per-(tile, image) channel sums
+ *                         of y as stored — the squeeze-excite pooling pass disappears
+ *   dfd_se_fwd_parts    : dfd_se_fwd from those sums (mean = sum over tiles / HW)
+ * out_bnstate: float[>=2][C] scale, shift (dfd_bn_eval_coeffs*).  out_act: DFD_ACT_SILU (the EfficientNet blocks);
+ * anything else returns DFD_EUNSUPPORTED.  Values equal the training-form chain bit for bit except the pooled mean
+ * (same addends, summed tile by tile instead of split by split).
+ * dfd_dwconv_fwd_eval_tiles: rows of pool_parts the call will write (0 = invalid shape); ntiles returns the same. */
+int dfd_pwconv_fwd_eval(int dtype, const void* a, const void* w, const float* out_bnstate, int out_act,
+                        void* out, int M, int K, int Nout, dfd_stream stream);
+int dfd_dwconv_fwd_eval_tiles(int dtype, const dfd_dwconv_shape* s);
+int dfd_dwconv_fwd_eval(int dtype, const void* x, const float* w, const float* out_bnstate, int out_act, void* y,
+                        const dfd_dwconv_shape* s, float* pool_parts, int* ntiles, dfd_stream stream);
+int dfd_se_fwd_parts(const float* parts, int splits, int N, int HW, int C, const float* w1, const float* b1,
+                     const float* w2, const float* b2, int R, int act, float* pooled, float* hpre, float* gate,
+                     float* w2t, dfd_stream stream);
 size_t dfd_dwconv_bwd_weight_ws(const dfd_dwconv_shape* s);
 
 /* ----------------------------------------------------------- pointwise conv ---
@@ -365,7 +390,7 @@ int dfd_bias_scatter(const float* dfull, const int* idx, float* dtable, int H, i
  * (zero padding in the activated domain); nothing is materialised.  w_nk [Cout][k*k*C] in the activation dtype, column
  * (kh*k + kw)*C + c (dfd_conv_weight_perm + dfd_pw_prep_weights).  C % 8 == 0, Cout % 8 == 0.  Output, partials and
  * nparts as dfd_pwconv_fwd.  Reference call sites: the 3x3 convolutions of timm's EfficientFormerV2 stem and of
- * NVlabs FasterViT's PatchEmbed / ConvBlock / Downsample, reached from trainers/*.py `model(x)`.                  */
+ * NVlabs FasterViT's PatchEmbed / ConvBlock / Downsample, reached from trainers/<model>.py `model(x)`.                  */
 int dfd_conv_fwd(int dtype, const void* x, const dfd_dwconv_shape* s, const float* in_bnstate, int in_act,
                  const void* w_nk, int Cout, void* y, float* partials, int pcap, int* nparts, dfd_stream stream);
 

@@ -334,3 +334,48 @@ def test_eval_batchnorm_coefficients_from_one_batched_launch_track_the_buffers()
         blk = m.block_list()[3]
         h = torch.randn(2, 12, 12, blk.plan.cin, device="cuda")
         assert torch.isfinite(blk(h)).all()               # standalone: per-layer path
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant,flavour", [("b0", "timm"), ("b3", "lukemelas")])
+def test_inference_form_of_the_blocks_matches_the_training_form_kernels(variant, flavour, monkeypatch):
+    """model.eval() without autograd runs the producer-side BatchNorm + activation chain (dfd_pwconv_fwd_eval,
+    dfd_dwconv_fwd_eval, dfd_se_fwd_parts); DFD_EVAL_FUSED=0 keeps the raw-output + consumer-prologue chain.  Same
+    per-stage arithmetic — only the squeeze-excite mean is added in another (fixed) order."""
+    ref, hip = make_pair(variant, flavour, 2, seed=11)
+    warm_running_stats(ref, 96)
+    hip.load_state_dict(ref.state_dict())
+    hip = hip.cuda().eval()
+    x = torch.randn(6, 3, 128, 128, generator=torch.Generator().manual_seed(4)).cuda().to(memory_format=torch.channels_last)
+    from deepfakedetection_amd import kernels
+
+    calls = []
+    real = kernels.dwconv_eval
+    monkeypatch.setattr(kernels, "dwconv_eval", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+    out = {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("DFD_EVAL_FUSED", flag)
+        calls.clear()
+        with torch.inference_mode():
+            f32 = hip(x)
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                b16 = hip(x)
+            again = hip(x)
+        assert torch.equal(f32, again)
+        assert len(calls) == (0 if flag == "0" else 3 * len(hip.block_list())), (flag, len(calls))    # the form that was asked for ran
+        out[flag] = (f32.float().cpu(), b16.float().cpu())
+    assert rel_err(out["1"][0], out["0"][0]) <= 1e-5, rel_err(out["1"][0], out["0"][0])
+    assert rel_err(out["1"][1], out["0"][1]) <= 2e-2, rel_err(out["1"][1], out["0"][1])
+    ref.eval()
+    with torch.no_grad():
+        want = ref(x.cpu().contiguous())
+    assert rel_err(out["1"][0], want) <= 1e-3
+    # with autograd on (fine-tuning a frozen, eval-mode backbone) the training-form chain still runs and keeps its tensors
+    monkeypatch.setenv("DFD_EVAL_FUSED", "1")
+    calls.clear()
+    y = hip(x)
+    assert not calls
+    y.sum().backward()
+    grads = [p.grad for p in hip.parameters() if p.grad is not None]
+    assert grads and all(torch.isfinite(g).all() for g in grads)
+    assert rel_err(y, out["0"][0]) <= 1e-6

@@ -597,3 +597,61 @@ def test_batched_partial_sums_are_the_unbatched_ones():
     assert K._L().dfd_sum_batch_end() != 0                   # nothing open
     again = K.pwconv_wgrad(*ops[1][:1], None, ops[1][1], None)
     assert torch.equal(again, want[1])                       # the unbatched path is untouched afterwards
+
+
+# ---- eval / inference form of the MBConv block: the producer applies its own BatchNorm + activation
+@pytest.mark.parametrize("rd", DT)
+@pytest.mark.parametrize("case", DW_CASES + [(4, 112, 112, 32, 3, 1, 1, 1), (3, 28, 28, 240, 5, 2, 1, 1)])
+def test_dwconv_eval_form(case, rd):
+    K = _k()
+    N, H, W, C, k, s, pt, pl = case
+    Ho, Wo = -(-H // s), -(-W // s)
+    x = gen((N, H, W, C), 1, rd)
+    w = gen((C, 1, k, k), 2, torch.float32, 0.3)
+    st = rand_state(C, 3)
+    # oracle: raw convolution rounded to the activation dtype, then act(scale*y+shift) rounded again
+    raw = R.dwconv_fwd(x.float(), None, R.ACT_NONE, w, k, s, pt, pl, Ho, Wo, rd)
+    want = R.rnd(R.act_fwd(raw.float() * st[0] + st[1], R.ACT_SILU), rd)
+    a, parts, tiles = K.dwconv_eval(dev(x), dev(w), dev(st), R.ACT_SILU, k, s, pt, pl, Ho, Wo)
+    close(a, want, tol(rd), "dwconv_eval a")
+    # the training-form kernels on the same input: identical bits
+    y, _, _ = K.dwconv_fwd(dev(x), None, R.ACT_NONE, dev(w), k, s, pt, pl, Ho, Wo, stats=False)
+    a_ref = K.bn_act_apply(y, dev(st), R.ACT_SILU)
+    assert torch.equal(a, a_ref), "eval-form depthwise output differs from dwconv_fwd + bn_act_apply"
+    # channel sums of the stored tensor, one row per (tile, image)
+    assert parts.shape == (tiles, N, C)
+    got = parts.double().sum(0).cpu()
+    ref = a.double().sum((1, 2)).cpu()
+    assert float((got - ref).abs().max()) <= 1e-5 * max(float(ref.abs().max()), 1.0) * (1 if rd == torch.float32 else 1)
+
+
+@pytest.mark.parametrize("rd", DT)
+@pytest.mark.parametrize("case", [(2 * 112 * 112, 16, 96), (3 * 56 * 56, 24, 144), (5 * 14 * 14, 80, 480), (7 * 7 * 7, 192, 1152),
+                                  (64 * 112 * 112, 16, 96), (64 * 28 * 28, 40, 240)])
+def test_pwconv_eval_form(case, rd):
+    K = _k()
+    M, Kd, Nout = case
+    a = dev(gen((1, 1, M, Kd), 5, rd))
+    w = dev(gen((Nout, Kd), 6, rd, 0.2))
+    st = dev(rand_state(Nout, 7))
+    got = K.pwconv_eval(a, w, st, R.ACT_SILU)
+    y, _, _ = K.pwconv(a, None, w, None, stats=False)
+    ref = K.bn_act_apply(y, st, R.ACT_SILU)
+    assert torch.equal(got, ref), "eval-form 1x1 convolution differs from pwconv + bn_act_apply"
+    if M <= 5 * 14 * 14:
+        want = R.rnd(R.act_fwd(R.rnd(a.float().cpu() @ w.float().cpu().T, rd).float() * st[0].cpu() + st[1].cpu(), R.ACT_SILU), rd)
+        close(got, want, tol(rd), "pwconv_eval")
+
+
+@pytest.mark.parametrize("case", [(3, 56 * 56, 96, 4, 5), (5, 49, 1152, 48, 1), (2, 112 * 112, 32, 8, 16)])
+def test_se_from_tile_sums(case):
+    K = _k()
+    N, HW, C, Rr, tiles = case
+    parts = dev(gen((tiles, N, C), 1, torch.float32, 3.0))
+    w1, b1 = dev(gen((Rr, C), 2, torch.float32, 0.1)), dev(gen((Rr,), 3, torch.float32, 0.1))
+    w2, b2 = dev(gen((C, Rr), 4, torch.float32, 0.1)), dev(gen((C,), 5, torch.float32, 0.1))
+    pooled, gate, _ = K.se_fwd_parts(parts, HW, w1, b1, w2, b2, R.ACT_SILU)
+    want_pooled = (parts.double().sum(0) / HW).float().cpu()
+    close(pooled, want_pooled, 1e-6, "pooled")
+    _, want_gate = R.se_fc(want_pooled, w1.cpu(), b1.cpu(), w2.cpu(), b2.cpu(), R.ACT_SILU)
+    close(gate, want_gate, 1e-5, "gate")
