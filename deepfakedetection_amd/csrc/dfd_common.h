@@ -196,4 +196,6 @@ __device__ __forceinline__ void reduce_rowlanes(float (&acc)[NV], float* red, in
     }
 
 // sums P partial rows of L floats; the buffer needs room for P + ceil(P/32) rows (two-stage reduction)
-int dfd_launch_sum_partials(float* partials, int P, long L, float* out, int accumulate, hipStream_t st);
+// deferrable: inside dfd_sum_batch_begin/_end the sum is recorded and launched with the batch (weight gradients);
+// false: launched now, the next launch may read `out`
+int dfd_launch_sum_partials(float* partials, int P, long L, float* out, int accumulate, hipStream_t st, bool deferrable = true);

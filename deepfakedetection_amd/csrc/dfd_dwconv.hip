@@ -100,8 +100,8 @@ extern "C" int dfd_sum_batch_end(void) {
 }
 
 // `partials` must have room for P + ceil(P / SUM_GROUP) rows of L floats.
-int dfd_launch_sum_partials(float* partials, int P, long L, float* out, int accumulate, hipStream_t st) {
-    if (tl_batch.on) {
+int dfd_launch_sum_partials(float* partials, int P, long L, float* out, int accumulate, hipStream_t st, bool deferrable) {
+    if (tl_batch.on && deferrable) {
         SumJobs& J = tl_batch.j;
         if (J.n == SUM_MAX_JOBS || (J.n > 0 && st != tl_batch.st)) {
             const int rc = sum_batch_flush();

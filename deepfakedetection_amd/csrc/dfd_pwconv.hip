@@ -912,7 +912,8 @@ static int conv_tn_t(const void* p, const dfd_prologue* pro_p, int Cout, const v
     }
 #undef LAUNCH_CTN
     if (hipGetLastError() != hipSuccess) return DFD_ELAUNCH;
-    return dfd_launch_sum_partials(ws, splits, (long)Ni * Nj, dw, accumulate, st);
+    // dw is in GEMM layout: the caller's dfd_conv_weight_perm reads it next, so the sum is not left to an open batch
+    return dfd_launch_sum_partials(ws, splits, (long)Ni * Nj, dw, accumulate, st, false);
 }
 
 extern "C" size_t dfd_conv_wgrad_ws(const dfd_dwconv_shape* s, int Cout) {

@@ -326,7 +326,8 @@ extern "C" int dfd_channel_stats(int dtype, const void* x, long rows, int C, flo
 
 extern "C" int dfd_sum_rows(float* partials, int P, long L, float* out, int accumulate, dfd_stream stream) {
     if (!partials || !out || P < 1 || L < 1) return DFD_EINVAL;
-    return dfd_launch_sum_partials(partials, P, L, out, accumulate, (hipStream_t)stream);
+    // the caller's next launch may read `out`: never left to an open batch
+    return dfd_launch_sum_partials(partials, P, L, out, accumulate, (hipStream_t)stream, false);
 }
 
 // ===========================================================================
@@ -1361,7 +1362,7 @@ extern "C" int dfd_rowtable_grad(int dtype, const void* g, float* dtable, long r
     if (dtype == DFD_BF16) hipLaunchKernelGGL((k_rowtable_grad<bf16>), grid, dim3(DFD_THREADS), 0, st, (const bf16*)g, ws, nw, T, C, cm, w_per);
     else hipLaunchKernelGGL((k_rowtable_grad<float>), grid, dim3(DFD_THREADS), 0, st, (const float*)g, ws, nw, T, C, cm, w_per);
     if (hipGetLastError() != hipSuccess) return DFD_ELAUNCH;
-    return dfd_launch_sum_partials(ws, splits, (long)T * C, dtable, accumulate, st);
+    return dfd_launch_sum_partials(ws, splits, (long)T * C, dtable, accumulate, st, false);   // consumed by the table's MLP backward
 }
 
 // average pooling k x k, stride s, no padding (TokenInitializer's AvgPool2d(5, 3)) and its gradient

@@ -20,7 +20,7 @@ from torch import nn
 from ._lib import ACT_RELU
 from .efficientnet import compute_dtype
 from .fastervit_functions import (AttnSpec, ConvBlockCtx, ConvBlockFunction, FVDownsampleFunction, HATCtx, HATFunction,
-                                  TokenInitFunction)
+                                  TokenInitFunction, derived_weights)
 from .functions import BNRef, bn_eval_batch
 from .vit_functions import ConvStemCtx, ConvStemFunction, DenseConvBNFunction, DenseConvCtx, TailCtx, TailFunction
 
@@ -350,8 +350,24 @@ class HipFasterViT(nn.Module):
             raise RuntimeError("HipFasterViT runs on a HIP device only (no CPU fallback); move the input with .to('cuda')")
         # the coefficient blocks of every eval-mode BatchNorm and of every Linear's identity statistics (bias, LayerScale):
         # one batched launch per pass instead of ~70 small ones
-        with bn_eval_batch(self.__dict__, (self.training, compute_dtype())):
+        with bn_eval_batch(self.__dict__, (self.training, compute_dtype())), derived_weights(self._derived_weights(compute_dtype())):
             return self._forward(x)
+
+    def _derived_weights(self, dt: torch.dtype) -> dict:
+        """{weight.data_ptr(): (w_nk, w_kn)} for the qkv / proj / fc1 / fc2 Linear of every attention block, refreshed by ONE
+        batched launch per forward pass (kernels.DerivedWeights); one cache entry per activation dtype, never freed (a
+        captured hipGraph holds raw pointers into it)."""
+        from . import kernels as K
+
+        weights = [lin.weight for m in self.modules() if isinstance(m, (WindowAttention, Mlp))
+                   for lin in ((m.qkv, m.proj) if isinstance(m, WindowAttention) else (m.fc1, m.fc2))]
+        caches = self.__dict__.setdefault("_derived_caches", {})
+        cache = caches.get(dt)
+        if cache is None or not cache.valid_for(weights, dt):
+            with torch.inference_mode(False):
+                cache = caches[dt] = K.DerivedWeights([(w, True, True, False) for w in weights], dt)
+        cache.refresh()
+        return {w.data_ptr(): pair for w, pair in zip(weights, cache.out)}
 
     def _forward(self, x: torch.Tensor) -> torch.Tensor:
         if x.shape[2] != self.resolution or x.shape[3] != self.resolution:

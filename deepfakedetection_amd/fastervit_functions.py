@@ -18,6 +18,8 @@ oracle/fastervit_ref.py).
 
 from __future__ import annotations
 
+import contextlib
+import threading
 from dataclasses import dataclass
 
 import torch
@@ -80,6 +82,30 @@ def coord_mlp_bwd(dtab, coords, w0, b0, w2, saved, need):
 
 
 # =========================================================================== attention / MLP sub-blocks on [n, T, C]
+_derived_tls = threading.local()
+
+
+@contextlib.contextmanager
+def derived_weights(table: dict | None):
+    """Inside the block `_prep` serves the (w_nk, w_kn) pairs of `table` ({weight.data_ptr(): pair}, refreshed for the whole
+    network by ONE batched launch per forward pass — kernels.DerivedWeights) instead of one small launch per Linear."""
+    prev = getattr(_derived_tls, "table", None)
+    _derived_tls.table = table
+    try:
+        yield
+    finally:
+        _derived_tls.table = prev
+
+
+def _prep(w: torch.Tensor, dt: torch.dtype):
+    table = getattr(_derived_tls, "table", None)
+    if table is not None:
+        hit = table.get(w.data_ptr())
+        if hit is not None and hit[0].dtype == dt:
+            return hit
+    return K.prep_weights(w, dt, True, True)
+
+
 @dataclass
 class AttnSpec:
     heads: int
@@ -97,7 +123,7 @@ def attn_sub_fwd(x, P, spec: AttnSpec, ls, row_scale):
     hd = C // H
     dt = x.dtype
     xn, lnst = K.layernorm_fwd(x, P["ln_w"], P["ln_b"], 1e-5)
-    wq_nk, wq_kn = K.prep_weights(P["qkv_w"], dt, True, True)
+    wq_nk, wq_kn = _prep(P["qkv_w"], dt)
     qkv, yq, stq = lin_fwd(xn, wq_nk, P["qkv_b"])
     table, mlp_saved = coord_mlp_fwd(spec.coords2d, P["cpb_w0"], P["cpb_b0"], P["cpb_w2"])
     bias_full = K.relpos_bias_fwd(table, spec.idx, spec.n_local, spec.n_global)
@@ -108,7 +134,7 @@ def attn_sub_fwd(x, P, spec: AttnSpec, ls, row_scale):
     Pm, _ = K.attn_softmax_fwd(S, None)
     O = torch.empty((n, T, 1, C), dtype=dt, device=x.device)
     K.bgemm(Pm, (H * T * T, T * T, T, 1), v, (T * 3 * C, hd, 3 * C, 1), O, (T * C, hd, C, 1), n, H, T, hd, T)
-    wp_nk, wp_kn = K.prep_weights(P["proj_w"], dt, True, True)
+    wp_nk, wp_kn = _prep(P["proj_w"], dt)
     out, yp, stp = lin_fwd(O, wp_nk, P["proj_b"], ACT_NONE, ls, x, row_scale)
     return out, (x, xn, lnst, qkv, yq, stq, table, mlp_saved, Pm, O, yp, stp, wq_kn, wp_kn)
 
@@ -175,12 +201,12 @@ def mlp_sub_fwd(x, P, ls, row_scale):
     """x + [rs *] [ls *] fc2(GELU(fc1(LN(x)))).  P: ln_w, ln_b, fc1_w, fc1_b, fc2_w, fc2_b."""
     dt = x.dtype
     xn, lnst = K.layernorm_fwd(x, P["ln_w"], P["ln_b"], 1e-5)
-    w1_nk, w1_kn = K.prep_weights(P["fc1_w"], dt, True, True)
+    w1_nk, w1_kn = _prep(P["fc1_w"], dt)
     h, _, _ = K.pwconv(xn, None, w1_nk, None, stats=False)
     hid = P["fc1_w"].shape[0]
     ones, ref = ident(x.device, hid)
     st1 = _bn_state(None, 0, _rows(h), ref, ones, P["fc1_b"], False)
-    w2_nk, w2_kn = K.prep_weights(P["fc2_w"], dt, True, True)
+    w2_nk, w2_kn = _prep(P["fc2_w"], dt)
     y2, _, _ = K.pwconv(h, K.pro_bn_act(st1, ACT_GELU), w2_nk, None, stats=False)
     C = P["fc2_w"].shape[0]
     ones2, ref2 = ident(x.device, C)
@@ -307,6 +333,7 @@ class HATFunction(torch.autograd.Function):
         return x_out, ct_out
 
     @staticmethod
+    @K.batched_sums
     def backward(ctx, gx, gct):
         cfg: HATCtx = ctx.cfg
         names, T = ctx.names, ctx.T
@@ -417,6 +444,7 @@ class ConvBlockFunction(torch.autograd.Function):
         return out
 
     @staticmethod
+    @K.batched_sums
     def backward(ctx, g):
         cfg: ConvBlockCtx = ctx.cfg
         x, y1, y2, st1, st2, w1_kn, w2_kn, w1, b1, g1, be1, w2, b2, g2, be2, gamma, row_scale = ctx.saved_tensors
@@ -473,6 +501,7 @@ class FVDownsampleFunction(torch.autograd.Function):
         return y
 
     @staticmethod
+    @K.batched_sums
     def backward(ctx, g):
         x, xn, lnst, w_kn, ln_w, ln_b, w = ctx.saved_tensors
         need = ctx.needs_input_grad
@@ -507,6 +536,7 @@ class TokenInitFunction(torch.autograd.Function):
         return out.view(N, p.shape[1] * p.shape[2], 1, C)
 
     @staticmethod
+    @K.batched_sums
     def backward(ctx, g):
         x, w, b = ctx.saved_tensors
         kernel, stride, yshape = ctx.geom

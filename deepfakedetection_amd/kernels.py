@@ -9,6 +9,7 @@ is no fallback: a CPU tensor or a missing library raises.
 from __future__ import annotations
 
 import contextlib
+import functools
 import ctypes
 import threading
 from dataclasses import dataclass
@@ -157,6 +158,15 @@ def sum_batch():
         rc = _L().dfd_sum_batch_end()
         _sum_batch.keep.clear()
         check(rc, "dfd_sum_batch_end")
+
+
+def batched_sums(fn):
+    """Decorator for a block's `backward`: runs it inside sum_batch()."""
+    @functools.wraps(fn)
+    def wrapper(*args, **kwargs):
+        with sum_batch():
+            return fn(*args, **kwargs)
+    return wrapper
 
 
 def _nbytes(t: torch.Tensor | None) -> int:

@@ -255,6 +255,7 @@ class ConvStemFunction(torch.autograd.Function):
         return out
 
     @staticmethod
+    @K.batched_sums
     def backward(ctx, g):
         cfg: ConvStemCtx = ctx.cfg
         x, y, st, weight, bias, gamma, beta = ctx.saved_tensors
@@ -328,6 +329,7 @@ class DenseConvBNFunction(torch.autograd.Function):
         return out
 
     @staticmethod
+    @K.batched_sums
     def backward(ctx, g):
         cfg: DenseConvCtx = ctx.cfg
         x, y, st, wg_kn, weight, bias, gamma, beta = ctx.saved_tensors
@@ -492,6 +494,7 @@ class AttentionFunction(torch.autograd.Function):
         return out
 
     @staticmethod
+    @K.batched_sums
     def backward(ctx, g):
         cfg: AttentionCtx = ctx.cfg
         sv = ctx.saved_tensors
@@ -635,6 +638,7 @@ class DownsampleFunction(torch.autograd.Function):
         return out
 
     @staticmethod
+    @K.batched_sums
     def backward(ctx, g):
         cfg: DownsampleCtx = ctx.cfg
         sv = ctx.saved_tensors
@@ -740,6 +744,7 @@ class TailFunction(torch.autograd.Function):
         return logits
 
     @staticmethod
+    @K.batched_sums
     def backward(ctx, dlogits):
         cfg: TailCtx = ctx.cfg
         x, st, feat, gamma, beta, w_h, b_h, w_d, b_d, drop_u = ctx.saved_tensors

@@ -73,9 +73,10 @@ typedef void* dfd_stream;          /* a hipStream_t */
  * dfd_se_fwd_parts. */
 int dfd_version(void);
 
-/* Batched final summation of weight gradients.  Every weight-gradient entry point (dfd_pwconv_wgrad,
- * dfd_dwconv_bwd_weight, dfd_conv_wgrad, dfd_stem_conv_wgrad, ...) ends with a fixed-order sum of its workspace's
- * partial rows into dw.  Between dfd_sum_batch_begin() and dfd_sum_batch_end() ON THE CALLING HOST THREAD these sums are
+/* Batched final summation of weight gradients.  The weight-gradient entry points whose result goes straight to the
+ * optimizer (dfd_pwconv_wgrad, dfd_dwconv_bwd_weight, dfd_stem_conv_wgrad) end with a fixed-order sum of their workspace's
+ * partial rows into dw.  (dfd_conv_wgrad, dfd_rowtable_grad and dfd_sum_rows always sum at once: their callers' next
+ * launch reads the result.)  Between dfd_sum_batch_begin() and dfd_sum_batch_end() ON THE CALLING HOST THREAD these sums are
  * recorded instead of launched, and _end() (or the ninth recorded sum) adds them all up with one pair of launches —
  * same order, same bits.  Contract while a batch is open: each call gets its OWN workspace, which must stay untouched
  * until _end(); dw is valid only after _end(); all calls use one stream.  The state is thread-local: other threads are
