@@ -36,6 +36,11 @@ k_pw_tnw(const bf16* __restrict__ a, ProArgs pa, int Na, const bf16* __restrict_
     const bf16* a2 = reinterpret_cast<const bf16*>(pa.a2);
     const bf16* b2 = reinterpret_cast<const bf16*>(pb.a2);
     const int ca = Na >> 3, cb = Nb >> 3;                       // 16-byte chunks per row
+    // PB = BN_ACT_GATE: this wave's copy of the squeeze-excite gate rows of images gimg and gimg + 1 (a step of ROWS <= HW
+    // rows touches no other).  Read from global memory inside the prologue, every item waited on vmcnt(0) for its own gate
+    // values — in-order completion also drains the next step's row loads — i.e. one memory round trip per item.
+    float* gc = cl + 3 * (Na + Nb) + wave * 2 * Nb;
+    int gimg = -1;
 
     for (int i = t; i < 3 * Na; i += DFD_THREADS) cl[i] = (PA != DFD_PRO_NONE) ? pa.coef[i] : 0.f;
     for (int i = t; i < 3 * Nb; i += DFD_THREADS) {
@@ -78,28 +83,33 @@ k_pw_tnw(const bf16* __restrict__ a, ProArgs pa, int Na, const bf16* __restrict_
     int mend = mbeg + rows_per_wave;
     if (mend > M) mend = M;
 
+    // One register set for the rows in flight (the accumulators take the rest of the 128-register budget).  An item's
+    // registers are refilled with the NEXT step's row as soon as this step's prologue has consumed them (s_store_*), so
+    // that every load has the rest of the prologue arithmetic and the MFMA phase to land — requested in one batch after
+    // the stores, the loads had only the MFMA phase (a few hundred cycles against ~2 us of latency).
     uint4 va[ITA], va2[ITA], vb[ITB], vb2[ITB];
+    // Loads are UNCONDITIONAL (row and chunk clamped into the operand; what an absent item or a row past the wave's
+    // range loads is never stored): with a load inside a divergent branch the compiler cannot count the loads in flight
+    // and falls back to s_waitcnt vmcnt(0) in front of every item, which serialises one memory round trip per item.
+    auto load_a = [&](int i, int m0) {
+        int row = m0 + (ra[i] < 0 ? 0 : ra[i]);
+        row = row < M ? row : M - 1;
+        const long off = (long)row * Na + cha[i] * 8;
+        va[i] = *reinterpret_cast<const uint4*>(a + off);
+        if constexpr (PA == DFD_PRO_AFFINE2) va2[i] = *reinterpret_cast<const uint4*>(a2 + off);
+    };
+    auto load_b = [&](int i, int m0) {
+        int row = m0 + (rb[i] < 0 ? 0 : rb[i]);
+        row = row < M ? row : M - 1;
+        const long off = (long)row * Nb + chb[i] * 8;
+        vb[i] = *reinterpret_cast<const uint4*>(b + off);
+        if constexpr (PB == DFD_PRO_AFFINE2) vb2[i] = *reinterpret_cast<const uint4*>(b2 + off);
+    };
     auto g_load = [&](int m0) {
 #pragma unroll
-        for (int i = 0; i < ITA; ++i) {
-            va[i] = make_uint4(0, 0, 0, 0);
-            if (PA == DFD_PRO_AFFINE2) va2[i] = make_uint4(0, 0, 0, 0);
-            if (ra[i] >= 0 && m0 + ra[i] < mend) {
-                const long off = (long)(m0 + ra[i]) * Na + cha[i] * 8;
-                va[i] = *reinterpret_cast<const uint4*>(a + off);
-                if constexpr (PA == DFD_PRO_AFFINE2) va2[i] = *reinterpret_cast<const uint4*>(a2 + off);
-            }
-        }
+        for (int i = 0; i < ITA; ++i) load_a(i, m0);
 #pragma unroll
-        for (int i = 0; i < ITB; ++i) {
-            vb[i] = make_uint4(0, 0, 0, 0);
-            if (PB == DFD_PRO_AFFINE2) vb2[i] = make_uint4(0, 0, 0, 0);
-            if (rb[i] >= 0 && m0 + rb[i] < mend) {
-                const long off = (long)(m0 + rb[i]) * Nb + chb[i] * 8;
-                vb[i] = *reinterpret_cast<const uint4*>(b + off);
-                if constexpr (PB == DFD_PRO_AFFINE2) vb2[i] = *reinterpret_cast<const uint4*>(b2 + off);
-            }
-        }
+        for (int i = 0; i < ITB; ++i) load_b(i, m0);
     };
     // one operand item through its prologue
     auto pro_item = [&](auto mode_tag, uint4 q, uint4 q2, const float* cf, int N, int ch, int m, const ProArgs& pr) -> uint4 {
@@ -123,7 +133,7 @@ k_pw_tnw(const bf16* __restrict__ a, ProArgs pa, int Na, const bf16* __restrict_
                 for (int j = 0; j < 8; ++j) v[j] = act_fwd<ACT>(fmaf(c0[j], v[j], c1[j]));
             } else {
                 float gt[8];
-                load_f32<8>(pr.gate + (long)pro_image(pr, m) * N + ch * 8, gt);
+                load_f32<8>(gc + (pro_image(pr, m) - gimg) * N + ch * 8, gt);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) v[j] = round_to<bf16>(act_fwd<ACT>(fmaf(c0[j], v[j], c1[j]))) * gt[j];
             }
@@ -134,21 +144,26 @@ k_pw_tnw(const bf16* __restrict__ a, ProArgs pa, int Na, const bf16* __restrict_
     auto s_store_a = [&](int m0) {
 #pragma unroll
         for (int i = 0; i < ITA; ++i) {
-            if (ra[i] < 0) continue;
-            uint4 v = va[i];
-            if (PA != DFD_PRO_NONE && m0 + ra[i] < mend)
-                v = pro_item(std::integral_constant<int, PA>{}, va[i], va2[i], cl, Na, cha[i], m0 + ra[i], pa);
-            *reinterpret_cast<uint4*>(at + tn_off_bf16(ra[i], cha[i])) = v;
+            if (ra[i] >= 0) {                                   // arithmetic and LDS only inside the branch
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (m0 + ra[i] < mend) v = pro_item(std::integral_constant<int, PA>{}, va[i], va2[i], cl, Na, cha[i], m0 + ra[i], pa);
+                *reinterpret_cast<uint4*>(at + tn_off_bf16(ra[i], cha[i])) = v;
+            }
+            load_a(i, m0 + ROWS);
         }
     };
-    auto s_store_b = [&](int m0, int grp) {
+    // refill: this call is the last one that consumes B items of the step (the second column group when there are two)
+    auto s_store_b = [&](int m0, int grp, auto refill_tag) {
+        constexpr bool refill = decltype(refill_tag)::value;
 #pragma unroll
         for (int i = 0; i < ITB; ++i) {
-            if (rb[i] < 0 || (chb[i] >> 4) != grp) continue;
-            uint4 v = vb[i];
-            if (PB != DFD_PRO_NONE && m0 + rb[i] < mend)
-                v = pro_item(std::integral_constant<int, PB>{}, vb[i], vb2[i], cl + 3 * Na, Nb, chb[i], m0 + rb[i], pb);
-            *reinterpret_cast<uint4*>(bt + tn_off_bf16(rb[i], chb[i] & 15)) = v;
+            if (rb[i] >= 0 && (chb[i] >> 4) == grp) {
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (m0 + rb[i] < mend)
+                    v = pro_item(std::integral_constant<int, PB>{}, vb[i], vb2[i], cl + 3 * Na, Nb, chb[i], m0 + rb[i], pb);
+                *reinterpret_cast<uint4*>(bt + tn_off_bf16(rb[i], chb[i] & 15)) = v;
+            }
+            if constexpr (refill) load_b(i, m0 + ROWS);
         }
     };
     auto wave_sync = [&]() {
@@ -182,23 +197,32 @@ k_pw_tnw(const bf16* __restrict__ a, ProArgs pa, int Na, const bf16* __restrict_
         }
     };
 
-    const int ngrp = (cb + 15) >> 4;
+    constexpr int NGRP = NBT > 8 ? 2 : 1;               // column groups of 128 channels the B tile is walked in
     if (mbeg < mend) g_load(mbeg);
     for (int m0 = mbeg; m0 < mend; m0 += ROWS) {
         short8_t fa[NA];
+        if constexpr (PB == DFD_PRO_BN_ACT_GATE) {
+            const int img0 = pro_image(pb, m0);                 // wave-uniform
+            if (img0 != gimg) {
+                gimg = img0;
+                for (int i = lane; i < 2 * Nb; i += 64) {
+                    const int im = img0 + (i >= Nb ? 1 : 0);
+                    gc[i] = ((long)im * pb.HW < M) ? pb.gate[(long)im * Nb + (i >= Nb ? i - Nb : i)] : 0.f;
+                }
+                wave_sync();
+            }
+        }
         s_store_a(m0);
-        s_store_b(m0, 0);
-        // group 1 (channels 128..) still sits in vb/vb2; it needs the B tile after group 0's reads
-        if (ngrp == 1 && m0 + ROWS < mend) g_load(m0 + ROWS);
+        s_store_b(m0, 0, std::integral_constant<bool, NGRP == 1>{});
         wave_sync();
 #pragma unroll
         for (int x = 0; x < NA; ++x)
             if (x < na) fa[x] = frag(at, 2 * x);
-        for (int grp = 0; grp < ngrp; ++grp) {
+#pragma unroll
+        for (int grp = 0; grp < NGRP; ++grp) {
             if (grp > 0) {
                 wave_sync();                            // group grp-1's fragment reads are done
-                s_store_b(m0, grp);
-                if (grp == ngrp - 1 && m0 + ROWS < mend) g_load(m0 + ROWS);
+                s_store_b(m0, grp, std::true_type{});   // (NGRP == 2: the last group)
                 wave_sync();
             }
 #pragma unroll
@@ -266,7 +290,9 @@ static int tnw_launch(const void* a, const dfd_prologue* pro_a, int Na, const vo
     rpb = (rpb + 4 * ROWS - 1) / (4 * ROWS) * (4 * ROWS);
     nblocks = (M + rpb - 1) / rpb;
     if ((size_t)(nblocks + nblocks / 32 + 2) * Na * Nb * 4 > ws_bytes) return DFD_EUNSUPPORTED;
-    const int lds = 4 * 2 * ROWS * 256 + 3 * (Na + Nb) * 4;
+    const bool gated = mb == DFD_PRO_BN_ACT_GATE;
+    if (gated && pb.HW < ROWS) return DFD_EUNSUPPORTED;           // a step must not span more than two images (gate cache)
+    const int lds = 4 * 2 * ROWS * 256 + 3 * (Na + Nb) * 4 + (gated ? 4 * 2 * Nb * 4 : 0);
 #define LAUNCH_TNW(PAV, PBV, ACTV)                                                                                     \
     hipLaunchKernelGGL((k_pw_tnw<ROWS, NA, NBT, PAV, PBV, ACTV>), dim3(nblocks), dim3(DFD_THREADS), lds, st, (const bf16*)a, pa, \
                        Na, (const bf16*)b, pb, Nb, M, rpb, swap, ws)
