@@ -116,24 +116,28 @@ k_pw_nt(const T* __restrict__ a, ProArgs pa, const T* __restrict__ w, T* __restr
                 }
             }
         } else {
+        // Unconditional loads from a row / chunk clamped into the operand; what does not belong to the tile is replaced by
+        // zeros at the LDS store (s_store).  With the loads inside divergent branches the compiler cannot count how many are
+        // in flight: it waited vmcnt(0) in front of the MFMAs of every K step, i.e. for the stage it had just requested,
+        // and the two-stage pipeline hid nothing.
+        const int cc = c < kc ? c : 0;
 #pragma unroll
         for (int i = 0; i < AI; ++i) {
             const int r = rb0 + i * rstep;
-            R.a[i] = make_uint4(0, 0, 0, 0);
-            if (PRO == DFD_PRO_AFFINE2) R.a2[i] = make_uint4(0, 0, 0, 0);
-            if (r < BM && c < kc && m0 + r < M) {
-                const long off = (long)(m0 + r) * K + k0 + c * E;
-                R.a[i] = *reinterpret_cast<const uint4*>(a + off);
-                if constexpr (PRO == DFD_PRO_AFFINE2) R.a2[i] = *reinterpret_cast<const uint4*>(a2 + off);
-            }
+            const int rr = r < BM ? r : rb0;                    // (narrow K tiles: 64 rows per pass, the tile has fewer passes)
+            const int m = m0 + rr < M ? m0 + rr : M - 1;
+            const long off = (long)m * K + k0 + cc * E;
+            R.a[i] = *reinterpret_cast<const uint4*>(a + off);
+            if constexpr (PRO == DFD_PRO_AFFINE2) R.a2[i] = *reinterpret_cast<const uint4*>(a2 + off);
         }
         }
         if (with_b) {
+            const int cc = c < kc ? c : 0;
 #pragma unroll
             for (int i = 0; i < BN / 32; ++i) {
                 const int r = rb0 + i * rstep;
-                R.b[i] = (r < BN && c < kc && n0 + r < Nout) ? *reinterpret_cast<const uint4*>(w + (long)(n0 + r) * K + k0 + c * E)
-                                                           : make_uint4(0, 0, 0, 0);
+                const int n = n0 + r < Nout ? n0 + r : Nout - 1;
+                R.b[i] = *reinterpret_cast<const uint4*>(w + (long)n * K + k0 + cc * E);
             }
         }
     };
@@ -162,8 +166,9 @@ k_pw_nt(const T* __restrict__ a, ProArgs pa, const T* __restrict__ w, T* __restr
         for (int i = 0; i < AI; ++i) {
             const int r = rb0 + i * rstep;
             if (r >= BM) continue;
-            uint4 q = R.a[i];
-            if (PRO != DFD_PRO_NONE && c < kc && m0 + r < M && (!CONV || ((R.ok >> i) & 1u))) {
+            const bool valid = c < kc && m0 + r < M && (!CONV || ((R.ok >> i) & 1u));
+            uint4 q = (CONV || valid) ? R.a[i] : make_uint4(0, 0, 0, 0);
+            if (PRO != DFD_PRO_NONE && valid) {
                 const float* gk = nullptr;
                 if constexpr (PRO == DFD_PRO_BN_ACT_GATE) gk = pa.gate + (long)pro_image(pa, m0 + r) * K + k0 + c * E;
                 q = apply_pro_c<T, PRO, ACT, E>(R.a[i], R.a2[i], c0, c1, c2, gk);
@@ -174,7 +179,8 @@ k_pw_nt(const T* __restrict__ a, ProArgs pa, const T* __restrict__ w, T* __restr
 #pragma unroll
             for (int i = 0; i < BN / 32; ++i) {
                 const int r = rb0 + i * rstep;
-                if (r < BN) *reinterpret_cast<uint4*>(bb + r * 128 + ((c ^ (r & 7)) << 4)) = R.b[i];
+                if (r < BN)
+                    *reinterpret_cast<uint4*>(bb + r * 128 + ((c ^ (r & 7)) << 4)) = (c < kc && n0 + r < Nout) ? R.b[i] : make_uint4(0, 0, 0, 0);
             }
         }
     };
@@ -254,27 +260,43 @@ k_pw_nt(const T* __restrict__ a, ProArgs pa, const T* __restrict__ w, T* __restr
                 if (n < Nout) {
                     float es[E], eh[E];
                     if constexpr (EACT >= 0) { load_f32<E>(ebn + n, es); load_f32<E>(ebn + Nout + n, eh); }
-#pragma unroll 4
-                    for (int r = er; r < BM; r += RL) {
-                        const int m = m0 + r;
-                        if (m >= M) break;
-                        float v[E];
-                        q_to_f(*reinterpret_cast<const uint4*>(smem + r * OROW + ec * 16), v);
-                        if constexpr (EACT >= 0) {
+                    // rows in groups of four: the group's residual vectors are requested together, before any of them is
+                    // used (one at a time, each load was waited for before the next row's was issued)
+                    constexpr int NR = (BM + RL - 1) / RL;
 #pragma unroll
-                            for (int j = 0; j < E; ++j) v[j] = round_to<T>(act_fwd<EACT>(fmaf(es[j], v[j], eh[j])));
-                        }
+                    for (int g0 = 0; g0 < NR; g0 += 4) {
+                        float rq[4][E];
                         if constexpr (RES) {
-                            float q[E];
-                            Vec<T>::load(res + (long)m * Nout + n, q);
 #pragma unroll
-                            for (int j = 0; j < E; ++j) v[j] = round_to<T>(v[j] + q[j]);
+                            for (int u = 0; u < 4; ++u) {
+                                if (g0 + u < NR) {
+                                    const int m = m0 + er + (g0 + u) * RL;
+                                    Vec<T>::load(res + (long)(m < M ? m : M - 1) * Nout + n, rq[u]);
+                                }
+                            }
                         }
-                        if constexpr (STATS) {
 #pragma unroll
-                            for (int j = 0; j < E; ++j) { s1[j] += v[j]; s2[j] = fmaf(v[j], v[j], s2[j]); }
+                        for (int u = 0; u < 4; ++u) {
+                            if (g0 + u >= NR) continue;
+                            const int r = er + (g0 + u) * RL;
+                            const int m = m0 + r;
+                            if (r >= BM || m >= M) continue;
+                            float v[E];
+                            q_to_f(*reinterpret_cast<const uint4*>(smem + r * OROW + ec * 16), v);
+                            if constexpr (EACT >= 0) {
+#pragma unroll
+                                for (int j = 0; j < E; ++j) v[j] = round_to<T>(act_fwd<EACT>(fmaf(es[j], v[j], eh[j])));
+                            }
+                            if constexpr (RES) {
+#pragma unroll
+                                for (int j = 0; j < E; ++j) v[j] = round_to<T>(v[j] + rq[u][j]);
+                            }
+                            if constexpr (STATS) {
+#pragma unroll
+                                for (int j = 0; j < E; ++j) { s1[j] += v[j]; s2[j] = fmaf(v[j], v[j], s2[j]); }
+                            }
+                            Vec<T>::store(out + (long)m * Nout + n, v);
                         }
-                        Vec<T>::store(out + (long)m * Nout + n, v);
                     }
                 }
                 __syncthreads();            // overlay reads done before the next stage lands in the A buffers
@@ -292,8 +314,10 @@ k_pw_nt(const T* __restrict__ a, ProArgs pa, const T* __restrict__ w, T* __restr
     auto step = [&](Regs& rfree, const Regs& rnext) -> bool {
         int mt2 = mt1, kt2 = kt1;
         advance(mt2, kt2);
-        if (mt1 < m_tiles && mt2 < m_tiles) g_load(rfree, mt2, kt2, next_b);
+        // coefficients first: they are consumed first (the next s_store), and a wait for the YOUNGEST load drains every
+        // older one — requested after the prefetch, they forced the stage just requested to land before the MFMAs
         if (mt1 < m_tiles) c_load(kt1);
+        if (mt1 < m_tiles && mt2 < m_tiles) g_load(rfree, mt2, kt2, next_b);
         compute(mt, kt, buf);
         if (mt1 >= m_tiles) return false;
         const int nbuf = (kt == nk - 1) ? 0 : (buf ^ 1);
