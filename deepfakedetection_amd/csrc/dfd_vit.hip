@@ -564,12 +564,27 @@ __device__ __forceinline__ void bg_stage(float* __restrict__ dst, int ld, const 
                                          int n_outer, int n_inner, bool transpose, int round) {
     // element (o, i) at base + o*s_outer + i*s_inner with i the fast (ideally unit-stride) index;
     // stored at dst[o*ld + i] (transpose == false) or dst[i*ld + o] (transpose == true)
+    // four outer rows per pass, their loads issued back to back from clamped (always valid) coordinates and only then
+    // used: one load at a time inside the bounds check, each was waited for (vmcnt(0)) before the next was requested
     const int li = threadIdx.x & 31, lo = threadIdx.x >> 5;
-    for (int o = lo; o < n_outer; o += DFD_THREADS / 32)
-        for (int i = li; i < n_inner; i += 32) {
-            float v = ElemIO<DT>::ld(src, base + o * s_outer + i * s_inner);
-            if (round) v = bf2f(f2bf(v));
-            dst[transpose ? i * ld + o : o * ld + i] = v;
+    constexpr int RS = DFD_THREADS / 32, U = 4;
+    for (int o0 = lo; o0 < n_outer; o0 += RS * U)
+        for (int i = li; i < ((n_inner + 31) & ~31); i += 32) {
+            const int ic = i < n_inner ? i : n_inner - 1;
+            float v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int o = o0 + u * RS;
+                v[u] = ElemIO<DT>::ld(src, base + (long)(o < n_outer ? o : n_outer - 1) * s_outer + ic * s_inner);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int o = o0 + u * RS;
+                if (o < n_outer && i < n_inner) {
+                    const float x = round ? bf2f(f2bf(v[u])) : v[u];
+                    dst[transpose ? i * ld + o : o * ld + i] = x;
+                }
+            }
         }
 }
 template <int DA, int DB, int DC>
@@ -613,6 +628,17 @@ k_bgemm(const void* __restrict__ A, MatDesc da, const void* __restrict__ B, MatD
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(a4[i], b4[j], acc[i][j]);
         }
+        // the tile's 16 bias values are requested together (clamped coordinates) before the first one is used
+        float bz[4][4];
+        if (bias) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int m = 4 * im + i < M ? 4 * im + i : M - 1, n = 4 * in + j < N ? 4 * in + j : N - 1;
+                    bz[i][j] = bias[((long)h * M + m) * N + n];
+                }
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int m = 4 * im + i;
@@ -622,7 +648,7 @@ k_bgemm(const void* __restrict__ A, MatDesc da, const void* __restrict__ B, MatD
                 const int n = 4 * in + j;
                 if (n >= N) continue;
                 float v = alpha * acc[i][j];
-                if (bias) v += bias[((long)h * M + m) * N + n];
+                if (bias) v += bz[i][j];
                 ElemIO<DC>::st(C, c0 + m * dc.sr + n * dc.sc, v);
             }
         }
