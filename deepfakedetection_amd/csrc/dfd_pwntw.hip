@@ -234,28 +234,43 @@ k_pw_ntw(const T* __restrict__ a, ProArgs pa, const T* __restrict__ w, T* __rest
             if (n < Nout) {
                 float es[E], eh[E];
                 if constexpr (EACT >= 0) { load_f32<E>(ebn + n, es); load_f32<E>(ebn + Nout + n, eh); }
+                // rows in groups of four: the group's residual vectors are requested together, from clamped rows, before any
+                // is used (inside the bounds check each load was waited for before the next row's was issued)
+                constexpr int NPS = WR / RL;
 #pragma unroll
-                for (int ps = 0; ps < WR / RL; ++ps) {
-                    const int r = er + ps * RL;
-                    const int m = mw + r;
-                    if (m < M) {
-                        float v[E];
-                        q_to_f(*reinterpret_cast<const uint4*>(eb + r * OROW + ec * 16), v);
-                        if constexpr (EACT >= 0) {
+                for (int g0 = 0; g0 < NPS; g0 += 4) {
+                    float rq[4][E];
+                    if constexpr (RES) {
 #pragma unroll
-                            for (int x = 0; x < E; ++x) v[x] = round_to<T>(act_fwd<EACT>(fmaf(es[x], v[x], eh[x])));
+                        for (int u = 0; u < 4; ++u) {
+                            if (g0 + u < NPS) {
+                                const int m = mw + er + (g0 + u) * RL;
+                                Vec<T>::load(res + (long)(m < M ? m : M - 1) * Nout + n, rq[u]);
+                            }
                         }
-                        if constexpr (RES) {
-                            float q[E];
-                            Vec<T>::load(res + (long)m * Nout + n, q);
+                    }
 #pragma unroll
-                            for (int x = 0; x < E; ++x) v[x] = round_to<T>(v[x] + q[x]);
-                        }
-                        if constexpr (STATS) {
+                    for (int u = 0; u < 4; ++u) {
+                        if (g0 + u >= NPS) continue;
+                        const int r = er + (g0 + u) * RL;
+                        const int m = mw + r;
+                        if (m < M) {
+                            float v[E];
+                            q_to_f(*reinterpret_cast<const uint4*>(eb + r * OROW + ec * 16), v);
+                            if constexpr (EACT >= 0) {
 #pragma unroll
-                            for (int x = 0; x < E; ++x) { t1[x] += v[x]; t2[x] = fmaf(v[x], v[x], t2[x]); }
+                                for (int x = 0; x < E; ++x) v[x] = round_to<T>(act_fwd<EACT>(fmaf(es[x], v[x], eh[x])));
+                            }
+                            if constexpr (RES) {
+#pragma unroll
+                                for (int x = 0; x < E; ++x) v[x] = round_to<T>(v[x] + rq[u][x]);
+                            }
+                            if constexpr (STATS) {
+#pragma unroll
+                                for (int x = 0; x < E; ++x) { t1[x] += v[x]; t2[x] = fmaf(v[x], v[x], t2[x]); }
+                            }
+                            Vec<T>::store(out + (long)m * Nout + n, v);
                         }
-                        Vec<T>::store(out + (long)m * Nout + n, v);
                     }
                 }
             }
