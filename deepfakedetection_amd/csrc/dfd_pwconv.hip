@@ -574,7 +574,10 @@ k_pw_tn(const T* __restrict__ p, ProArgs pp, int Ni, const T* __restrict__ q, Pr
                                                                                   __builtin_bit_cast(bf16x8_t, fb[b]), acc[a][b], 0, 0, 0);
                 }
             };
-            if (na == 4 && nb == 4) mfma_step(std::true_type{}); else mfma_step(std::false_type{});
+            // a wave with any valid tile runs all 16 MFMAs in straight-line code: tiles past Ni / Nj only feed accumulators
+            // that are never written out.  Guarding each MFMA (`a < na && b < nb`) put every one in its own basic block behind
+            // an lgkmcnt(0), i.e. one exposed LDS round trip per MFMA on every edge tile — most tiles of 80..192-wide outputs.
+            if (na > 0 && nb > 0) mfma_step(std::true_type{});
         } else {
             const int col = lane & 15, kq = lane >> 4;
 #pragma unroll
