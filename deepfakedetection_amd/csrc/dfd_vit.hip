@@ -566,6 +566,40 @@ __device__ __forceinline__ void bg_stage(float* __restrict__ dst, int ld, const 
     // stored at dst[o*ld + i] (transpose == false) or dst[i*ld + o] (transpose == true)
     // four outer rows per pass, their loads issued back to back from clamped (always valid) coordinates and only then
     // used: one load at a time inside the bounds check, each was waited for (vmcnt(0)) before the next was requested
+    if constexpr (DT == DFD_BF16) {
+        // unit-stride bf16 rows whose length and pitch are multiples of 8 (q, k, v, dO of the attention layers: head_dim
+        // contiguous): 16-byte loads, two items per thread in flight — 1/8 of the load instructions of the element path
+        const unsigned short* sp = reinterpret_cast<const unsigned short*>(src) + base;
+        if (s_inner == 1 && (n_inner & 7) == 0 && (s_outer & 7) == 0 && (reinterpret_cast<unsigned long>(sp) & 15) == 0) {
+            const int nv = n_inner >> 3, total = n_outer * nv;
+            for (int idx0 = threadIdx.x; idx0 < total; idx0 += 2 * DFD_THREADS) {
+                uint4 q[2];
+                int oo[2], iv[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int idx = idx0 + u * DFD_THREADS < total ? idx0 + u * DFD_THREADS : total - 1;
+                    oo[u] = idx / nv;
+                    iv[u] = idx - oo[u] * nv;
+                    q[u] = *reinterpret_cast<const uint4*>(sp + (long)oo[u] * s_outer + iv[u] * 8);
+                }
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    if (idx0 + u * DFD_THREADS >= total) continue;
+                    float v[8];
+                    Vec<bf16>::unpack(q[u], v);         // bf16 -> f32 is exact; `round` (to bf16) is the identity here
+                    if (!transpose) {
+                        float* d = dst + oo[u] * ld + iv[u] * 8;        // ld % 4 == 0: 16-byte aligned
+                        *reinterpret_cast<float4*>(d) = make_float4(v[0], v[1], v[2], v[3]);
+                        *reinterpret_cast<float4*>(d + 4) = make_float4(v[4], v[5], v[6], v[7]);
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) dst[(iv[u] * 8 + j) * ld + oo[u]] = v[j];
+                    }
+                }
+            }
+            return;
+        }
+    }
     const int li = threadIdx.x & 31, lo = threadIdx.x >> 5;
     constexpr int RS = DFD_THREADS / 32, U = 4;
     for (int o0 = lo; o0 < n_outer; o0 += RS * U)
