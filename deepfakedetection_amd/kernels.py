@@ -489,9 +489,10 @@ def identity_state(device: torch.device, C: int) -> torch.Tensor:
     key = (device.type, device.index, C)
     st = _identity_states.get(key)
     if st is None:
-        st = torch.zeros((4, C), dtype=torch.float32, device=device)
-        st[0].fill_(1.0)
-        st[3].fill_(1.0)
+        with torch.inference_mode(False):               # a plain tensor: the cache outlives the caller's inference_mode block
+            st = torch.zeros((4, C), dtype=torch.float32, device=device)
+            st[0].fill_(1.0)
+            st[3].fill_(1.0)
         if not (device.type == "cuda" and torch.cuda.is_current_stream_capturing()):
             _identity_states[key] = st          # a tensor born inside a capture belongs to that graph's pool: not cached
     return st
