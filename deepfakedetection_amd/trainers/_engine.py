@@ -82,9 +82,7 @@ def evaluate(model: nn.Module, dl: DataLoader, device: str, tail=None) -> EvalRe
     correct = torch.zeros((), dtype=torch.float64, device=device)
     total = 0
     with torch.inference_mode():
-        for batch_x, batch_y in dl:
-            inputs = _base._to_device(batch_x, device, tail)
-            targets = batch_y.to(device, non_blocking=True)
+        for inputs, targets in _base.device_batches(dl, device, tail):
             correct += (model(inputs).argmax(1) == targets).sum()
             total += targets.numel()
     n_correct, n_total = all_reduce_counts(float(correct), float(total), device=device)
@@ -103,9 +101,7 @@ def train_one_epoch(model: nn.Module, dl: DataLoader, opt: optim.Optimizer, scal
         opt.zero_grad(set_to_none=True)
     seen_total = pending = 0
     shown = float("nan")
-    for i, (batch_x, batch_y) in enumerate(dl, 1):
-        inputs = _base._to_device(batch_x, device, tail)
-        targets = batch_y.to(device, non_blocking=True)
+    for i, (inputs, targets) in enumerate(_base.device_batches(dl, device, tail, prefetch=stepper is not None), 1):
         if stepper is not None:
             # hipGraph replay of the same body; zero_grad belongs to the first micro-batch of a cycle either way
             loss = stepper.micro_batch(inputs, targets, first=pending == 0)

@@ -22,6 +22,7 @@ Deliberate differences, all keeping the reference's defaults:
 
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass
 from pathlib import Path
 from time import perf_counter
@@ -186,6 +187,46 @@ def _to_device(batch_x: torch.Tensor, device: str, tail) -> torch.Tensor:
     return batch_x.to(device, non_blocking=True).to(memory_format=torch.channels_last)
 
 
+def device_batches(dl, device: str, tail, prefetch: bool = False):
+    """(inputs, targets) on the device for every batch of `dl`, with the host-to-device copy of batch i+1 issued on a copy
+    stream BEFORE the caller enqueues the work of batch i (the reference's loop, trainers/efficientnet.py:283-287, copies
+    in-stream: at batch 256 that is 154 MB, ~3 ms of PCIe time the kernels wait for).  Asked for by the hipGraph-replayed
+    loop only (`prefetch`): measured on MI355X, B0, 256 x 1: 14.6 k -> 17.1 k images/s, 32 x 4: 5.8 k -> 6.1 k; the eager
+    loop is host-bound and loses 2..10 % to the extra stream bookkeeping.  The GPU input tail (`tail`: uint8 batches +
+    dfd_image_prep) and CPU runs keep the in-stream path.  PREFETCH_H2D=0 switches the copy stream off."""
+    use = prefetch and tail is None and str(device).startswith("cuda") and os.environ.get("PREFETCH_H2D", "1") != "0"
+    if not use:
+        for batch_x, batch_y in dl:
+            yield _to_device(batch_x, device, tail), batch_y.to(device, non_blocking=True)
+        return
+    copy = torch.cuda.Stream(device=device)
+
+    def stage(batch):
+        with torch.cuda.stream(copy):
+            x = batch[0].to(device, non_blocking=True)
+            y = batch[1].to(device, non_blocking=True)
+            done = torch.cuda.Event()
+            done.record(copy)
+        return x, y, done
+
+    it = iter(dl)
+    try:
+        nxt = stage(next(it))
+    except StopIteration:
+        return
+    while nxt is not None:
+        x, y, done = nxt
+        cur = torch.cuda.current_stream()
+        cur.wait_event(done)
+        x.record_stream(cur)                    # allocated on the copy stream, consumed on this one
+        y.record_stream(cur)
+        try:
+            nxt = stage(next(it))               # requested before the caller enqueues this batch's kernels
+        except StopIteration:
+            nxt = None
+        yield x.to(memory_format=torch.channels_last), y
+
+
 def evaluate(model: nn.Module, dl: DataLoader, device: str, criterion: nn.Module, tail=None) -> EvalResult:
     """Top-1 accuracy and mean loss; f32, no autocast (reference :237-262).  Counters stay
     on the device and are read once at the end (and summed over ranks)."""
@@ -194,9 +235,7 @@ def evaluate(model: nn.Module, dl: DataLoader, device: str, criterion: nn.Module
     loss_sum = torch.zeros((), dtype=torch.float64, device=device)
     total = 0
     with torch.inference_mode():
-        for batch_x, batch_y in dl:
-            inputs = _to_device(batch_x, device, tail)
-            targets = batch_y.to(device, non_blocking=True)
+        for inputs, targets in device_batches(dl, device, tail):
             logits = model(inputs)
             loss_sum += criterion(logits, targets).double() * targets.size(0)
             correct += (logits.argmax(1) == targets).sum()
@@ -228,9 +267,7 @@ def train_one_epoch(model: nn.Module, dl: DataLoader, opt: optim.Optimizer, scal
     loss_sum = torch.zeros((), dtype=torch.float64, device=device)
     seen_total = pending = 0
     shown = float("nan")
-    for i, (batch_x, batch_y) in enumerate(dl, 1):
-        inputs = _to_device(batch_x, device, tail)
-        targets = batch_y.to(device, non_blocking=True)
+    for i, (inputs, targets) in enumerate(device_batches(dl, device, tail, prefetch=stepper is not None), 1):
         if stepper is not None:
             loss = stepper.micro_batch(inputs, targets, first=pending == 0)      # zero_grad is part of the "first" body
             pending += 1
