@@ -82,7 +82,8 @@ def evaluate(model: nn.Module, dl: DataLoader, device: str, tail=None) -> EvalRe
     correct = torch.zeros((), dtype=torch.float64, device=device)
     total = 0
     with torch.inference_mode():
-        for inputs, targets in _base.device_batches(dl, device, tail):
+        # (large validation batches: the forward is GPU-bound and the in-stream copy would add ~40 % to it)
+        for inputs, targets in _base.device_batches(dl, device, tail, prefetch=(getattr(dl, "batch_size", 0) or 0) >= 128):
             correct += (model(inputs).argmax(1) == targets).sum()
             total += targets.numel()
     n_correct, n_total = all_reduce_counts(float(correct), float(total), device=device)
