@@ -52,9 +52,13 @@ def parse() -> argparse.Namespace:
                     help="N>1: 'split' = hipGraph(fwd+bwd) | RCCL all-reduce | hipGraph(AdamW); "
                          "'overlap' = eager step, buckets all-reduced from backward hooks")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-batch", type=int, default=16)
-    ap.add_argument("--cpu-steps", type=int, default=3)
-    ap.add_argument("--cpu-timeout", type=int, default=150, help="seconds granted to the CPU baseline child process")
+    ap.add_argument("--cpu-batch", type=int, default=32, help="SURVEY 8(d): N = 32 with the ratio to the GPU batch stated")
+    ap.add_argument("--cpu-steps", type=int, default=10, help="timed CPU steps (median)")
+    ap.add_argument("--cpu-warmup", type=int, default=3)
+    ap.add_argument("--cpu-timeout", type=int, default=240, help="seconds granted to the CPU baseline child process")
+    ap.add_argument("--extra-models", default="efficientformerv2_s1,faster_vit_0_224",
+                    help="N = 1, default workload only: after the timed region, also measure these models (batch 256, bf16) in "
+                         "child processes and report them under `models` ('' to skip)")
     ap.add_argument("--cpu-baseline-only", action="store_true", help="(internal) measure the CPU oracle and print its JSON")
     ap.add_argument("--profile-steps", type=int, default=2)
     ap.add_argument("--eval-steps", type=int, default=10, help="f32 eval-mode forward passes timed after the train steps (0: skip)")
@@ -115,7 +119,8 @@ def cpu_baseline_measure(args) -> dict:
     g = torch.Generator().manual_seed(1)
     x = torch.randn(args.cpu_batch, 3, args.size, args.size, generator=g).contiguous(memory_format=torch.channels_last)
     y = torch.randint(0, args.classes, (args.cpu_batch,), generator=g)
-    train_step_ref(model, opt, x, y)        # warm-up
+    for _ in range(max(1, args.cpu_warmup)):
+        train_step_ref(model, opt, x, y)
     times = []
     for _ in range(args.cpu_steps):
         t0 = time.perf_counter()
@@ -123,8 +128,10 @@ def cpu_baseline_measure(args) -> dict:
         times.append(time.perf_counter() - t0)
     med = sorted(times)[len(times) // 2]
     return {"value": round(args.cpu_batch / med, 2), "unit": "images/sec", "cores": cores, "kind": "port",
+            "batch": args.cpu_batch, "gpu_batch_over_cpu_batch": round(args.batch / args.cpu_batch, 3),
             "sample": f"oracle {model_label(args)} f32 channels_last train step (fwd+CE+bwd+AdamW), "
-                      f"batch {args.cpu_batch} @{args.size}px, median of {args.cpu_steps} steps after 1 warm-up"}
+                      f"batch {args.cpu_batch} @{args.size}px (the GPU step's batch is {args.batch}: ratio {args.batch / args.cpu_batch:g}), "
+                      f"median of {args.cpu_steps} timed steps after {max(1, args.cpu_warmup)} warm-up steps"}
 
 
 def cpu_baseline(args) -> dict:
@@ -133,8 +140,8 @@ def cpu_baseline(args) -> dict:
 
     cmd = [sys.executable, str(ROOT / "bench.py"), "--cpu-baseline-only", "--model", args.model, "--variant", args.variant,
            "--flavour", args.flavour,
-           "--classes", str(args.classes), "--size", str(args.size), "--cpu-batch", str(args.cpu_batch),
-           "--cpu-steps", str(args.cpu_steps)]
+           "--classes", str(args.classes), "--size", str(args.size), "--batch", str(args.batch), "--cpu-batch", str(args.cpu_batch),
+           "--cpu-steps", str(args.cpu_steps), "--cpu-warmup", str(args.cpu_warmup)]
     env = dict(os.environ)
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
         env.pop(k, None)
@@ -151,20 +158,57 @@ def cpu_baseline(args) -> dict:
     return {"value": None, "unit": "images/sec", "cores": usable_cores(), "kind": "port", "sample": f"not measured ({note})"}
 
 
-def pmc_traffic(family: str, args) -> int | None:
-    """HBM bytes per launch of a kernel family from the committed rocprofv3 --pmc passes (counters
-    cannot be read from inside this process): newest profiles/*pmc_traffic.json, which records GB per
-    training step of exactly this workload.  None when the file is absent or the workload differs."""
+def pmc_traffic(family: str, args) -> tuple[int | None, dict]:
+    """HBM bytes per launch of a kernel family from the committed rocprofv3 --pmc passes (counters cannot be read from
+    inside this process): newest profiles/*pmc_traffic.json, which records GB per training step of exactly this workload.
+    Returns (bytes or None, provenance).  None when the file is absent, the workload differs, or the file was collected
+    from OTHER kernel sources than the ones this run was built from (the file records a digest of csrc/ + include/;
+    build.source_digest() recomputes it) — a stale counter file must not dress up new kernels."""
     if (args.model, args.variant, args.flavour, args.batch, args.size) != ("efficientnet", "b0", "timm", 256, 224):
-        return None
+        return None, {"file": None, "reason": "counter passes exist for the default workload only"}
     files = sorted((ROOT / "profiles").glob("*pmc_traffic.json"))
     if not files:
-        return None
+        return None, {"file": None, "reason": "no profiles/*pmc_traffic.json"}
+    from deepfakedetection_amd.build import source_digest
+
+    src = {"file": f"profiles/{files[-1].name}"}
     try:
-        fam = json.loads(files[-1].read_text())["families"][family]
-        return int((fam["ea_read_gb_per_step"] + fam["ea_write_gb_per_step"]) * 1e9 / fam["dispatches_per_step"])
-    except (KeyError, ValueError, ZeroDivisionError):
-        return None
+        doc = json.loads(files[-1].read_text())
+        src["git_commit"] = doc.get("git_commit")
+        src["csrc_sha256"] = doc.get("csrc_sha256")
+        if doc.get("csrc_sha256") != source_digest():
+            src["reason"] = "stale: kernel sources changed since these counters were collected"
+            return None, src
+        fam = doc["families"][family]
+        return int((fam["ea_read_gb_per_step"] + fam["ea_write_gb_per_step"]) * 1e9 / fam["dispatches_per_step"]), src
+    except (KeyError, ValueError, ZeroDivisionError) as exc:
+        src["reason"] = f"unreadable ({type(exc).__name__})"
+        return None, src
+
+
+def extra_model_line(name: str, args) -> dict:
+    """`bench.py --model name` (batch 256, bf16, hipGraph) in a child process, AFTER this process's timed region:
+    BASELINE.json's metric names EfficientFormerV2-S1 next to EfficientNet-B0 (and config 5 names FasterViT-0)."""
+    import subprocess
+
+    cmd = [sys.executable, str(ROOT / "bench.py"), "--model", name, "--batch", str(args.batch), "--size", str(args.size),
+           "--classes", str(args.classes), "--steps", str(min(args.steps, 20)), "--warmup", str(min(args.warmup, 5)),
+           "--no-cpu-baseline", "--eval-steps", "0", "--extra-models", ""]
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    try:
+        proc = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env)
+        for line in reversed(proc.stdout.strip().splitlines()):
+            if line.startswith("{"):
+                d = json.loads(line)
+                return {"metric": d["metric"], "value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"],
+                        "dtype": d["dtype"], "per_gpu_batch": d["config"]["per_gpu_batch"], "launch": d["config"]["launch"],
+                        "workload": d["config"]["workload"], "roofline": d["roofline"],
+                        "top_kernels": d["kernels"][:6]}
+        return {"value": None, "note": f"child exited {proc.returncode}: {proc.stderr.strip()[-300:]}"}
+    except subprocess.TimeoutExpired:
+        return {"value": None, "note": "did not finish within 300 s"}
 
 
 def progress(msg: str) -> None:
@@ -252,12 +296,13 @@ def main() -> None:
         step_body()
     torch.cuda.synchronize()
 
-    # Launch modes.  N = 1: the whole step is ONE hipGraph.  N > 1 ("split"): the collective stays
-    # outside of graph capture — graph A = zero_grad + forward + loss + backward, then the RCCL
-    # all-reduce of the flat gradient arena, then graph B = AdamW.  ("overlap" runs eagerly so the
-    # backward hooks can fire.)
+    # Launch modes.  N = 1: the whole step is ONE hipGraph.  N > 1 ("split"): graph_step.GraphedTrainStep — the very
+    # object the trainers drive (trainers/efficientnet.make_stepper): graph(zero_grad + forward + loss + backward), then
+    # the RCCL all-reduce of the flat gradient arena in bucket-sized chunks OUTSIDE of graph capture, then graph(AdamW).
+    # ("overlap" runs eagerly so that the backward hooks can fire.)
     launch = "eager"
-    graph_a = graph_b = None
+    graph_a = None
+    stepper = None
     if not args.no_graph and not overlap:
         try:
             side = torch.cuda.Stream()
@@ -267,23 +312,23 @@ def main() -> None:
                     step_body()
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
-            opt.prepare_step()
             if reducer is None:
+                opt.prepare_step()
                 graph_a = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(graph_a, capture_error_mode="thread_local"):
                     fwd_bwd()
                     opt.step()
                 launch = "hipgraph"
             else:
-                pool = torch.cuda.graph_pool_handle()
-                graph_a = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph_a, pool=pool, capture_error_mode="thread_local"):
-                    fwd_bwd()
+                from deepfakedetection_amd.graph_step import GraphedTrainStep
+
+                stepper = GraphedTrainStep(model, crit, opt, accum_steps=1, use_amp=True, eager_cycles=1, reducer=reducer)
+                for _ in range(3):          # eager cycle, first sight of the shape, capture + first replay
+                    loss_box[0] = stepper.micro_batch(x, y, first=True, last=True)
+                    stepper.optimizer_step()
                 torch.cuda.synchronize()
-                exchange()
-                graph_b = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph_b, pool=pool, capture_error_mode="thread_local"):
-                    opt.step()
+                if stepper.failed or stepper.step_graph is None:
+                    raise RuntimeError("GraphedTrainStep fell back to eager")
                 coll = "rccl" if dist.get_backend() == "nccl" else dist.get_backend()
                 launch = f"hipgraph(fwd+bwd) | {coll} all-reduce | hipgraph(adamw)"
         except Exception as exc:  # noqa: BLE001 - any capture failure means: measure eagerly
@@ -292,25 +337,18 @@ def main() -> None:
 
                 traceback.print_exc()
                 print(f"[bench] hipGraph capture failed ({type(exc).__name__}); running eagerly", file=sys.stderr)
-            graph_a = graph_b = None
+            graph_a = stepper = None
             torch.cuda.synchronize()
     elif overlap:
         launch = "eager, all-reduce overlapped with backward"
-
-    debug = bool(os.environ.get("DFD_BENCH_DEBUG"))
 
     def run_step() -> None:
         if graph_a is not None:
             opt.prepare_step()
             graph_a.replay()
-            if graph_b is not None:
-                if debug:
-                    torch.cuda.synchronize(); t_a = time.perf_counter()
-                exchange()
-                if debug:
-                    torch.cuda.synchronize(); t_b = time.perf_counter()
-                    print(f"[bench rank {rank}] exchange {1e3 * (t_b - t_a):.2f} ms", file=sys.stderr)
-                graph_b.replay()
+        elif stepper is not None:
+            loss_box[0] = stepper.micro_batch(x, y, first=True, last=True)
+            stepper.optimizer_step()
         else:
             step_body()
 
@@ -395,8 +433,9 @@ def main() -> None:
         # intensity (all 1x1 layers < 312 flop/B), so bound = "hbm"
         top = breakdown[0]
         t, b, f, n, b8 = agg[top["kernel"]]
+        traffic, traffic_src = pmc_traffic(top["kernel"], args)
         roofline = {"kernel": top["kernel"], "bound": "hbm", "achieved": round(b8 / t / 1e9, 1), "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(b8 / t / 1e9 / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(top["kernel"], args),
+                    "unit": "GB/s", "frac": round(b8 / t / 1e9 / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                     "bytes": "SURVEY 8(d): M*(K+Nout)*2 + K*Nout*2 per 1x1 pass; N*C*(Hin*Win+Hout*Wout)*2 + k*k*C*4 per depthwise forward",
                     "achieved_incl_fusion_operands": round(b / t / 1e9, 1),
                     "avg_launch_us": round(t / n * 1e6, 2), "avg_launch_bytes": int(b8 / n),
@@ -426,6 +465,11 @@ def main() -> None:
         if world == 1 and not args.no_cpu_baseline:
             progress(f"{value:.0f} images/sec measured; timing the CPU oracle on {usable_cores()} host cores (bounded)")
             line["cpu_baseline"] = cpu_baseline(args)
+        if world == 1 and args.extra_models and (args.model, args.variant, args.flavour) == ("efficientnet", "b0", "timm"):
+            line["models"] = {}
+            for name in [m for m in args.extra_models.split(",") if m]:
+                progress(f"extra model {name} (child process, outside the timed region)")
+                line["models"][name] = extra_model_line(name, args)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

@@ -47,6 +47,11 @@ class GradArena:
     def reset(self) -> None:
         self.written = [False] * len(self.params)
 
+    def mark_written(self) -> None:
+        """Every slot holds this cycle's gradient (a hipGraph replay wrote them behind Python's back): a later eager
+        micro-batch of the same cycle must allocate its own tensor and let autograd ADD it into the slot."""
+        self.written = [True] * len(self.params)
+
     def holds_all_grads(self) -> bool:
         """True when every parameter's .grad IS its slot (static pointer table valid)."""
         return all(p.grad is not None and p.grad.data_ptr() == s.data_ptr() for p, s in zip(self.params, self.slots))

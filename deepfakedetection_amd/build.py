@@ -35,6 +35,18 @@ def _deps_mtime() -> float:
     return max(p.stat().st_mtime for p in headers)
 
 
+def source_digest() -> str:
+    """sha256 over the kernel sources and the ABI header (names + contents, sorted): what a counter file under profiles/
+    records so that bench.py can tell whether it still describes the kernels it is running."""
+    import hashlib
+
+    h = hashlib.sha256()
+    for path in sorted(list(CSRC.glob("*.hip")) + list(CSRC.glob("*.h")) + [PKG_DIR.parent / "include" / "dfd_hip.h"]):
+        h.update(path.name.encode())
+        h.update(path.read_bytes())
+    return h.hexdigest()
+
+
 def _compile(src: Path, obj: Path, hipcc: str) -> None:
     cmd = [hipcc, *FLAGS, "-c", str(src), "-o", str(obj)]
     proc = subprocess.run(cmd, capture_output=True, text=True)

@@ -135,21 +135,36 @@ class GradAllReducer:
             h.remove()
         self._hooks = []
 
+    def _sync_for_gloo(self, t: torch.Tensor) -> None:
+        # gloo stages device tensors through the host: hand it finished data (one-GPU rehearsals and tests only;
+        # RCCL orders the collective after the producing kernels on the stream by itself)
+        if t.is_cuda and dist.get_backend() == "gloo":
+            torch.cuda.synchronize()
+
     def _launch(self, b: int, early: bool) -> None:
         bucket = self.buckets[b]
         arena = self.arena
-        if self._ranges is not None and arena is not None and all(
-                p.grad is not None and p.grad.data_ptr() == arena.slots[i].data_ptr()
-                for p, i in ((p, self._slot_index(p)) for p in bucket)):
-            lo, hi = self._ranges[b]
-            chunk = arena.flat[lo:hi]
-            self._pending.append((dist.all_reduce(chunk, op=dist.ReduceOp.SUM, async_op=True), None, None))
-        else:
-            live = [p for p in bucket if p.grad is not None]
-            if not live:
+        live = [p for p in bucket if p.grad is not None]
+        if not live:
+            return
+        if self._ranges is not None and arena is not None:
+            if all(p.grad.data_ptr() == arena.slots[self._slot_index(p)].data_ptr() for p in live):
+                # copy-free: the bucket IS a range of the flat arena (slots of parameters without a gradient this
+                # step travel along; nobody reads them)
+                lo, hi = self._ranges[b]
+                chunk = arena.flat[lo:hi]
+                self._sync_for_gloo(chunk)
+                self._pending.append((dist.all_reduce(chunk, op=dist.ReduceOp.SUM, async_op=True), None, None))
+                if early:
+                    self.launched_early += 1
                 return
-            flat = torch.cat([p.grad.reshape(-1).float() for p in live])
-            self._pending.append((dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True), flat, live))
+            if live[0].is_cuda:
+                raise RuntimeError("GradAllReducer: a gradient of an arena parameter lives outside its arena slot; the "
+                                   "data-parallel hot loop has no flatten/copy path on the GPU (was .grad replaced by hand?)")
+        # no arena (CPU runs of the plumbing, optimizers other than HipAdamW): flatten, reduce, re-point
+        flat = torch.cat([p.grad.reshape(-1).float() for p in live])
+        self._sync_for_gloo(flat)
+        self._pending.append((dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True), flat, live))
         if early:
             self.launched_early += 1
 
@@ -202,6 +217,7 @@ class GradAllReducer:
         arena = self.arena
         if arena is not None and arena.holds_all_grads():
             # every gradient already sits in one flat buffer: reduce it in place, bucket by bucket
+            self._sync_for_gloo(arena.flat)
             works = [dist.all_reduce(chunk, op=dist.ReduceOp.SUM, async_op=True)
                      for chunk in arena.flat.split(self.bucket_elems)]
             for w in works:

@@ -41,7 +41,9 @@ def ident(device: torch.device, C: int):
         with torch.inference_mode(False):
             ones = torch.ones(C, dtype=torch.float32, device=device)
             zeros = torch.zeros(C, dtype=torch.float32, device=device)
-        hit = _ident_cache[key] = (ones, BNRef(zeros, ones, None, 0.0, 0.0))
+        hit = (ones, BNRef(zeros, ones, None, 0.0, 0.0))
+        if not (device.type == "cuda" and torch.cuda.is_current_stream_capturing()):
+            _ident_cache[key] = hit             # tensors born inside a capture belong to that graph's pool: not cached
     return hit
 
 

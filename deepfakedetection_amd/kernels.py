@@ -12,6 +12,7 @@ import contextlib
 import functools
 import ctypes
 import threading
+import weakref
 from dataclasses import dataclass
 
 import os
@@ -90,6 +91,85 @@ def _dt(t: torch.Tensor) -> int:
     raise TypeError(f"unsupported activation dtype {t.dtype}")
 
 
+# ---- capture journal (graph_step.GraphedTrainStep / GraphedForward).  A hipGraph records raw addresses.  While a capture
+# is open every tensor whose address goes to the library is noted here (weak reference to the tensor — or to its base
+# when it is a view — plus the address).  After the capture the owner keeps the entries that (a) are still alive, i.e.
+# are owned by something outside the captured body (parameters, buffers, caches, the optimizer's state and tables, the
+# Philox state), and (b) do not sit in the graph's private memory pool; before every replay it asserts that each of
+# them still lives at the recorded address (`stale_entries`).  A cache that replaced or dropped a recorded tensor
+# (dtype switch, regrown buffer, rebuilt table) then raises instead of letting the replay read or write freed memory.
+_journal: dict | None = None
+
+
+def journal_note(t) -> None:
+    """Record `t` (tensor, or an iterable of tensors / None) in the open capture journal; no-op when none is open."""
+    j = _journal
+    if j is None or t is None:
+        return
+    if not isinstance(t, torch.Tensor):
+        for u in t:
+            journal_note(u)
+        return
+    if not t.is_cuda:
+        return
+    base = t._base if t._base is not None else t
+    key = id(base)
+    if key not in j:
+        try:
+            j[key] = (weakref.ref(base), base.data_ptr(), base.numel() * base.element_size(), tuple(base.shape), base.dtype)
+        except TypeError:
+            pass
+
+
+@contextlib.contextmanager
+def capture_journal():
+    """`with capture_journal() as notes:` around a stream capture; `notes` is filled while the body runs."""
+    global _journal
+    if _journal is not None:
+        raise RuntimeError("nested capture journals")
+    notes: dict = {}
+    _journal = notes
+    try:
+        yield notes
+    finally:
+        _journal = None
+
+
+def _pool_ranges(device) -> list[tuple[int, int]]:
+    """Address ranges of the caching allocator's private (graph) pools on `device`."""
+    out = []
+    idx = torch.device(device).index
+    for seg in torch.cuda.memory_snapshot():
+        if seg.get("device") == (idx if idx is not None else torch.cuda.current_device()) and tuple(seg.get("segment_pool_id", (0, 0))) != (0, 0):
+            out.append((seg["address"], seg["address"] + seg["total_size"]))
+    return out
+
+
+def journal_guard(notes: dict, device) -> list[tuple]:
+    """The journal entries a replay depends on: still referenced after the capture, outside the graph pools."""
+    pools = _pool_ranges(device)
+    keep = []
+    for ref, ptr, nbytes, shape, dtype in notes.values():
+        if ref() is None or nbytes == 0:
+            continue
+        if any(lo <= ptr < hi for lo, hi in pools):
+            continue
+        keep.append((ref, ptr, nbytes, shape, dtype))
+    return keep
+
+
+def stale_entries(guard: list[tuple]) -> list[str]:
+    """Descriptions of the guarded tensors that are gone or have moved (empty list: the graph may replay)."""
+    bad = []
+    for ref, ptr, nbytes, shape, dtype in guard:
+        t = ref()
+        if t is None:
+            bad.append(f"{dtype} {shape} at {ptr:#x} was freed")
+        elif t.data_ptr() != ptr or t.numel() * t.element_size() != nbytes:
+            bad.append(f"{dtype} {shape} moved {ptr:#x} -> {t.data_ptr():#x}")
+    return bad
+
+
 def _p(t: torch.Tensor | None):
     if t is None:
         return None
@@ -97,6 +177,8 @@ def _p(t: torch.Tensor | None):
         raise RuntimeError("dfd kernels need tensors on a HIP device (no CPU fallback)")
     if not t.is_contiguous():
         raise ValueError(f"dfd kernels need contiguous tensors, got shape {tuple(t.shape)} strides {t.stride()}")
+    if _journal is not None:
+        journal_note(t)
     return t.data_ptr()
 
 
@@ -541,6 +623,9 @@ class DerivedWeights:
             s.data_ptr() == p for s, p in zip(sources, self.ptrs))
 
     def refresh(self) -> None:
+        if _journal is not None:                # the job table carries raw addresses: sources and destinations
+            journal_note(self.sources)
+            journal_note([t for pair in self.out for t in pair])
         check(_L().dfd_prep_weights_multi(self._jobs, len(self._jobs), _stream()), "dfd_prep_weights_multi")
 
 
@@ -568,6 +653,7 @@ class BNEvalBatch:
     def begin(self) -> None:
         self.pos, self.ok, self._rec = 0, True, []
         if self.keys is not None:
+            journal_note(self._flat)
             check(_L().dfd_bn_eval_coeffs_multi(self._jobs, len(self._jobs), _stream()), "dfd_bn_eval_coeffs_multi")
 
     def request(self, p: "BNParams") -> torch.Tensor:
@@ -628,6 +714,7 @@ class EvalBNStates:
             jobs[i] = BnEvalJob(bn.weight.data_ptr(), bn.bias.data_ptr(), None, None, bn.running_mean.data_ptr(),
                                 bn.running_var.data_ptr(), st.data_ptr(), float(bn.eps), C)
         self._jobs = jobs
+        self._tensors = [t for bn in bns for t in (bn.weight, bn.bias, bn.running_mean, bn.running_var)]
         self.fresh = False
 
     def valid_for(self, bns: list) -> bool:
@@ -636,6 +723,9 @@ class EvalBNStates:
             for bn, p in zip(bns, self.ptrs))
 
     def refresh(self) -> None:
+        if _journal is not None:
+            journal_note(self.flat)
+            journal_note(self._tensors)
         check(_L().dfd_bn_eval_coeffs_multi(self._jobs, len(self._jobs), _stream()), "dfd_bn_eval_coeffs_multi")
 
 
@@ -1119,12 +1209,26 @@ class DeviceRng:
     draws fresh numbers on every replay (a host-side offset would be frozen into the graph)."""
 
     def __init__(self, device: torch.device, seed: int | None = None) -> None:
-        seed = torch.initial_seed() if seed is None else seed
-        host = torch.tensor([seed & 0x7FFFFFFFFFFFFFFF, 0], dtype=torch.int64)
         with torch.inference_mode(False):
-            self.state = host.to(device)
+            self.state = torch.zeros(2, dtype=torch.int64, device=device)
+        self.reseed(seed)
         self._counter_key: tuple = ()
         self._counter_table: torch.Tensor | None = None
+
+    @staticmethod
+    def mix_seed(seed: int, rank: int) -> int:
+        """The Philox key of data-parallel rank `rank`: ranks see different samples and must not share dropout /
+        drop-connect / DropPath masks (a shared SEED would otherwise give every rank the same stream)."""
+        return (seed ^ (rank * 0x9E3779B97F4A7C15)) & 0x7FFFFFFFFFFFFFFF
+
+    def reseed(self, seed: int | None = None, rank: int | None = None) -> None:
+        """(seed, offset) <- (mix(seed, rank), 0), in place (a captured hipGraph keeps reading the same two words).
+        Defaults: torch.initial_seed() and $RANK.  Call after torch.manual_seed() to re-key an existing network."""
+        seed = torch.initial_seed() if seed is None else seed
+        rank = int(os.environ.get("RANK", "0")) if rank is None else rank
+        host = torch.tensor([self.mix_seed(seed, rank), 0], dtype=torch.int64)
+        with torch.inference_mode(False):
+            self.state.copy_(host)
 
     def uniform(self, n: int, stream_id: int) -> torch.Tensor:
         out = torch.empty(n, dtype=torch.float32, device=self.state.device)
@@ -1143,6 +1247,7 @@ class DeviceRng:
             self._counter_key = key
             with torch.inference_mode(False):
                 self._counter_table = torch.tensor(list(key), dtype=torch.int64).to(self.state.device) if key else None
+        journal_note(counters)
         check(_L().dfd_step_tick(_p(self._counter_table), len(key), _p(self.state), _stream()), "dfd_step_tick")
 
 

@@ -48,6 +48,16 @@ class HipAdamW(torch.optim.Optimizer):
         if use_arena and trainable:
             self.arena = GradArena(trainable)
 
+    def state_dict(self):
+        """torch.optim.AdamW's format: every parameter gets its OWN `step` tensor.  Internally all parameters of a
+        group share one counter object (see prepare_step); pickling that aliasing would make torch.optim.AdamW advance
+        the shared counter once per parameter after loading the checkpoint (train_env.save_latest_checkpoint stores this
+        dict as is, reference train_env.py:254-278)."""
+        sd = super().state_dict()
+        sd["state"] = {k: {n: (v.clone() if n == "step" and isinstance(v, torch.Tensor) else v) for n, v in st.items()}
+                       for k, st in sd["state"].items()}
+        return sd
+
     def load_state_dict(self, state_dict) -> None:
         super().load_state_dict(state_dict)
         self._shared_step.clear()                  # the loaded per-parameter counters are re-shared at the next step
@@ -144,6 +154,7 @@ class HipAdamW(torch.optim.Optimizer):
                 continue
             if gi not in self._hp:
                 raise RuntimeError("HipAdamW.step() under stream capture needs prepare_step() before the capture")
+            K.journal_note([t for e in entries for t in e])     # the table carries these addresses
             K.adamw_step(self._table(gi, entries), self._hp[gi])
         return loss
 

@@ -62,16 +62,6 @@ def _fastervit(model_name: str, num_classes: int) -> nn.Module:
             "run on the HIP kernels (there is no ATen fallback).") from exc
 
 
-def _not_built(family: str) -> Callable[[str, int], nn.Module]:
-    def build(model_name: str, num_classes: int) -> nn.Module:
-        raise NotImplementedError(
-            f"{family} ('{model_name}') is registered but its MI355X engine is not built yet; "
-            "the EfficientNet and EfficientFormerV2 families run on the HIP kernels (there is no ATen fallback)."
-        )
-
-    return build
-
-
 _exact: dict[str, ModelSpec] = {
     "efficientnet_b3": ModelSpec("efficientnet_b3", _EFFNET_TRAINER, "efficientnet_b3", 224, _effnet("b3", "lukemelas")),
     "efficientnet_b0": ModelSpec("efficientnet_b0", _EFFNET_TRAINER, "efficientnet_b0", 224, _effnet("b0", "timm")),

@@ -83,8 +83,9 @@ def evaluate(model: nn.Module, dl: DataLoader, device: str, tail=None) -> EvalRe
     total = 0
     with torch.inference_mode():
         # (large validation batches: the forward is GPU-bound and the in-stream copy would add ~40 % to it)
+        fwd = _base.eval_forward(model, device)
         for inputs, targets in _base.device_batches(dl, device, tail, prefetch=(getattr(dl, "batch_size", 0) or 0) >= 128):
-            correct += (model(inputs).argmax(1) == targets).sum()
+            correct += (fwd(inputs).argmax(1) == targets).sum()
             total += targets.numel()
     n_correct, n_total = all_reduce_counts(float(correct), float(total), device=device)
     return EvalResult(acc=n_correct / max(1, n_total), total=int(n_total), correct=int(n_correct))
@@ -105,7 +106,7 @@ def train_one_epoch(model: nn.Module, dl: DataLoader, opt: optim.Optimizer, scal
     for i, (inputs, targets) in enumerate(_base.device_batches(dl, device, tail, prefetch=stepper is not None), 1):
         if stepper is not None:
             # hipGraph replay of the same body; zero_grad belongs to the first micro-batch of a cycle either way
-            loss = stepper.micro_batch(inputs, targets, first=pending == 0)
+            loss = stepper.micro_batch(inputs, targets, first=pending == 0, last=pending + 1 == accum_steps)
             pending += 1
             if pending == accum_steps:
                 stepper.optimizer_step()
@@ -248,7 +249,8 @@ def run(spec: TrainerSpec) -> None:  # noqa: PLR0915
             stats = train_one_epoch(model, train_dl, warm_opt, scaler, criterion, device, use_cuda_amp=use_cuda, progress=progress,
                                     task=task, accum_steps=1, zero_grad_first=True, reducer=reducer, tail=train_tail,
                                     label="warmup", ips_in_extra=True,
-                                    stepper=_base.make_stepper(model, criterion, warm_opt, accum_steps=1, use_cuda=use_cuda, world=world))
+                                    stepper=_base.make_stepper(model, criterion, warm_opt, accum_steps=1, use_cuda=use_cuda, world=world,
+                                                                 reducer=reducer))
             log_throughput(env, chief, world, phase="warmup", epoch=0, model=model_name, batch_size=batch_size, **stats)
             if reducer is not None:
                 reducer.detach()
@@ -274,7 +276,7 @@ def run(spec: TrainerSpec) -> None:  # noqa: PLR0915
         if reducer is not None:
             reducer.attach()
         scheduler = optim.lr_scheduler.CosineAnnealingLR(opt, T_max=max(1, epochs - 1))
-        stepper = _base.make_stepper(model, criterion, opt, accum_steps=accum, use_cuda=use_cuda, world=world)
+        stepper = _base.make_stepper(model, criterion, opt, accum_steps=accum, use_cuda=use_cuda, world=world, reducer=reducer)
         start_epoch = 0
         resume_state = maybe_load_checkpoint(env, model=model, optimizer=opt, scheduler=scheduler)
         if resume_state is not None:

@@ -236,8 +236,9 @@ def evaluate(model: nn.Module, dl: DataLoader, device: str, criterion: nn.Module
     total = 0
     with torch.inference_mode():
         # (large validation batches: the forward is GPU-bound and the in-stream copy would add ~40 % to it)
+        fwd = eval_forward(model, device)
         for inputs, targets in device_batches(dl, device, tail, prefetch=(getattr(dl, "batch_size", 0) or 0) >= 128):
-            logits = model(inputs)
+            logits = fwd(inputs)
             loss_sum += criterion(logits, targets).double() * targets.size(0)
             correct += (logits.argmax(1) == targets).sum()
             total += targets.numel()
@@ -245,16 +246,32 @@ def evaluate(model: nn.Module, dl: DataLoader, device: str, criterion: nn.Module
     return EvalResult(acc=n_correct / max(1, n_total), loss=s_loss / max(1, n_total), total=int(n_total), correct=int(n_correct))
 
 
-def make_stepper(model: nn.Module, criterion: nn.Module, opt, *, accum_steps: int, use_cuda: bool, world: int):
-    """hipGraph replay of the loop body ($GRAPH_STEP, YAML training.graph_step; default on): one rank on a HIP device
-    with the HIP optimizer.  Otherwise None: the loop runs eagerly as the reference's does."""
-    if not use_cuda or world > 1 or getattr(opt, "arena", None) is None:
+def eval_forward(model: nn.Module, device: str):
+    """The callable evaluate() runs per batch: the model itself, or — on a HIP device, unless GRAPH_STEP is off — a
+    graph_step.GraphedForward kept on the model, which replays the eval-mode forward per batch shape (bit-identical to
+    the eager forward; at the reference's validation batch sizes the eager forward is host-bound)."""
+    if not str(device).startswith("cuda") or env_str("GRAPH_STEP", "1").lower() in {"0", "false", "no", "off"}:
+        return model
+    fwd = model.__dict__.get("_graphed_eval")
+    if fwd is None:
+        from ..graph_step import GraphedForward
+
+        fwd = model.__dict__["_graphed_eval"] = GraphedForward(model)
+    return fwd
+
+
+def make_stepper(model: nn.Module, criterion: nn.Module, opt, *, accum_steps: int, use_cuda: bool, world: int, reducer=None):
+    """hipGraph replay of the loop body ($GRAPH_STEP, YAML training.graph_step; default on) on a HIP device with the
+    HIP optimizer; with `world` > 1 the object also drives the gradient exchange (`reducer`): graph(zero_grad + forward +
+    backward) -> all-reduce of the flat gradient arena (RCCL, outside of capture) -> graph(AdamW).  Otherwise None: the
+    loop runs eagerly as the reference's does."""
+    if not use_cuda or getattr(opt, "arena", None) is None or (world > 1 and reducer is None):
         return None
     if env_str("GRAPH_STEP", "1").lower() in {"0", "false", "no", "off"}:
         return None
     from ..graph_step import GraphedTrainStep
 
-    return GraphedTrainStep(model, criterion, opt, accum_steps=accum_steps, use_amp=True)
+    return GraphedTrainStep(model, criterion, opt, accum_steps=accum_steps, use_amp=True, reducer=reducer)
 
 
 def train_one_epoch(model: nn.Module, dl: DataLoader, opt: optim.Optimizer, scaler, criterion: nn.Module, device: str, *,
@@ -270,7 +287,8 @@ def train_one_epoch(model: nn.Module, dl: DataLoader, opt: optim.Optimizer, scal
     shown = float("nan")
     for i, (inputs, targets) in enumerate(device_batches(dl, device, tail, prefetch=stepper is not None), 1):
         if stepper is not None:
-            loss = stepper.micro_batch(inputs, targets, first=pending == 0)      # zero_grad is part of the "first" body
+            # zero_grad is part of the "first" body; `last` lets an eager micro-batch overlap the DP exchange with its backward
+            loss = stepper.micro_batch(inputs, targets, first=pending == 0, last=pending + 1 == accum_steps)
             pending += 1
             if pending == accum_steps:
                 stepper.optimizer_step()
@@ -442,7 +460,7 @@ def main() -> None:  # noqa: PLR0915
             stats: dict = {}
             train_one_epoch(model, train_dl, warm_opt, scaler, criterion, device, use_cuda_amp=use_cuda, progress=progress,
                             task=task, accum_steps=1, reducer=reducer, tail=train_tail, stats=stats,
-                            stepper=make_stepper(model, criterion, warm_opt, accum_steps=1, use_cuda=use_cuda, world=world))
+                            stepper=make_stepper(model, criterion, warm_opt, accum_steps=1, use_cuda=use_cuda, world=world, reducer=reducer))
             _log_throughput(env, chief, world, phase="warmup", epoch=0, model=model_name, batch_size=batch_size, **stats)
             if reducer is not None:
                 reducer.detach()
@@ -463,7 +481,7 @@ def main() -> None:  # noqa: PLR0915
         if reducer is not None:
             reducer.attach()
         scheduler = optim.lr_scheduler.CosineAnnealingLR(opt, T_max=max(1, epochs - 1))
-        stepper = make_stepper(model, criterion, opt, accum_steps=accum_steps, use_cuda=use_cuda, world=world)
+        stepper = make_stepper(model, criterion, opt, accum_steps=accum_steps, use_cuda=use_cuda, world=world, reducer=reducer)
         start_epoch = 0
         resume_state = maybe_load_checkpoint(env, model=model, optimizer=opt, scheduler=scheduler)
         if resume_state is not None:

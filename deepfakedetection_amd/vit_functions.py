@@ -223,7 +223,9 @@ def _ones(device: torch.device) -> torch.Tensor:
     t = _ones_cache.get(key)
     if t is None:
         with torch.inference_mode(False):
-            t = _ones_cache[key] = torch.ones(8, dtype=torch.float32, device=device)
+            t = torch.ones(8, dtype=torch.float32, device=device)
+        if not (device.type == "cuda" and torch.cuda.is_current_stream_capturing()):
+            _ones_cache[key] = t                # a tensor born inside a capture belongs to that graph's pool: not cached
     return t
 
 

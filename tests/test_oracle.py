@@ -209,3 +209,111 @@ def test_train_mode_updates_running_stats_and_grads_flow():
     assert not torch.equal(before, model.bn1.running_mean)
     assert int(model.bn1.num_batches_tracked) == 1
     assert all(p.grad is not None for p in model.parameters())
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The timm flavour (BASELINE config 2: what bench.py measures) against the same independent implementation.
+# timm differs from the TF lineage in three places and HF's model can be configured into each:
+#   * BatchNorm eps 1e-5 / momentum 0.1                     -> batch_norm_eps=1e-5, batch_norm_momentum=0.1
+#   * stride-2 depthwise convolutions pad k//2 on all sides -> every stride-2 block index (B0: 1, 3, 5, 11) listed in
+#                                                              `depthwise_padding` (HF: "adjust_padding = idx not in list")
+#   * the stem pads 1 on all sides; HF's stem pads (0, 1)   -> HF is fed the image shifted by one pixel (zero first
+#                                                              row / column) and the image has a zero last row / column,
+#                                                              so both stems multiply the same 3x3 windows.
+# SE widths (timm round(cin/4) vs HF int(cin/4)) coincide for every B0 block.
+
+
+def _hf_timm_twin(classes: int, calibrate_on=None):
+    transformers = pytest.importorskip("transformers")
+    cfg = transformers.EfficientNetConfig(width_coefficient=1.0, depth_coefficient=1.0, image_size=224, hidden_dim=1280,
+                                          dropout_rate=0.0, drop_connect_rate=0.0, num_labels=classes,
+                                          batch_norm_eps=1e-5, batch_norm_momentum=0.1, depthwise_padding=[1, 3, 5, 11])
+    hf = transformers.EfficientNetForImageClassification(cfg)
+    torch.manual_seed(17)
+    ours = EfficientNetRef("b0", "timm", classes)
+    ours.drop_rate = 0.0
+    with torch.no_grad():
+        for m in ours.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.running_mean.normal_(0, 0.1)
+                m.running_var.uniform_(0.5, 1.5)
+                m.weight.uniform_(0.5, 1.5)
+                m.bias.normal_(0, 0.1)
+    if calibrate_on is not None:
+        # running statistics = this batch's statistics: with the fresh (0, 1) statistics the signal dies out over 80
+        # layers in eval mode and every image gets the same logits (a check that could not see the input)
+        bns = [m for m in ours.modules() if isinstance(m, torch.nn.BatchNorm2d)]
+        saved = [m.momentum for m in bns]
+        for m in bns:
+            m.momentum = 1.0
+        ours.train()
+        with torch.no_grad():
+            ours(calibrate_on)
+        for m, mom in zip(bns, saved):
+            m.momentum = mom
+            m.num_batches_tracked.zero_()
+    src, dst = ours.state_dict(), hf.state_dict()
+    assert len(src) == len(dst)
+    mapped = {}
+    for (ks, vs), (kd, vd) in zip(src.items(), dst.items()):
+        assert vs.shape == vd.shape, (ks, kd, vs.shape, vd.shape)
+        mapped[kd] = vs.clone()
+    hf.load_state_dict(mapped)
+    return ours, hf
+
+
+def _stem_aligned_inputs(n: int, size: int, seed: int):
+    """(x for the timm-flavour oracle, x shifted by one pixel for HF's (0, 1)-padded stem)."""
+    x = torch.randn(n, 3, size, size, generator=torch.Generator().manual_seed(seed))
+    x[:, :, -1, :] = 0
+    x[:, :, :, -1] = 0
+    shifted = torch.zeros_like(x)
+    shifted[:, :, 1:, 1:] = x[:, :, :-1, :-1]
+    return x, shifted
+
+
+def test_timm_flavour_b0_eval_logits_match_independent_hf_implementation():
+    x, xs = _stem_aligned_inputs(4, 224, 5)
+    ours, hf = _hf_timm_twin(10, calibrate_on=x)
+    assert sum(p.numel() for p in hf.parameters()) == sum(p.numel() for p in ours.parameters()) == 4_007_548 + 1280 * 10 + 10
+    ours.eval(); hf.eval()
+    with torch.no_grad():
+        a, b = ours(x), hf(pixel_values=xs).logits
+    assert float((a - a.mean(0, keepdim=True)).abs().max()) > 1e-2, "degenerate input: identical logits for every image"
+    assert torch.allclose(a, b, rtol=1e-4, atol=1e-5), float((a - b).abs().max())
+    assert torch.equal(a.argmax(1), b.argmax(1))
+    # the flavour matters: the TF-lineage oracle with the same weights gives other logits (eps and padding differ)
+    other = EfficientNetRef("b0", "lukemelas", 10).eval()
+    other.load_state_dict({k2: v for (k2, _), v in zip(other.state_dict().items(), ours.state_dict().values())})
+    with torch.no_grad():
+        c = other(x)
+    assert float((a - c).abs().max()) > 1e-3 * float(a.abs().max())
+
+
+def test_timm_flavour_b0_training_mode_matches_independent_hf_implementation():
+    """Batch-statistic BatchNorm with eps 1e-5, running-statistic update with momentum 0.1, and every parameter gradient."""
+    ours, hf = _hf_timm_twin(5)
+    ours.train(); hf.train()
+    x, xs = _stem_aligned_inputs(6, 96, 6)
+    y = torch.randint(0, 5, (6,), generator=torch.Generator().manual_seed(7))
+    bns_o = [m for m in ours.modules() if isinstance(m, torch.nn.BatchNorm2d)]
+    bns_h = [m for m in hf.modules() if isinstance(m, torch.nn.BatchNorm2d)]
+    a = ours(x)
+    b = hf(pixel_values=xs).logits
+    assert torch.allclose(a, b, rtol=1e-4, atol=2e-5), float((a - b).abs().max())
+    torch.nn.functional.cross_entropy(a, y, label_smoothing=0.1).backward()
+    torch.nn.functional.cross_entropy(b, y, label_smoothing=0.1).backward()
+    mine = dict(ours.named_parameters())
+    for (n1, p1), (n2, p2) in zip(ours.named_parameters(), hf.named_parameters()):
+        assert p1.shape == p2.shape, (n1, n2)
+        scale = max(float(p1.grad.abs().max()), 1e-8)
+        sib = n1[:-4] + "weight"
+        if n1.endswith("bias") and sib in mine:       # structurally zero BN-bias gradients: judged on the layer's scale
+            scale = max(scale, float(mine[sib].grad.abs().max()))
+        assert float((p1.grad - p2.grad).abs().max()) <= 2e-3 * scale + 1e-7, (n1, n2)
+    assert len(bns_o) == len(bns_h) == 49
+    for mo, mh in zip(bns_o, bns_h):
+        assert mo.momentum == mh.momentum == 0.1 and mo.eps == mh.eps == 1e-5
+        assert torch.allclose(mo.running_mean, mh.running_mean, rtol=2e-3, atol=2e-5)
+        assert torch.allclose(mo.running_var, mh.running_var, rtol=2e-3, atol=2e-5)
+        assert int(mo.num_batches_tracked) == int(mh.num_batches_tracked) == 1

@@ -229,3 +229,34 @@ def test_gpu_input_tail_sampler_and_uint8_pipeline():
     assert bool((e[:, 2] < 64).all()) and bool((e[:, 3] < 48).all())
     area = (e[:, 2] * e[:, 3]).float() / (64 * 48)
     assert float(area.min()) > 0.01 and float(area.max()) < 0.40
+
+
+def test_hip_adamw_state_dict_round_trips_into_torch_adamw():
+    """HipAdamW shares ONE step counter per group internally; the checkpoint must still carry an
+    independent `step` per parameter, or torch.optim.AdamW (the reference's optimizer, trainers/efficientnet.py:487-491)
+    advances the shared tensor once per parameter after a resume."""
+    import pickle
+
+    import torch
+
+    from deepfakedetection_amd.optim import HipAdamW
+
+    params = [torch.nn.Parameter(torch.randn(3, 2)) for _ in range(5)]
+    opt = HipAdamW(params, lr=1e-3)
+    for _ in range(3):
+        opt.prepare_step()                      # host side of a step: counters + hyper-parameters (no kernel)
+    sd = pickle.loads(pickle.dumps(opt.state_dict()))
+    steps = [st["step"] for st in sd["state"].values()]
+    assert len(steps) == 5 and all(float(s) == 3.0 for s in steps)
+    assert len({id(s) for s in steps}) == 5, "per-parameter step tensors must not alias"
+    ref = torch.optim.AdamW(params, lr=1e-3)
+    ref.load_state_dict(sd)
+    for p in params:
+        p.grad = torch.ones_like(p)
+    ref.step()
+    assert all(float(ref.state[p]["step"]) == 4.0 for p in params)
+    # and back: HipAdamW re-shares the loaded counters
+    opt2 = HipAdamW(params, lr=1e-3)
+    opt2.load_state_dict(ref.state_dict())
+    opt2.prepare_step()
+    assert all(float(opt2.state[p]["step"]) == 5.0 for p in params)

@@ -74,22 +74,45 @@ def test_orchestrated_training_and_inference_on_gpu(tmp_path, monkeypatch, model
     assert sum(map(sum, row["confusion_matrix"])) == 16
 
 
-@pytest.mark.parametrize("accum", [1, 3])
-def test_graphed_step_is_bitwise_the_eager_step(accum):
+def _build(family: str):
+    if family == "efficientnet":
+        from deepfakedetection_amd.efficientnet import HipEfficientNet
+
+        return HipEfficientNet("b0", "timm", 2), 64
+    if family == "efficientformer":
+        from deepfakedetection_amd.efficientformer_v2 import build_efficientformer_v2
+
+        return build_efficientformer_v2("efficientformerv2_s0", 2, 64), 64
+    from deepfakedetection_amd.fastervit import build_fastervit
+
+    return build_fastervit("faster_vit_0_224", 2), 224
+
+
+@pytest.mark.parametrize("family,accum", [("efficientnet", 1), ("efficientnet", 3), ("efficientformer", 2), ("fastervit", 2)])
+def test_graphed_step_is_bitwise_the_eager_step(family, accum):
     """graph_step.GraphedTrainStep replays exactly the kernels the eager loop body launches (same order, same
     fixed-order reductions, Philox masks from the same device-resident state): after several optimizer cycles the
     parameters, BatchNorm statistics and counters are bit-identical, also across an epoch boundary where the trainer
-    drops the gradients (zero_grad(set_to_none=True))."""
-    from deepfakedetection_amd.efficientnet import HipEfficientNet
+    drops the gradients (zero_grad(set_to_none=True)), with a RAGGED batch in the middle of a cycle (the last batch of a
+    loader with drop_last=False: first sight of a shape runs eagerly — FasterViT builds its window maps for that batch
+    size with a pageable copy, illegal under capture — and an eager micro-batch after replayed ones must ADD to the
+    arena slots the replay wrote), for all three model families."""
     from deepfakedetection_amd.graph_step import GraphedTrainStep
     from deepfakedetection_amd.optim import HipAdamW, HipCrossEntropyLoss
 
+    _, size = _build(family)
+    bs = 8 if family != "fastervit" else 4
     g = torch.Generator().manual_seed(3)
-    batches = [(torch.randn(8, 3, 64, 64, generator=g).cuda(), torch.randint(0, 2, (8,), generator=g).cuda()) for _ in range(5 * accum)]
+    cycles = 6
+    sizes = [bs] * (cycles * accum)
+    ragged_at = 4 * accum + (1 if accum > 1 else 0)      # a "next" micro-batch (a "first" one when accum == 1) of cycle 5
+    sizes[ragged_at] = bs - 2
+    batches = [(torch.randn(n, 3, size, size, generator=g).cuda(), torch.randint(0, 2, (n,), generator=g).cuda()) for n in sizes]
 
     def run(graph: bool):
         torch.manual_seed(11)
-        model = HipEfficientNet("b0", "timm", 2).cuda().train()
+        model, _ = _build(family)
+        model = model.cuda().train()
         opt = HipAdamW(model.parameters(), lr=1e-3, weight_decay=5e-2)
         step = GraphedTrainStep(model, HipCrossEntropyLoss(0.1), opt, accum_steps=accum)
         if not graph:
@@ -98,7 +121,7 @@ def test_graphed_step_is_bitwise_the_eager_step(accum):
         for i, (x, y) in enumerate(batches):
             if i == 3 * accum:
                 opt.zero_grad(set_to_none=True)              # what train_one_epoch does at the start of an epoch
-            losses.append(step.micro_batch(x, y, first=i % accum == 0).clone())
+            losses.append(step.micro_batch(x, y, first=i % accum == 0, last=(i + 1) % accum == 0).clone())
             if (i + 1) % accum == 0:
                 step.optimizer_step()
         torch.cuda.synchronize()
@@ -106,8 +129,84 @@ def test_graphed_step_is_bitwise_the_eager_step(accum):
 
     m_e, l_e, _ = run(False)
     m_g, l_g, step = run(True)
-    assert step.replays >= 4 * accum - accum and not step.failed and step.step_graph is not None
+    # cycle 1 eager (first sight of every key), cycles 2.. replayed except the ragged micro-batch
+    assert not step.failed and step.step_graph is not None
+    assert step.replays == (cycles - 1) * accum - 1, step.replays
     assert torch.equal(l_e, l_g), (l_e, l_g)
     for (n1, a), (_, b) in zip(m_e.state_dict().items(), m_g.state_dict().items()):
         assert torch.equal(a, b), n1
-    assert float((m_e.conv_stem.weight - HipEfficientNet("b0", "timm", 2).conv_stem.weight.cuda()).abs().max()) > 0   # it trained
+    first = next(iter(m_e.parameters()))
+    torch.manual_seed(11)
+    fresh, _ = _build(family)
+    assert float((first - next(iter(fresh.parameters())).cuda()).abs().max()) > 0   # it trained
+
+
+def test_replay_refuses_stale_addresses():
+    """A hipGraph records raw addresses (the k_pw_tn fault was a cached buffer replaced behind a graph's
+    back).  Every externally owned tensor a capture touched is journalled; train/eval and dtype switches keep their
+    caches (one entry per dtype) so replays continue, while a cache that really is rebuilt makes the next replay raise
+    StaleGraphError instead of touching freed memory."""
+    import gc
+
+    from deepfakedetection_amd.efficientnet import HipEfficientNet
+    from deepfakedetection_amd.graph_step import GraphedTrainStep, StaleGraphError
+    from deepfakedetection_amd.optim import HipAdamW, HipCrossEntropyLoss
+
+    torch.manual_seed(5)
+    model = HipEfficientNet("b0", "timm", 2).cuda().train()
+    opt = HipAdamW(model.parameters(), lr=1e-3)
+    step = GraphedTrainStep(model, HipCrossEntropyLoss(0.1), opt)
+    g = torch.Generator().manual_seed(1)
+    x, y = torch.randn(8, 3, 64, 64, generator=g).cuda(), torch.randint(0, 2, (8,), generator=g).cuda()
+    for _ in range(3):
+        step.micro_batch(x, y, first=True)
+        step.optimizer_step()
+    assert step.replays >= 1 and not step.failed
+    entry = next(iter(step.graphs.values()))
+    guard = entry[-1]
+    assert len(guard) > 100                                  # parameters, BN buffers, derived weights, arena, rng, ...
+    ptrs = {e[1] for e in guard}
+    assert model.conv_stem.weight.data_ptr() in ptrs and opt.arena.flat.data_ptr() in ptrs
+    # train -> eval (f32, inference mode) -> train: every recorded tensor is still where it was
+    model.eval()
+    with torch.inference_mode():
+        model(x)
+    model.train()
+    step.micro_batch(x, y, first=True)
+    step.optimizer_step()
+    torch.cuda.synchronize()
+    # now really rebuild a cache the graph reads: the replay must refuse
+    model.__dict__["_derived_caches"].clear()
+    gc.collect()
+    with pytest.raises(StaleGraphError):
+        step.micro_batch(x, y, first=True)
+    torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("family", ["efficientnet", "efficientformer", "fastervit"])
+def test_graphed_eval_forward_is_bitwise_the_eager_forward(family):
+    """evaluate() replays its forward per batch shape (graph_step.GraphedForward through trainers.efficientnet.eval_forward):
+    same logits bit for bit, also after the weights and BatchNorm statistics changed in between (the graph re-derives
+    coefficients and derived weights from the live tensors), with a ragged last batch."""
+    from deepfakedetection_amd.graph_step import GraphedForward
+
+    torch.manual_seed(2)
+    model, size = _build(family)
+    model = model.cuda().eval()
+    fwd = GraphedForward(model)
+    g = torch.Generator().manual_seed(9)
+    bs = 8 if family != "fastervit" else 4
+    xs = [torch.randn(n, 3, size, size, generator=g).cuda().contiguous(memory_format=torch.channels_last) for n in (bs, bs, bs, bs - 3, bs)]
+    with torch.inference_mode():
+        for i, x in enumerate(xs):
+            if i == 3:
+                with torch.no_grad():
+                    for p in model.parameters():
+                        p.mul_(1.01)
+                    for b in model.buffers():
+                        if b.dtype == torch.float32:
+                            b.add_(0.01)
+            got = fwd(x).clone()
+            want = model(x)
+            assert torch.equal(got, want), (family, i)
+    assert fwd.replays == 3 and not fwd.failed
