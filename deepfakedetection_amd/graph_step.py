@@ -35,6 +35,7 @@ instead of reading or writing memory it no longer owns.
 
 from __future__ import annotations
 
+import os
 import warnings
 
 import torch
@@ -92,6 +93,10 @@ class GraphedTrainStep:
     def _give_up(self, exc: Exception) -> None:
         self.failed = True
         torch.cuda.synchronize()
+        if os.environ.get("DFD_GRAPH_DEBUG"):
+            import traceback
+
+            traceback.print_exception(type(exc), exc, exc.__traceback__)
         warnings.warn(f"hipGraph capture of the training step failed ({type(exc).__name__}: {exc}); running eagerly", stacklevel=3)
 
     # ------------------------------------------------------------------ public
@@ -207,14 +212,17 @@ class GraphedForward:
             try:
                 if self.pool is None:
                     self.pool = torch.cuda.graph_pool_handle()
-                with torch.inference_mode(False):
+                # ordinary (non-inference) mode for the capture itself: torch's graph machinery creates bookkeeping tensors
+                # (the generator's extra-graph seed / offset) on first use and updates them in place on every later
+                # capture — born under inference_mode they would make every later capture outside of it fail
+                with torch.inference_mode(False), torch.no_grad():
                     sx = torch.empty_strided(x.shape, x.stride(), dtype=x.dtype, device=x.device)
-                sx.copy_(x)
-                torch.cuda.synchronize()
-                g = torch.cuda.CUDAGraph()
-                with K.capture_journal() as notes:
-                    with torch.cuda.graph(g, pool=self.pool, capture_error_mode="thread_local"):
-                        out = self._fwd(sx)
+                    sx.copy_(x)
+                    torch.cuda.synchronize()
+                    g = torch.cuda.CUDAGraph()
+                    with K.capture_journal() as notes:
+                        with torch.cuda.graph(g, pool=self.pool, capture_error_mode="thread_local"):
+                            out = self._fwd(sx)
                 entry = self.graphs[key] = (g, sx, out, K.journal_guard(notes, x.device))
             except Exception as exc:  # noqa: BLE001
                 self.failed = True

@@ -138,7 +138,7 @@ def test_graphed_step_is_bitwise_the_eager_step(family, accum):
     first = next(iter(m_e.parameters()))
     torch.manual_seed(11)
     fresh, _ = _build(family)
-    assert float((first - next(iter(fresh.parameters())).cuda()).abs().max()) > 0   # it trained
+    assert float((first.detach() - next(iter(fresh.parameters())).detach().cuda()).abs().max()) > 0   # it trained
 
 
 def test_replay_refuses_stale_addresses():
