@@ -134,12 +134,22 @@ SIGNATURES: dict[str, tuple] = {
     "dfd_add": (c_int, [c_int, P, P, P, c_long, P]),
     "dfd_rand": (c_int, [P, c_uint32, c_float, P, c_long, P]),
     "dfd_step_tick": (c_int, [P, c_int, P, P]),
+    "dfd_mx_quant_weights_multi": (c_int, [P, c_int, P]),
+    "dfd_mx_quant_rows": (c_int, [c_int, P, POINTER(Prologue), P, P, c_long, c_int, P]),
+    "dfd_mx_gemm": (c_int, [P, P, P, P, c_int, P, c_long, c_int, c_int, P]),
 }
 
 class BnEvalJob(Structure):
     """dfd_bn_eval_job"""
     _fields_ = [("gamma", c_void_p), ("beta", c_void_p), ("conv_bias", c_void_p), ("ls", c_void_p), ("running_mean", c_void_p),
                 ("running_var", c_void_p), ("bnstate", c_void_p), ("eps", c_float), ("C", c_int)]
+
+
+class MxJob(Structure):
+    """struct dfd_mx_job (include/dfd_hip.h)."""
+
+    _fields_ = [("src", c_void_p), ("q", c_void_p), ("scale", c_void_p), ("kn", c_void_p), ("N", c_int), ("K", c_int),
+                ("kn_dtype", c_int), ("_pad", c_int)]
 
 
 class PrepJob(Structure):

@@ -677,4 +677,4 @@ extern "C" int dfd_bn_bwd_finalize(const float* partials, int nparts, int C, dou
                                   nullptr, accumulate, coef, stream);
 }
 
-extern "C" int dfd_version(void) { return 112; }   // see include/dfd_hip.h
+extern "C" int dfd_version(void) { return 120; }   // see include/dfd_hip.h

@@ -304,8 +304,13 @@ class HipPatchEmbed(nn.Module):
 class HipFasterViT(nn.Module):
     """FasterViT-{0,1,2,3} at 224 px (7x7 windows) whose forward/backward run on the MI355X kernels."""
 
-    def __init__(self, variant: str = "0", num_classes: int = 1000, resolution: int = 224, drop_path_rate: float | None = None) -> None:
+    def __init__(self, variant: str = "0", num_classes: int = 1000, resolution: int = 224, drop_path_rate: float | None = None,
+                 fp8_weights: bool = False) -> None:
         super().__init__()
+        # BASELINE config 5 ("bf16/fp8 weights"): the qkv / proj / fc1 / fc2 weights whose K is a multiple of 128 are held as
+        # OCP MX fp8 (e4m3fn + one e8m0 scale per 32) next to the f32 masters and the forward products run on the block-scaled
+        # fp8 MFMA (csrc/dfd_mx.hip); off by default: bf16 weights
+        self.fp8_weights = bool(fp8_weights)
         if variant not in _CONFIGS:
             raise KeyError(f"unknown FasterViT variant '{variant}'")
         depths, heads, dim, in_dim, dpr, layer_scale = _CONFIGS[variant]
@@ -356,18 +361,31 @@ class HipFasterViT(nn.Module):
     def _derived_weights(self, dt: torch.dtype) -> dict:
         """{weight.data_ptr(): (w_nk, w_kn)} for the qkv / proj / fc1 / fc2 Linear of every attention block, refreshed by ONE
         batched launch per forward pass (kernels.DerivedWeights); one cache entry per activation dtype, never freed (a
-        captured hipGraph holds raw pointers into it)."""
+        captured hipGraph holds raw pointers into it).  With `fp8_weights` the entries of the weights with K % 128 == 0 are
+        (kernels.MxWeight, dequantised [K][N] copy) from one batched quantisation launch (kernels.MxWeights) instead."""
         from . import kernels as K
 
         weights = [lin.weight for m in self.modules() if isinstance(m, (WindowAttention, Mlp))
                    for lin in ((m.qkv, m.proj) if isinstance(m, WindowAttention) else (m.fc1, m.fc2))]
+        fp8 = [w for w in weights if self.fp8_weights and dt == torch.bfloat16 and w.shape[1] % 128 == 0]
+        plain = [w for w in weights if not any(w is q for q in fp8)]
         caches = self.__dict__.setdefault("_derived_caches", {})
-        cache = caches.get(dt)
-        if cache is None or not cache.valid_for(weights, dt):
-            with torch.inference_mode(False):
-                cache = caches[dt] = K.DerivedWeights([(w, True, True, False) for w in weights], dt)
-        cache.refresh()
-        return {w.data_ptr(): pair for w, pair in zip(weights, cache.out)}
+        table: dict = {}
+        if plain:
+            cache = caches.get(dt)
+            if cache is None or not cache.valid_for(plain, dt):
+                with torch.inference_mode(False):
+                    cache = caches[dt] = K.DerivedWeights([(w, True, True, False) for w in plain], dt)
+            cache.refresh()
+            table.update({w.data_ptr(): pair for w, pair in zip(plain, cache.out)})
+        if fp8:
+            cache = caches.get(("mx", dt))
+            if cache is None or not cache.valid_for(fp8, dt):
+                with torch.inference_mode(False):
+                    cache = caches[("mx", dt)] = K.MxWeights(fp8, dt)
+            cache.refresh()
+            table.update({w.data_ptr(): pair for w, pair in zip(fp8, cache.out)})
+        return table
 
     def _forward(self, x: torch.Tensor) -> torch.Tensor:
         if x.shape[2] != self.resolution or x.shape[3] != self.resolution:
@@ -396,11 +414,16 @@ def variant_of(name: str) -> str:
     raise KeyError(f"not a FasterViT name handled by the HIP engine: {name}")
 
 
-def build_fastervit(name: str, num_classes: int) -> HipFasterViT:
-    """'faster_vit_2_224' (the reference's MODEL_NAME, trainers/fastervit.py:62), 'faster_vit_0_224' (BASELINE config 5), ..."""
+def build_fastervit(name: str, num_classes: int, fp8_weights: bool | None = None) -> HipFasterViT:
+    """'faster_vit_2_224' (the reference's MODEL_NAME, trainers/fastervit.py:62), 'faster_vit_0_224' (BASELINE config 5), ...
+    fp8_weights None: $FP8_WEIGHTS (YAML `training.fp8_weights` / `inference.fp8_weights`, exported by the orchestrator)."""
+    import os
+
     parts = name.lower().replace("-", "_").split("_")
     res = int(parts[3]) if len(parts) > 3 and parts[3].isdigit() else 224
-    return HipFasterViT(variant_of(name), num_classes, res)
+    if fp8_weights is None:
+        fp8_weights = os.environ.get("FP8_WEIGHTS", "0").lower() in {"1", "true", "yes", "on"}
+    return HipFasterViT(variant_of(name), num_classes, res, fp8_weights=fp8_weights)
 
 
 __all__ = ["HipFasterViT", "build_fastervit", "variant_of"]

@@ -103,7 +103,7 @@ def _prep(w: torch.Tensor, dt: torch.dtype):
     table = getattr(_derived_tls, "table", None)
     if table is not None:
         hit = table.get(w.data_ptr())
-        if hit is not None and hit[0].dtype == dt:
+        if hit is not None and (isinstance(hit[0], K.MxWeight) or hit[0].dtype == dt):
             return hit
     return K.prep_weights(w, dt, True, True)
 

@@ -629,6 +629,87 @@ class DerivedWeights:
         check(_L().dfd_prep_weights_multi(self._jobs, len(self._jobs), _stream()), "dfd_prep_weights_multi")
 
 
+# ---- MX fp8 weights (include/dfd_hip.h "MX fp8"): FasterViT's Linear layers with `fp8_weights` on ------------------------
+class MxWeight:
+    """One Linear weight in OCP MX fp8: q [N][K] e4m3fn bytes + scale [N][K/32] e8m0 bytes.  kernels.pwconv() takes it in
+    place of the bf16 [N][K] copy and then runs quantise-activations + dfd_mx_gemm."""
+
+    __slots__ = ("q", "scale", "N", "K")
+
+    def __init__(self, q: torch.Tensor, scale: torch.Tensor) -> None:
+        self.q, self.scale = q, scale
+        self.N, self.K = q.shape
+
+    @property
+    def shape(self):
+        return (self.N, self.K)
+
+    @property
+    def dtype(self):
+        return torch.uint8
+
+
+class MxWeights:
+    """Every fp8 weight of a network, re-quantised from the f32 masters by ONE batched launch per forward pass
+    (dfd_mx_quant_weights_multi) together with the dequantised [K][N] copies the bf16 backward multiplies by."""
+
+    def __init__(self, sources: list[torch.Tensor], dtype: torch.dtype) -> None:
+        from ._lib import MxJob
+
+        self.dtype = dtype
+        self.sources = list(sources)
+        self.ptrs = [s.data_ptr() for s in self.sources]
+        self.out: list[tuple[MxWeight, torch.Tensor]] = []
+        jobs = (MxJob * len(self.sources))()
+        for i, src in enumerate(self.sources):
+            n, kdim = src.shape
+            if kdim % 128:
+                raise ValueError(f"MX fp8 weights need K % 128 == 0, got {tuple(src.shape)}")
+            q = torch.empty((n, kdim), dtype=torch.uint8, device=src.device)
+            sc = torch.empty((n, kdim // 32), dtype=torch.uint8, device=src.device)
+            kn = torch.empty((kdim, n), dtype=dtype, device=src.device)
+            self.out.append((MxWeight(q, sc), kn))
+            jobs[i] = MxJob(src.data_ptr(), q.data_ptr(), sc.data_ptr(), kn.data_ptr(), n, kdim, _code(dtype), 0)
+        self._jobs = jobs
+
+    def valid_for(self, sources: list[torch.Tensor], dtype: torch.dtype) -> bool:
+        return dtype == self.dtype and len(sources) == len(self.ptrs) and all(s.data_ptr() == p for s, p in zip(sources, self.ptrs))
+
+    def refresh(self) -> None:
+        if _journal is not None:
+            journal_note(self.sources)
+            journal_note([t for w, kn in self.out for t in (w.q, w.scale, kn)])
+        check(_L().dfd_mx_quant_weights_multi(self._jobs, len(self._jobs), _stream()), "dfd_mx_quant_weights_multi")
+
+
+def mx_quant_weight(w: torch.Tensor, dtype: torch.dtype = torch.bfloat16):
+    """(MxWeight, dequantised [K][N] copy) of one f32 [N][K] weight."""
+    mw = MxWeights([w], dtype)
+    mw.refresh()
+    return mw.out[0]
+
+
+def mx_quant_rows(a: torch.Tensor, pro: Prologue | None = None):
+    """a [..., K] (bf16 / f32) -> (q uint8 [M][K], scale uint8 [M][K/32]) after the optional BN+activation prologue."""
+    Kd = a.shape[-1]
+    M = a.numel() // Kd
+    q = torch.empty((M, Kd), dtype=torch.uint8, device=a.device)
+    sc = torch.empty((M, Kd // 32), dtype=torch.uint8, device=a.device)
+    check(_L().dfd_mx_quant_rows(_dt(a), _p(a), ctypes.byref(pro) if pro is not None else None, _p(q), _p(sc), M, Kd, _stream()),
+          "dfd_mx_quant_rows", f"M={M} K={Kd}")
+    return q, sc
+
+
+def mx_gemm(aq: torch.Tensor, ascale: torch.Tensor, w: MxWeight, out_dtype: torch.dtype, out_shape=None) -> torch.Tensor:
+    M, Kd = aq.shape
+    if Kd != w.K:
+        raise ValueError(f"mx_gemm: K mismatch {Kd} vs {w.K}")
+    out = torch.empty(out_shape if out_shape is not None else (M, w.N), dtype=out_dtype, device=aq.device)
+    check(_L().dfd_mx_gemm(_p(aq), _p(ascale), _p(w.q), _p(w.scale), _code(out_dtype), _p(out), M, Kd, w.N, _stream()),
+          "dfd_mx_gemm", f"M={M} K={Kd} N={w.N}")
+    return out
+
+
 class BNEvalBatch:
     """The eval-mode BatchNorm coefficient requests of one forward pass of a network (kernels.bn_eval_coeffs: real
     BatchNorms in eval mode, and the identity statistics that carry a Linear layer's bias / LayerScale), recorded in call
@@ -731,7 +812,14 @@ class EvalBNStates:
 
 def pwconv(a: torch.Tensor, pro: Prologue | None, w_nk: torch.Tensor, residual: torch.Tensor | None = None,
            stats: bool = False):
-    """out[..., Nout] = P(a)[..., K] @ w_nk[Nout, K]^T (+ residual). Returns (out, partials, nparts)."""
+    """out[..., Nout] = P(a)[..., K] @ w_nk[Nout, K]^T (+ residual). Returns (out, partials, nparts).
+    w_nk may be an MxWeight (fp8 weights): activations are then quantised to MX fp8 behind the prologue and the product
+    runs on the block-scaled fp8 MFMA (no residual / statistics in that form)."""
+    if isinstance(w_nk, MxWeight):
+        if residual is not None or stats:
+            raise ValueError("the MX fp8 GEMM has no residual / statistics epilogue")
+        aq, asc = mx_quant_rows(a, pro)
+        return mx_gemm(aq, asc, w_nk, a.dtype, (*a.shape[:-1], w_nk.N)), None, 0
     K = a.shape[-1]
     M = a.numel() // K
     Nout = w_nk.shape[0]

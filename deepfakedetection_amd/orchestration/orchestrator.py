@@ -163,7 +163,7 @@ _TRAIN_ENV = (("batch_size", "BATCH_SIZE"), ("epochs", "EPOCHS"), ("num_workers"
               ("weight_decay", "WEIGHT_DECAY"), ("accum_steps", "ACCUM_STEPS"), ("warmup_epochs", "WARMUP_EPOCHS"),
               ("early_stop_patience", "EARLY_STOP_PATIENCE"))
 _EXTRA_TRAIN_ENV = (("ft_batch_size", "FT_BATCH_SIZE"), ("pretrained", "PRETRAINED"), ("gpu_input_tail", "GPU_INPUT_TAIL"),
-                    ("graph_step", "GRAPH_STEP"))
+                    ("graph_step", "GRAPH_STEP"), ("fp8_weights", "FP8_WEIGHTS"))
 
 
 def _first_set(*values: Any) -> Any:
@@ -412,6 +412,8 @@ def _run_inference_job(*, config_path: Path, config: dict[str, Any], model_cfg: 
     device = torch.device(device_name)
 
     model = load_model(name, num_classes, _resolve_weights(infer_cfg, name, out), device, image_size)
+    if str(infer_cfg.get("fp8_weights", "")).lower() in ("1", "true", "yes", "on") and hasattr(model, "fp8_weights"):
+        model.fp8_weights = True       # extra key (FasterViT, with `amp: bf16`): Linear weights as MX fp8 on the scaled fp8 MFMA
     transform = build_eval_transforms(image_size, toggles=resolve_transform_mapping(model_cfg, phase="eval"))
     root = Path(data_cfg.get("root")).expanduser()
     if not root.is_absolute():

@@ -70,7 +70,8 @@ typedef void* dfd_stream;          /* a hipStream_t */
  * dfd_conv_fwd / dfd_conv_wgrad (implicit-GEMM dense convolution); dfd_sum_batch_begin / _end;
  * dfd_bn_eval_coeffs_multi;
  * 112 = the eval / inference form of the MBConv block: dfd_pwconv_fwd_eval, dfd_dwconv_fwd_eval(_tiles),
- * dfd_se_fwd_parts. */
+ * dfd_se_fwd_parts;
+ * 120 = MX fp8 weights (dfd_mx_*), fused window attention on bf16 MFMA (dfd_attn_*). */
 int dfd_version(void);
 
 /* Batched final summation of weight gradients.  The weight-gradient entry points whose result goes straight to the
@@ -456,6 +457,34 @@ int dfd_rand(const uint64_t* rng_state, uint32_t stream_id, float keep, float* o
 /* once per forward pass: *counter_ptrs[i] += 1 (BatchNorm num_batches_tracked, int64) and rng offset += 1.
  * counter_ptrs is a DEVICE array of ncounters addresses.                                                       */
 int dfd_step_tick(const int64_t* counter_ptrs, int ncounters, uint64_t* rng_state, dfd_stream stream);
+
+/* ------------------------------------------------------- MX fp8 (FasterViT fp8 weights) ---
+ * BASELINE config 5 ("FasterViT-0 bf16/fp8 weights ... on CDNA4 fp8 MFMA"); carries the Linear layers (qkv / proj /
+ * fc1 / fc2) of the third-party module's forward at trainers/fastervit.py:271 (training), :235 (evaluate) and
+ * orchestration/orchestrator.py:529,590 (inference) when `fp8_weights` is switched on.
+ * Format: OCP microscaling FP8 — e4m3fn elements, one E8M0 scale byte (2^(b-127)) per 32 consecutive K elements:
+ *   e = clamp(floor(log2(max|v|)) - 8, -127, 127);  q = e4m3_rne_sat(v * 2^-e);  scale byte = e + 127.
+ * The GEMM is v_mfma_scale_f32_16x16x128_f8f6f4 (the one fp8 form above the bf16 MFMA rate); it takes BOTH operands in this
+ * format, so activations are quantised the same way (dfd_mx_quant_rows) right before the product.  K % 128 == 0.          */
+typedef struct dfd_mx_job {
+    const float* src;      /* f32 master weight [N][K]                                                       */
+    uint8_t* q;            /* e4m3fn [N][K]                                                                  */
+    uint8_t* scale;        /* e8m0 [N][K/32]                                                                 */
+    void* kn;              /* optional: DEQUANTISED weight, transposed [K][N], element type kn_dtype
+                              (what the bf16 data-gradient GEMM multiplies by)                               */
+    int N, K;
+    int kn_dtype;
+    int _pad;
+} dfd_mx_job;
+/* all fp8 weights of a network in one call (32 jobs per launch); `jobs` is a HOST array */
+int dfd_mx_quant_weights_multi(const dfd_mx_job* jobs, int njobs, dfd_stream stream);
+/* a [M][K] (dtype) [-> act(coef[0][k]*a + coef[1][k]) rounded to dtype: prologue modes DFD_PRO_NONE / DFD_PRO_BN_ACT]
+ * -> q e4m3fn [M][K], scale e8m0 [M][K/32]                                                                              */
+int dfd_mx_quant_rows(int dtype, const void* a, const dfd_prologue* pro, uint8_t* q, uint8_t* scale, long M, int K,
+                      dfd_stream stream);
+/* out[M][N] (dtype_out) = dequant(aq, ascale) . dequant(wq, wscale)^T, f32 accumulation; wq [N][K], N % 4 == 0       */
+int dfd_mx_gemm(const uint8_t* aq, const uint8_t* ascale, const uint8_t* wq, const uint8_t* wscale, int dtype_out,
+                void* out, long M, int K, int N, dfd_stream stream);
 
 #ifdef __cplusplus
 }

@@ -149,3 +149,37 @@ def se_fc(pooled, w1, b1, w2, b2, act):
 
 def ce_label_smooth(logits, targets, eps):
     return F.cross_entropy(logits, targets, label_smoothing=eps)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# OCP microscaling (MX) FP8 — the format of the FasterViT fp8-weight path (include/dfd_hip.h "MX fp8"; BASELINE config 5).
+# Restates the OCP MX v1.0 conversion rule for element type e4m3 (emax_elem = 8) and block size 32:
+#   X = 2^(floor(log2(max|v|)) - 8) clamped to the E8M0 range, q = RNE_saturate_e4m3fn(v / X).
+# torch.float8_e4m3fn is OCP e4m3fn (not the MI300X fnuz variant); its f32 conversion rounds to nearest even.
+def mx_quant(v: torch.Tensor):
+    """v [..., K] f32 (K % 32 == 0) -> (q uint8 [..., K] e4m3fn bytes, scale uint8 [..., K/32] e8m0 bytes)."""
+    shape = v.shape
+    blocks = v.detach().to(torch.float32).reshape(-1, 32)
+    amax = blocks.abs().amax(dim=1)
+    _, ex = torch.frexp(amax)                                   # amax = m * 2^ex, m in [0.5, 1): floor(log2 amax) = ex - 1
+    e = (ex.to(torch.int32) - 1 - 8).clamp(-127, 127)
+    e = torch.where(amax > 0, e, torch.full_like(e, -127))
+    inv = torch.ldexp(torch.ones_like(amax), -e)                # 2^-e (e = -127 only for all-zero blocks: 0 * 2^127 = 0)
+    scaled = (blocks * inv[:, None]).clamp(-448.0, 448.0)
+    q = scaled.to(torch.float8_e4m3fn).view(torch.uint8)
+    return q.reshape(shape), (e + 127).to(torch.uint8).reshape(*shape[:-1], shape[-1] // 32)
+
+
+def mx_dequant(q: torch.Tensor, scale: torch.Tensor) -> torch.Tensor:
+    """(q, scale) of mx_quant -> f32 values (exact)."""
+    vals = q.contiguous().view(torch.float8_e4m3fn).to(torch.float32).reshape(-1, 32)
+    sc = torch.ldexp(torch.ones(vals.shape[0]), scale.reshape(-1).to(torch.int32) - 127)
+    return (vals * sc[:, None]).reshape(q.shape)
+
+
+def mx_linear(a: torch.Tensor, w: torch.Tensor, quantise_a: bool = True) -> torch.Tensor:
+    """deq(mx(a)) @ deq(mx(w))^T in f32 — what dfd_mx_quant_rows + dfd_mx_gemm compute (f32 accumulation; the products of
+    two e4m3 values are exact in f32).  quantise_a=False: weights-only quantisation (the looser, model-level yardstick)."""
+    wd = mx_dequant(*mx_quant(w))
+    ad = mx_dequant(*mx_quant(a)) if quantise_a else a.to(torch.float32)
+    return ad @ wd.t()
