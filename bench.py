@@ -47,6 +47,8 @@ def parse() -> argparse.Namespace:
                          "efficientformerv2_s1 (BASELINE config 3) or a FasterViT name such as faster_vit_0_224 (config 5)")
     ap.add_argument("--variant", default="b0")
     ap.add_argument("--flavour", default="timm")
+    ap.add_argument("--fp8-weights", action="store_true",
+                    help="FasterViT: qkv / proj / fc1 / fc2 weights as OCP MX fp8 on the block-scaled fp8 MFMA (BASELINE config 5)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--dp-mode", choices=("split", "overlap"), default="split",
                     help="N>1: 'split' = hipGraph(fwd+bwd) | RCCL all-reduce | hipGraph(AdamW); "
@@ -242,8 +244,8 @@ def main() -> None:
     elif args.model.startswith("faster_vit"):
         from deepfakedetection_amd.fastervit import build_fastervit
 
-        model = build_fastervit(args.model, args.classes).to(device).train()
-        workload = f"{model_label(args)} (fastervit 1.0.0 architecture, DropPath 0.2)"
+        model = build_fastervit(args.model, args.classes, fp8_weights=args.fp8_weights).to(device).train()
+        workload = f"{model_label(args)} (fastervit 1.0.0 architecture, DropPath 0.2{', MX fp8 Linear weights' if args.fp8_weights else ''})"
     else:
         model = HipEfficientNet(args.variant, args.flavour, args.classes).to(device).train()
         workload = f"EfficientNet-{args.variant} ({args.flavour} flavour)"
@@ -453,7 +455,7 @@ def main() -> None:
         line = {
             "metric": f"train images/sec @{args.size}^2 ({model_label(args)})", "value": round(value, 1), "unit": "images/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16 (MX fp8 e4m3 Linear forward)" if args.fp8_weights else "bf16", "data": "synthetic",
             "config": {"workload": f"{workload} {args.size}x{args.size} train step: "
                                    f"bf16 fwd + label-smoothed CE + bwd + AdamW, random-init weights, {args.classes} classes",
                        "per_gpu_batch": args.batch, "global_batch": args.batch * world, "parallelism": f"dp{world}",

@@ -137,6 +137,9 @@ SIGNATURES: dict[str, tuple] = {
     "dfd_mx_quant_weights_multi": (c_int, [P, c_int, P]),
     "dfd_mx_quant_rows": (c_int, [c_int, P, POINTER(Prologue), P, P, c_long, c_int, P]),
     "dfd_mx_gemm": (c_int, [P, P, P, P, c_int, P, c_long, c_int, c_int, P]),
+    "dfd_wattn_parts": (c_int, [c_int]),
+    "dfd_wattn_fwd": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_float, P]),
+    "dfd_wattn_bwd": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_float, P]),
 }
 
 class BnEvalJob(Structure):

@@ -129,21 +129,25 @@ def attn_sub_fwd(x, P, spec: AttnSpec, ls, row_scale):
     qkv, yq, stq = lin_fwd(xn, wq_nk, P["qkv_b"])
     table, mlp_saved = coord_mlp_fwd(spec.coords2d, P["cpb_w0"], P["cpb_b0"], P["cpb_w2"])
     bias_full = K.relpos_bias_fwd(table, spec.idx, spec.n_local, spec.n_global)
-    S = torch.empty((n, H, T, T), dtype=torch.float32, device=x.device)
-    q, k, v = qkv.view(n * T, 3 * C)[:, 0:C], qkv.view(n * T, 3 * C)[:, C:2 * C], qkv.view(n * T, 3 * C)[:, 2 * C:]
-    K.bgemm(q, (T * 3 * C, hd, 3 * C, 1), k, (T * 3 * C, hd, 1, 3 * C), S, (H * T * T, T * T, T, 1), n, H, T, T, hd,
-            alpha=hd ** -0.5, bias=bias_full)
-    Pm, _ = K.attn_softmax_fwd(S, None)
-    O = torch.empty((n, T, 1, C), dtype=dt, device=x.device)
-    K.bgemm(Pm, (H * T * T, T * T, T, 1), v, (T * 3 * C, hd, 3 * C, 1), O, (T * C, hd, C, 1), n, H, T, hd, T)
+    if K.wattn_supported(dt, T, hd):
+        # fused MFMA attention (csrc/dfd_attn.hip): S and P stay in registers; the backward recomputes P from L
+        O, Pm = K.wattn_fwd(qkv, bias_full, H, hd ** -0.5)
+    else:
+        S = torch.empty((n, H, T, T), dtype=torch.float32, device=x.device)
+        q, k, v = qkv.view(n * T, 3 * C)[:, 0:C], qkv.view(n * T, 3 * C)[:, C:2 * C], qkv.view(n * T, 3 * C)[:, 2 * C:]
+        K.bgemm(q, (T * 3 * C, hd, 3 * C, 1), k, (T * 3 * C, hd, 1, 3 * C), S, (H * T * T, T * T, T, 1), n, H, T, T, hd,
+                alpha=hd ** -0.5, bias=bias_full)
+        Pm, _ = K.attn_softmax_fwd(S, None)
+        O = torch.empty((n, T, 1, C), dtype=dt, device=x.device)
+        K.bgemm(Pm, (H * T * T, T * T, T, 1), v, (T * 3 * C, hd, 3 * C, 1), O, (T * C, hd, C, 1), n, H, T, hd, T)
     wp_nk, wp_kn = _prep(P["proj_w"], dt)
     out, yp, stp = lin_fwd(O, wp_nk, P["proj_b"], ACT_NONE, ls, x, row_scale)
-    return out, (x, xn, lnst, qkv, yq, stq, table, mlp_saved, Pm, O, yp, stp, wq_kn, wp_kn)
+    return out, (x, xn, lnst, qkv, yq, stq, table, mlp_saved, Pm, O, yp, stp, wq_kn, wp_kn, bias_full)
 
 
 def attn_sub_bwd(g, saved, P, spec: AttnSpec, ls, row_scale, need: dict, need_dx: bool):
     """-> (dx, grads dict).  need: name -> bool for the entries of P and 'ls'."""
-    x, xn, lnst, qkv, yq, stq, table, mlp_saved, Pm, O, yp, stp, wq_kn, wp_kn = saved
+    x, xn, lnst, qkv, yq, stq, table, mlp_saved, Pm, O, yp, stp, wq_kn, wp_kn, bias_full = saved
     n, T, _, C = x.shape
     H = spec.heads
     hd = C // H
@@ -154,25 +158,31 @@ def attn_sub_bwd(g, saved, P, spec: AttnSpec, ls, row_scale, need: dict, need_dx
                                                                  need["proj_w"], need["proj_b"], need["ls"], None, row_scale)
     if not upstream:
         return None, grads
-    q, k, v = qkv.view(n * T, 3 * C)[:, 0:C], qkv.view(n * T, 3 * C)[:, C:2 * C], qkv.view(n * T, 3 * C)[:, 2 * C:]
+    need_cpb = need["cpb_w0"] or need["cpb_b0"] or need["cpb_w2"]
     L = T * T
-    dT2 = torch.empty((n, H, T, T), dtype=torch.float32, device=dev)
-    K.bgemm(dO, (T * C, hd, C, 1), v, (T * 3 * C, hd, 1, 3 * C), dT2, (H * L, L, T, 1), n, H, T, T, hd)
-    dqkv = torch.empty_like(qkv)
-    dq, dk, dv = dqkv.view(n * T, 3 * C)[:, 0:C], dqkv.view(n * T, 3 * C)[:, C:2 * C], dqkv.view(n * T, 3 * C)[:, 2 * C:]
-    K.bgemm(Pm, (H * L, L, 1, T), dO, (T * C, hd, C, 1), dv, (T * 3 * C, hd, 3 * C, 1), n, H, T, hd, T)
-    dS_buf = torch.empty((_partial_rows(n), H, T, T), dtype=torch.float32, device=dev)
-    from ._lib import check
+    if K.wattn_supported(x.dtype, T, hd):
+        dqkv, dfull = K.wattn_bwd(qkv, dO, Pm, bias_full, H, hd ** -0.5, need_cpb)       # Pm holds the log-sum-exp rows here
+    else:
+        q, k, v = qkv.view(n * T, 3 * C)[:, 0:C], qkv.view(n * T, 3 * C)[:, C:2 * C], qkv.view(n * T, 3 * C)[:, 2 * C:]
+        dT2 = torch.empty((n, H, T, T), dtype=torch.float32, device=dev)
+        K.bgemm(dO, (T * C, hd, C, 1), v, (T * 3 * C, hd, 1, 3 * C), dT2, (H * L, L, T, 1), n, H, T, T, hd)
+        dqkv = torch.empty_like(qkv)
+        dq, dk, dv = dqkv.view(n * T, 3 * C)[:, 0:C], dqkv.view(n * T, 3 * C)[:, C:2 * C], dqkv.view(n * T, 3 * C)[:, 2 * C:]
+        K.bgemm(Pm, (H * L, L, 1, T), dO, (T * C, hd, C, 1), dv, (T * 3 * C, hd, 3 * C, 1), n, H, T, hd, T)
+        dS_buf = torch.empty((_partial_rows(n), H, T, T), dtype=torch.float32, device=dev)
+        from ._lib import check
 
-    check(K._L().dfd_attn_softmax_bwd(dT2.data_ptr(), Pm.data_ptr(), None, None, None, dS_buf.data_ptr(), n, H, T, T, K._stream()),
-          "dfd_attn_softmax_bwd")
-    dS = dS_buf[:n]
-    scale = hd ** -0.5
-    K.bgemm(dS, (H * L, L, T, 1), k, (T * 3 * C, hd, 3 * C, 1), dq, (T * 3 * C, hd, 3 * C, 1), n, H, T, hd, T, alpha=scale)
-    K.bgemm(dS, (H * L, L, 1, T), q, (T * 3 * C, hd, 3 * C, 1), dk, (T * 3 * C, hd, 3 * C, 1), n, H, T, hd, T, alpha=scale)
-    if need["cpb_w0"] or need["cpb_b0"] or need["cpb_w2"]:
-        dfull = torch.empty(H * L, dtype=torch.float32, device=dev)
-        K.sum_rows(dS_buf.view(-1), n, H * L, dfull)
+        check(K._L().dfd_attn_softmax_bwd(dT2.data_ptr(), Pm.data_ptr(), None, None, None, dS_buf.data_ptr(), n, H, T, T, K._stream()),
+              "dfd_attn_softmax_bwd")
+        dS = dS_buf[:n]
+        scale = hd ** -0.5
+        K.bgemm(dS, (H * L, L, T, 1), k, (T * 3 * C, hd, 3 * C, 1), dq, (T * 3 * C, hd, 3 * C, 1), n, H, T, hd, T, alpha=scale)
+        K.bgemm(dS, (H * L, L, 1, T), q, (T * 3 * C, hd, 3 * C, 1), dk, (T * 3 * C, hd, 3 * C, 1), n, H, T, hd, T, alpha=scale)
+        dfull = None
+        if need_cpb:
+            dfull = torch.empty(H * L, dtype=torch.float32, device=dev)
+            K.sum_rows(dS_buf.view(-1), n, H * L, dfull)
+    if need_cpb:
         dtable = K.relpos_bias_bwd(dfull.view(H, T, T), table, spec.idx, spec.n_local, spec.n_global)
         grads["cpb_w0"], grads["cpb_b0"], grads["cpb_w2"] = coord_mlp_bwd(dtable, spec.coords2d, P["cpb_w0"], P["cpb_b0"], P["cpb_w2"],
                                                                           mlp_saved, (need["cpb_w0"], need["cpb_b0"], need["cpb_w2"]))

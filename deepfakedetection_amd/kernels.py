@@ -1082,6 +1082,42 @@ def bgemm(A: torch.Tensor, sa: tuple, B: torch.Tensor, sb: tuple, C: torch.Tenso
                          int(round_b), _stream()), "dfd_bgemm", f"nb={nb} nh={nh} M={M} N={N} K={Kd}")
 
 
+def wattn_supported(dtype: torch.dtype, T: int, hd: int) -> bool:
+    """The fused MFMA window attention (csrc/dfd_attn.hip) covers bf16, head_dim 32, at most 64 tokens per window."""
+    return dtype == torch.bfloat16 and hd == 32 and 1 <= T <= 64
+
+
+def wattn_fwd(qkv: torch.Tensor, bias: torch.Tensor | None, H: int, scale: float, want_lse: bool = True):
+    """qkv [n, T, 1, 3*H*32] bf16 (q | k | v per token), bias f32 [H, T, T] or None ->
+    (o [n, T, 1, H*32] bf16, L [n, H, T] f32 = row max + log(row sum) of scale*q k^T + bias)."""
+    n, T = qkv.shape[0], qkv.shape[1]
+    C = qkv.shape[-1] // 3
+    out = torch.empty((n, T, 1, C), dtype=qkv.dtype, device=qkv.device)
+    L = torch.empty((n, H, T), dtype=torch.float32, device=qkv.device) if want_lse else None
+    check(_L().dfd_wattn_fwd(_p(qkv), _p(bias), _p(out), _p(L), n, T, H, C // H, float(scale), _stream()), "dfd_wattn_fwd",
+          f"n={n} T={T} H={H}")
+    return out, L
+
+
+def wattn_bwd(qkv: torch.Tensor, dout: torch.Tensor, L: torch.Tensor, bias: torch.Tensor | None, H: int, scale: float,
+              need_bias: bool):
+    """-> (dqkv like qkv, dbias f32 [H, T, T] | None): gradients of wattn_fwd's inputs for the gradient `dout` of o."""
+    n, T = qkv.shape[0], qkv.shape[1]
+    C = qkv.shape[-1] // 3
+    dqkv = torch.empty_like(qkv)
+    parts = None
+    rows = int(_L().dfd_wattn_parts(n))
+    if need_bias:
+        parts = torch.empty((rows + (min(rows, 1024) + 31) // 32 + 1) * H * T * T, dtype=torch.float32, device=qkv.device)
+    check(_L().dfd_wattn_bwd(_p(qkv), _p(dout), _p(L), _p(bias), _p(dqkv), _p(parts), n, T, H, C // H, float(scale), _stream()),
+          "dfd_wattn_bwd", f"n={n} T={T} H={H}")
+    dbias = None
+    if need_bias:
+        dbias = torch.empty((H, T, T), dtype=torch.float32, device=qkv.device)
+        sum_rows(parts, rows, H * T * T, dbias.view(-1))
+    return dqkv, dbias
+
+
 def attn_softmax_fwd(S: torch.Tensor, th: tuple | None):
     """S [B,H,Nq,Nk] f32 -> (P, T2); th = (w1 [H,H], b1 [H], w2 [H,H], b2 [H]) or None (then T2 is P)."""
     B, H, Nq, Nk = S.shape
@@ -1349,6 +1385,7 @@ _TIMED = ("bn_act_apply", "bn_bwd_reduce", "act_bn_bwd", "pool_act", "pool_bwd_r
           "dwconv_bwd_data", "dwconv_bwd_weight", "pwconv", "pwconv_wgrad", "stem_conv_fwd", "stem_conv_wgrad",
           "se_fc_fwd", "se_fc_bwd", "linear_fwd", "linear_bwd", "ce_loss", "adamw_step", "prep_weights", "bn_finalize",
           "bn_bwd_finalize", "bn_bwd_finalize_ex", "dropout", "bgemm", "attn_softmax_fwd", "attn_softmax_bwd", "im2col", "col2im",
+          "wattn_fwd", "wattn_bwd", "mx_quant_rows", "mx_gemm",
           "bn_add_act", "bn_add_act_bwd", "affine2_apply", "up2_act_fwd", "up2_act_bwd", "layernorm_fwd", "layernorm_bwd",
           "channel_stats", "subsample_add")
 

@@ -71,7 +71,7 @@ typedef void* dfd_stream;          /* a hipStream_t */
  * dfd_bn_eval_coeffs_multi;
  * 112 = the eval / inference form of the MBConv block: dfd_pwconv_fwd_eval, dfd_dwconv_fwd_eval(_tiles),
  * dfd_se_fwd_parts;
- * 120 = MX fp8 weights (dfd_mx_*), fused window attention on bf16 MFMA (dfd_attn_*). */
+ * 120 = MX fp8 weights (dfd_mx_*), fused window attention on bf16 MFMA (dfd_wattn_*). */
 int dfd_version(void);
 
 /* Batched final summation of weight gradients.  The weight-gradient entry points whose result goes straight to the
@@ -485,6 +485,20 @@ int dfd_mx_quant_rows(int dtype, const void* a, const dfd_prologue* pro, uint8_t
 /* out[M][N] (dtype_out) = dequant(aq, ascale) . dequant(wq, wscale)^T, f32 accumulation; wq [N][K], N % 4 == 0       */
 int dfd_mx_gemm(const uint8_t* aq, const uint8_t* ascale, const uint8_t* wq, const uint8_t* wscale, int dtype_out,
                 void* out, long M, int K, int N, dfd_stream stream);
+
+/* ------------------------------------------------ fused window attention (FasterViT) ---
+ * WindowAttention of the third-party module (forward at trainers/fastervit.py:271, backward at :274), bf16, head_dim 32,
+ * T <= 64 tokens per window:  o = softmax_k(scale * q k^T + bias[h]) v  with q / k / v read in place from the qkv projection
+ * output [n][T][3*H*32] and o written as [n][T][H*32].  One wave per (window, head) on v_mfma_f32_16x16x32_bf16; S and P stay
+ * in registers.  L [n][H][T] f32 = row max + log(row sum) (saved for the backward, which recomputes P).  bias f32 [H][T][T]
+ * or NULL.  Backward writes dqkv [n][T][3*H*32] and, when dbias_parts != NULL, dfd_wattn_parts(n) rows of [H][T][T] f32
+ * (sum over 4 windows each) for dfd_sum_rows.  DFD_EUNSUPPORTED for other head dimensions / longer windows (callers then
+ * use dfd_bgemm + dfd_attn_softmax_*).                                                                                  */
+int dfd_wattn_parts(int n);
+int dfd_wattn_fwd(const void* qkv, const float* bias, void* out, float* L, int n, int T, int H, int hd, float scale,
+                  dfd_stream stream);
+int dfd_wattn_bwd(const void* qkv, const void* dout, const float* L, const float* bias, void* dqkv, float* dbias_parts,
+                  int n, int T, int H, int hd, float scale, dfd_stream stream);
 
 #ifdef __cplusplus
 }

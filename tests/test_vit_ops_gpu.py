@@ -17,6 +17,7 @@ import torch.nn.functional as F
 from oracle import ops_ref as R
 
 pytestmark = pytest.mark.gpu
+BF = torch.bfloat16
 
 DT = [torch.float32, torch.bfloat16]
 
@@ -557,3 +558,54 @@ def test_stride1_conv_data_gradient_is_a_forward_conv_with_the_flipped_weight(rd
     dcol, _, _ = K.pwconv(g.cuda(), None, w_kn, None, stats=False)
     old = K.col2im(dcol, (N, H, H, C), k, 1, p)
     close(got, old.float().cpu(), tol(rd), "dgrad: implicit GEMM vs column matrix + col2im")
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# fused window attention on the bf16 matrix cores (csrc/dfd_attn.hip) against plain torch f32 attention
+@pytest.mark.parametrize("n,T,H,with_bias", [(5, 53, 8, True), (4, 49, 16, True), (3, 16, 8, True), (9, 49, 4, False), (2, 64, 2, True),
+                                              (1, 1, 1, True), (6, 33, 3, True)])
+def test_fused_window_attention_forward_and_backward(n, T, H, with_bias):
+    """o = softmax(scale q k^T + bias) v read in place from the qkv projection output; backward recomputes P from the saved
+    log-sum-exp.  Operands are bf16 (exact inputs for both sides); P and dS are rounded to bf16 for their products, so the
+    tolerance is bf16's (two ulps of the tensor's largest entry).  Ragged window counts (n % 4 != 0), padded token tiles
+    (T = 49, 53, 33 of 64; 16 of 32; a single token) and the bias gradient's cross-window sum are all exercised."""
+    from deepfakedetection_amd import kernels as K
+
+    hd, C = 32, H * 32
+    g = torch.Generator().manual_seed(n * 1000 + T)
+    qkv = (torch.randn(n, T, 3 * C, generator=g) * 1.5).to(BF)
+    bias = torch.randn(H, T, T, generator=g) if with_bias else None
+    dO = torch.randn(n, T, C, generator=g).to(BF)
+    scale = hd ** -0.5
+    # reference in f32 on the bf16-exact operands
+    q, k, v = [t.float().view(n, T, H, hd).permute(0, 2, 1, 3).requires_grad_() for t in qkv.split(C, dim=-1)]
+    bref = bias.clone().requires_grad_() if with_bias else None
+    S = q @ k.transpose(-1, -2) * scale
+    if with_bias:
+        S = S + bref
+    P = S.softmax(-1)
+    o_ref = (P @ v).permute(0, 2, 1, 3).reshape(n, T, C)
+    o_ref.backward(dO.float())
+    dqkv_ref = torch.cat([t.grad.permute(0, 2, 1, 3).reshape(n, T, C) for t in (q, k, v)], dim=-1)
+    L_ref = torch.logsumexp(S.detach(), dim=-1)
+
+    qd = qkv.cuda().view(n, T, 1, 3 * C)
+    bd = bias.cuda() if with_bias else None
+    o, L = K.wattn_fwd(qd, bd, H, scale)
+    dqkv, dbias = K.wattn_bwd(qd, dO.cuda().view(n, T, 1, C), L, bd, H, scale, with_bias)
+    torch.cuda.synchronize()
+    tol = 1.6e-2
+
+    def err(got, want):
+        return float((got.float().cpu().reshape(want.shape) - want).abs().max()) / max(float(want.abs().max()), 1e-12)
+
+    assert err(L, L_ref) <= 1e-5
+    assert err(o, o_ref.detach()) <= tol, err(o, o_ref.detach())
+    for name, sl in (("dq", slice(0, C)), ("dk", slice(C, 2 * C)), ("dv", slice(2 * C, 3 * C))):
+        e = err(dqkv.view(n, T, 3 * C)[..., sl], dqkv_ref[..., sl])
+        assert e <= tol, (name, e)
+    if with_bias:
+        assert err(dbias, bref.grad) <= tol, err(dbias, bref.grad)
+    # bitwise reproducible (fixed-order bias-gradient sum)
+    dqkv2, dbias2 = K.wattn_bwd(qd, dO.cuda().view(n, T, 1, C), L, bd, H, scale, with_bias)
+    assert torch.equal(dqkv, dqkv2) and (not with_bias or torch.equal(dbias, dbias2))
