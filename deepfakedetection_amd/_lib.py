@@ -140,6 +140,10 @@ SIGNATURES: dict[str, tuple] = {
     "dfd_wattn_parts": (c_int, [c_int]),
     "dfd_wattn_fwd": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_float, P]),
     "dfd_wattn_bwd": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_float, P]),
+    "dfd_coord_mlp_fwd_multi": (c_int, [P, c_int, P]),
+    "dfd_coord_mlp_bwd_multi": (c_int, [P, c_int, P]),
+    "dfd_relpos_bias_fwd_multi": (c_int, [P, c_int, P]),
+    "dfd_relpos_bias_bwd_multi": (c_int, [P, c_int, P]),
 }
 
 class BnEvalJob(Structure):
@@ -153,6 +157,19 @@ class MxJob(Structure):
 
     _fields_ = [("src", c_void_p), ("q", c_void_p), ("scale", c_void_p), ("kn", c_void_p), ("N", c_int), ("K", c_int),
                 ("kn_dtype", c_int), ("_pad", c_int)]
+
+
+class CmlpJob(Structure):
+    """struct dfd_cmlp_job (include/dfd_hip.h)."""
+
+    _fields_ = [(n, c_void_p) for n in ("coords", "w0", "b0", "w2", "table", "dtable", "dw0", "db0", "dw2")] + \
+               [(n, c_int) for n in ("T", "D", "Hd", "_pad")]
+
+
+class RelposJob(Structure):
+    """struct dfd_relpos_job (include/dfd_hip.h)."""
+
+    _fields_ = [(n, c_void_p) for n in ("table", "idx", "full", "dfull", "dtable")] + [(n, c_int) for n in ("H", "T", "n_local", "n_global")]
 
 
 class PrepJob(Structure):

@@ -90,7 +90,8 @@ class WindowAttention(nn.Module):
         return AttnSpec(self.heads, n_local, self.seq_length - n_local, self.pos_emb_funct._coords2d, self.pos_emb_funct._idx32)
 
     def tensors(self, norm: nn.LayerNorm):
-        return (norm.weight, norm.bias, self.qkv.weight, self.qkv.bias, self.proj.weight, self.proj.bias, *self.pos_emb_funct.tensors())
+        """The attention sub-block's own tensors; the relative-position bias (pos_emb_funct) comes from coord_tables."""
+        return (norm.weight, norm.bias, self.qkv.weight, self.qkv.bias, self.proj.weight, self.proj.bias)
 
 
 class Mlp(nn.Module):
@@ -126,17 +127,39 @@ class HipHAT(nn.Module):
             self.gamma1 = nn.Parameter(layer_scale * torch.ones(dim)) if use_ls else None
             self.gamma2 = nn.Parameter(layer_scale * torch.ones(dim)) if use_ls else None
 
-    def forward(self, x, ct, maps, rng=None):
+    def coord_jobs(self):
+        """(jobs, params): this block's coordinate MLPs for fastervit_functions.coord_tables — token position table, window
+        attention bias [, carrier position table, carrier attention bias]."""
+        from .fastervit_functions import CoordJob
+
+        def cpb(att: WindowAttention) -> CoordJob:
+            sp = att.spec()
+            return CoordJob("cpb", sp.coords2d, sp.idx, sp.n_local, sp.n_global)
+
+        jobs = [CoordJob("pos", self.pos_embed._coords), cpb(self.attn)]
+        params = [*self.pos_embed.tensors(), *self.attn.pos_emb_funct.tensors()]
+        if self.sr_ratio > 1:
+            jobs += [CoordJob("pos", self.hat_pos_embed._coords), cpb(self.hat_attn)]
+            params += [*self.hat_pos_embed.tensors(), *self.hat_attn.pos_emb_funct.tensors()]
+        return jobs, params
+
+    def forward(self, x, ct, maps, rng=None, tables=None):
+        """tables: this block's outputs of coord_tables (the level computes them for all of its blocks in one call); None:
+        computed here (a block used on its own)."""
+        from .fastervit_functions import coord_tables
+
         carrier = self.sr_ratio > 1
+        if tables is None:
+            tables = coord_tables(*self.coord_jobs())
         rs_win = rs_ct = None
         if self.training and self.drop_path > 0.0 and rng is not None:
             keep = 1.0 - self.drop_path
             rs_win = rng.drop_path_scale(x.shape[0], keep, stream_id=4 * self.index)
             if carrier:
                 rs_ct = rng.drop_path_scale(ct.shape[0], keep, stream_id=4 * self.index + 1)
-        flat = [*self.pos_embed.tensors(), *self.attn.tensors(self.norm1), *self.mlp.tensors(self.norm2)]
+        flat = [tables[0], *self.attn.tensors(self.norm1), tables[1], *self.mlp.tensors(self.norm2)]
         if carrier:
-            flat += [*self.hat_pos_embed.tensors(), *self.hat_attn.tensors(self.hat_norm1), *self.hat_mlp.tensors(self.hat_norm2)]
+            flat += [tables[2], *self.hat_attn.tensors(self.hat_norm1), tables[3], *self.hat_mlp.tensors(self.hat_norm2)]
         flat += [self.gamma3, self.gamma4]
         if carrier:
             flat += [self.gamma1, self.gamma2]
@@ -255,8 +278,19 @@ class HipFasterViTLayer(nn.Module):
                 maps = (src_ct, dst_ct, dst_x)
             else:
                 xw, maps = x.reshape(B, H * W, 1, C), None
+            # every coordinate MLP of the level (position tables, attention biases) in one batched call: they depend on
+            # parameters only (fastervit_functions.CoordTablesFunction)
+            from .fastervit_functions import coord_tables
+
+            jobs, params, spans = [], [], []
             for blk in self.blocks:
-                xw, ct = blk(xw, ct, maps, rng)
+                j, p = blk.coord_jobs()
+                spans.append((len(jobs), len(jobs) + len(j)))
+                jobs += j
+                params += p
+            tabs = coord_tables(jobs, params)
+            for blk, (lo, hi) in zip(self.blocks, spans):
+                xw, ct = blk(xw, ct, maps, rng, tabs[lo:hi])
             if nwin > 1:
                 x = _PermuteRows.apply(xw.reshape(B * H * W, C), part, False).view(B, H, W, C)
             else:

@@ -66,21 +66,106 @@ def lin_bwd(g, x, y, st, w_kn, w, bias, ls, act, need_dx, need_w, need_b, need_l
     return dx, dw, (dbeta if need_b else None), dls
 
 
-# =========================================================================== tiny coordinate MLPs (f32)
-def coord_mlp_fwd(coords, w0, b0, w2):
-    """Linear(2, 512) -> ReLU -> Linear(512, D, bias=False) on a [T, 2] coordinate table."""
-    hpre = K.linear_fwd(coords, w0, b0)
-    h = K.bn_add_act(hpre, None, None, ACT_RELU)
-    return K.linear_fwd(h, w2, None), (hpre, h)
+# =========================================================================== coordinate MLPs, batched per level (f32)
+@dataclass
+class CoordJob:
+    """One PosEmbMLPSwinv1D ("pos": table [T, C] added to the tokens) or PosEmbMLPSwinv2D ("cpb": relative-position attention
+    bias [H, S, S] = 16 sigmoid(table[idx])) of a hierarchical-attention block."""
+
+    kind: str                       # "pos" | "cpb"
+    coords: torch.Tensor            # [T, 2] f32 constant
+    idx: torch.Tensor | None = None     # cpb: int32 [n_local^2]
+    n_local: int = 0
+    n_global: int = 0
 
 
-def coord_mlp_bwd(dtab, coords, w0, b0, w2, saved, need):
-    hpre, h = saved
-    dh, dw2, _ = K.linear_bwd(dtab, h, w2, True, need[2], False, _slot(w2, need[2], tuple(w2.shape)), None)
-    dhpre, _, _ = K.bn_add_act_bwd(dh, hpre, None, None, ACT_RELU, stats=False)
-    _, dw0, db0 = K.linear_bwd(dhpre, coords, w0, False, need[0], need[1], _slot(w0, need[0], tuple(w0.shape)),
-                               _slot(b0, need[1], tuple(b0.shape)))
-    return dw0, db0, dw2
+class CoordTablesFunction(torch.autograd.Function):
+    """Every coordinate MLP of a level: Linear(2, 512) -> ReLU -> Linear(512, D, bias=False) on constant coordinates, and for
+    the "cpb" jobs the gather + 16 sigmoid that turns the table into the attention bias.  Inputs: (w0, b0, w2) per job.
+    Outputs: one tensor per job ("pos": table [T, D]; "cpb": bias [H, S, S]).  2 launches forward, 2 backward
+    (csrc/dfd_coord.hip) — the per-layer form cost ~16 launches per block and sat on every block's critical path."""
+
+    @staticmethod
+    def forward(ctx, jobs, *params):
+        from ._lib import CmlpJob, RelposJob
+
+        dev = params[0].device
+        n = len(jobs)
+        tables, outs = [], []
+        cj = (CmlpJob * n)()
+        rp = []
+        for i, job in enumerate(jobs):
+            w0, b0, w2 = params[3 * i:3 * i + 3]
+            T, D = job.coords.shape[0], w2.shape[0]
+            tab = torch.empty((T, D), dtype=torch.float32, device=dev)
+            tables.append(tab)
+            cj[i] = CmlpJob(K._p(job.coords), K._p(w0), K._p(b0), K._p(w2), K._p(tab), None, None, None, None, T, D, w0.shape[0], 0)
+            if job.kind == "cpb":
+                S = job.n_local + job.n_global
+                full = torch.empty((D, S, S), dtype=torch.float32, device=dev)
+                rp.append(RelposJob(K._p(tab), K._p(job.idx), K._p(full), None, None, D, T, job.n_local, job.n_global))
+                outs.append(full)
+            else:
+                outs.append(tab)
+        K.check(K._L().dfd_coord_mlp_fwd_multi(cj, n, K._stream()), "dfd_coord_mlp_fwd_multi")
+        if rp:
+            arr = (RelposJob * len(rp))(*rp)
+            K.check(K._L().dfd_relpos_bias_fwd_multi(arr, len(rp), K._stream()), "dfd_relpos_bias_fwd_multi")
+        # never keep an OUTPUT on ctx: output -> grad_fn (this node) -> ctx -> output is a cycle Python's collector cannot see
+        # through; it would pin this node and the AccumulateGrad nodes behind it across iterations (and a stale AccumulateGrad
+        # node on the legacy stream breaks a later hipGraph capture).  Only the raw tables of the "cpb" jobs are needed.
+        ctx.jobs, ctx.params = jobs, params
+        ctx.shapes = [tuple(t.shape) for t in tables]
+        ctx.raw = [t if job.kind == "cpb" else None for t, job in zip(tables, jobs)]
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        from ._lib import CmlpJob, RelposJob
+
+        jobs, params, shapes, raw = ctx.jobs, ctx.params, ctx.shapes, ctx.raw
+        need = ctx.needs_input_grad[1:]
+        dev = params[0].device
+        grads: list = [None] * len(params)
+        cj, rp, keep = [], [], []
+        for i, job in enumerate(jobs):
+            g = gouts[i]
+            nw0, nb0, nw2 = need[3 * i:3 * i + 3]
+            if g is None or not (nw0 or nb0 or nw2):
+                continue
+            w0, b0, w2 = params[3 * i:3 * i + 3]
+            T, D = shapes[i]
+            g = _c(g.float())
+            if job.kind == "cpb":
+                dtab = torch.empty((T, D), dtype=torch.float32, device=dev)
+                rp.append(RelposJob(K._p(raw[i]), K._p(job.idx), None, K._p(g), K._p(dtab), D, T, job.n_local, job.n_global))
+                keep.append(g)
+                g = dtab
+            dw0 = (_slot(w0, True, tuple(w0.shape)) if nw0 else None)
+            db0 = (_slot(b0, True, tuple(b0.shape)) if nb0 else None)
+            dw2 = (_slot(w2, True, tuple(w2.shape)) if nw2 else None)
+            if nw0 and dw0 is None:
+                dw0 = torch.empty_like(w0)
+            if nb0 and db0 is None:
+                db0 = torch.empty_like(b0)
+            if nw2 and dw2 is None:
+                dw2 = torch.empty_like(w2)
+            grads[3 * i], grads[3 * i + 1], grads[3 * i + 2] = dw0, db0, dw2
+            keep.append(g)
+            cj.append(CmlpJob(K._p(job.coords), K._p(w0), K._p(b0), K._p(w2), None, K._p(g), K._p(dw0), K._p(db0), K._p(dw2),
+                              T, D, w0.shape[0], 0))
+        if rp:
+            arr = (RelposJob * len(rp))(*rp)
+            K.check(K._L().dfd_relpos_bias_bwd_multi(arr, len(rp), K._stream()), "dfd_relpos_bias_bwd_multi")
+        if cj:
+            arr = (CmlpJob * len(cj))(*cj)
+            K.check(K._L().dfd_coord_mlp_bwd_multi(arr, len(cj), K._stream()), "dfd_coord_mlp_bwd_multi")
+        return (None, *grads)
+
+
+def coord_tables(jobs: list, params: list) -> list:
+    """[table | bias per job] for `jobs` (CoordJob) with their (w0, b0, w2) parameter triples flattened in `params`."""
+    return list(CoordTablesFunction.apply(jobs, *params))
 
 
 # =========================================================================== attention / MLP sub-blocks on [n, T, C]
@@ -119,7 +204,8 @@ class AttnSpec:
 
 def attn_sub_fwd(x, P, spec: AttnSpec, ls, row_scale):
     """x + [rs *] [ls *] proj(softmax(q k^T * scale + bias) v) with q, k, v = qkv(LN(x)).
-    P: dict of tensors (ln_w, ln_b, qkv_w, qkv_b, proj_w, proj_b, cpb_w0, cpb_b0, cpb_w2)."""
+    P: dict of tensors (ln_w, ln_b, qkv_w, qkv_b, proj_w, proj_b, bias); bias = the [H, T, T] relative-position bias of
+    CoordTablesFunction."""
     n, T, _, C = x.shape
     H = spec.heads
     hd = C // H
@@ -127,8 +213,7 @@ def attn_sub_fwd(x, P, spec: AttnSpec, ls, row_scale):
     xn, lnst = K.layernorm_fwd(x, P["ln_w"], P["ln_b"], 1e-5)
     wq_nk, wq_kn = _prep(P["qkv_w"], dt)
     qkv, yq, stq = lin_fwd(xn, wq_nk, P["qkv_b"])
-    table, mlp_saved = coord_mlp_fwd(spec.coords2d, P["cpb_w0"], P["cpb_b0"], P["cpb_w2"])
-    bias_full = K.relpos_bias_fwd(table, spec.idx, spec.n_local, spec.n_global)
+    bias_full = P["bias"]
     if K.wattn_supported(dt, T, hd):
         # fused MFMA attention (csrc/dfd_attn.hip): S and P stay in registers; the backward recomputes P from L
         O, Pm = K.wattn_fwd(qkv, bias_full, H, hd ** -0.5)
@@ -142,23 +227,23 @@ def attn_sub_fwd(x, P, spec: AttnSpec, ls, row_scale):
         K.bgemm(Pm, (H * T * T, T * T, T, 1), v, (T * 3 * C, hd, 3 * C, 1), O, (T * C, hd, C, 1), n, H, T, hd, T)
     wp_nk, wp_kn = _prep(P["proj_w"], dt)
     out, yp, stp = lin_fwd(O, wp_nk, P["proj_b"], ACT_NONE, ls, x, row_scale)
-    return out, (x, xn, lnst, qkv, yq, stq, table, mlp_saved, Pm, O, yp, stp, wq_kn, wp_kn, bias_full)
+    return out, (x, xn, lnst, qkv, yq, stq, Pm, O, yp, stp, wq_kn, wp_kn, bias_full)
 
 
 def attn_sub_bwd(g, saved, P, spec: AttnSpec, ls, row_scale, need: dict, need_dx: bool):
     """-> (dx, grads dict).  need: name -> bool for the entries of P and 'ls'."""
-    x, xn, lnst, qkv, yq, stq, table, mlp_saved, Pm, O, yp, stp, wq_kn, wp_kn, bias_full = saved
+    x, xn, lnst, qkv, yq, stq, Pm, O, yp, stp, wq_kn, wp_kn, bias_full = saved
     n, T, _, C = x.shape
     H = spec.heads
     hd = C // H
     dev = x.device
     grads = {}
-    upstream = need_dx or any(need[k] for k in ("ln_w", "ln_b", "qkv_w", "qkv_b", "cpb_w0", "cpb_b0", "cpb_w2"))
+    upstream = need_dx or any(need[k] for k in ("ln_w", "ln_b", "qkv_w", "qkv_b", "bias"))
     dO, grads["proj_w"], grads["proj_b"], grads["ls"] = lin_bwd(g, O, yp, stp, wp_kn, P["proj_w"], P["proj_b"], ls, ACT_NONE, upstream,
                                                                  need["proj_w"], need["proj_b"], need["ls"], None, row_scale)
     if not upstream:
         return None, grads
-    need_cpb = need["cpb_w0"] or need["cpb_b0"] or need["cpb_w2"]
+    need_cpb = need["bias"]
     L = T * T
     if K.wattn_supported(x.dtype, T, hd):
         dqkv, dfull = K.wattn_bwd(qkv, dO, Pm, bias_full, H, hd ** -0.5, need_cpb)       # Pm holds the log-sum-exp rows here
@@ -183,9 +268,7 @@ def attn_sub_bwd(g, saved, P, spec: AttnSpec, ls, row_scale, need: dict, need_dx
             dfull = torch.empty(H * L, dtype=torch.float32, device=dev)
             K.sum_rows(dS_buf.view(-1), n, H * L, dfull)
     if need_cpb:
-        dtable = K.relpos_bias_bwd(dfull.view(H, T, T), table, spec.idx, spec.n_local, spec.n_global)
-        grads["cpb_w0"], grads["cpb_b0"], grads["cpb_w2"] = coord_mlp_bwd(dtable, spec.coords2d, P["cpb_w0"], P["cpb_b0"], P["cpb_w2"],
-                                                                          mlp_saved, (need["cpb_w0"], need["cpb_b0"], need["cpb_w2"]))
+        grads["bias"] = dfull.view(H, T, T)
     need_xn = need_dx or need["ln_w"] or need["ln_b"]
     dxn, grads["qkv_w"], grads["qkv_b"], _ = lin_bwd(dqkv, xn, yq, stq, wq_kn, P["qkv_w"], P["qkv_b"], None, ACT_NONE, need_xn,
                                                      need["qkv_w"], need["qkv_b"])
@@ -266,9 +349,9 @@ def mlp_sub_bwd(g, saved, P, ls, row_scale, need: dict, need_dx: bool):
 
 
 # =========================================================================== HAT block
-_ATTN_KEYS = ("ln_w", "ln_b", "qkv_w", "qkv_b", "proj_w", "proj_b", "cpb_w0", "cpb_b0", "cpb_w2")
+_ATTN_KEYS = ("ln_w", "ln_b", "qkv_w", "qkv_b", "proj_w", "proj_b", "bias")
 _MLP_KEYS = ("ln_w", "ln_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b")
-_POS_KEYS = ("w0", "b0", "w2")
+_POS_KEYS = ("table",)
 
 
 @dataclass
@@ -308,26 +391,24 @@ class HATFunction(torch.autograd.Function):
         def sub(prefix, keys):
             return {k: T[f"{prefix}.{k}"] for k in keys}
 
-        tab_x, pos_saved = coord_mlp_fwd(cfg.coords_win, T["pos.w0"], T["pos.b0"], T["pos.w2"])
-        x1 = K.add_rowtable(x, tab_x)
+        x1 = K.add_rowtable(x, T["pos.table"])
         saved_ct = None
         if cfg.carrier:
             B, Tc = ct.shape[0], ct.shape[1]
-            tab_c, hpos_saved = coord_mlp_fwd(cfg.coords_ct, T["hpos.w0"], T["hpos.b0"], T["hpos.w2"])
-            c1 = K.add_rowtable(ct, tab_c)
+            c1 = K.add_rowtable(ct, T["hpos.table"])
             c2, hattn_saved = attn_sub_fwd(c1, sub("hattn", _ATTN_KEYS), cfg.ct_spec, T["gamma1"], T["rs_ct"])
             c3, hmlp_saved = mlp_sub_fwd(c2, sub("hmlp", _MLP_KEYS), T["gamma2"], T["rs_ct"])
             per = Tc * B // nW                                      # carrier tokens per window (4)
             xc = torch.empty((nW, Tw + per, 1, C), dtype=x.dtype, device=x.device)
             K.copy_rows(c3.view(-1, C), cfg.cat_src_ct, xc.view(-1, C), cfg.cat_dst_ct, nW * per)
             K.copy_rows(x1.view(-1, C), None, xc.view(-1, C), cfg.cat_dst_x, nW * Tw)
-            saved_ct = (hpos_saved, hattn_saved, hmlp_saved, per)
+            saved_ct = (hattn_saved, hmlp_saved, per)
         else:
             xc = x1
         xa, attn_saved = attn_sub_fwd(xc, sub("attn", _ATTN_KEYS), cfg.win_spec, T["gamma3"], T["rs_win"])
         xm, mlp_saved = mlp_sub_fwd(xa, sub("mlp", _MLP_KEYS), T["gamma4"], T["rs_win"])
         if cfg.carrier:
-            per = saved_ct[3]
+            per = saved_ct[2]
             x_out = torch.empty_like(x)
             ct_out = torch.empty_like(ct)
             K.copy_rows(xm.view(-1, C), cfg.cat_dst_x, x_out.view(-1, C), None, nW * Tw)
@@ -337,7 +418,7 @@ class HATFunction(torch.autograd.Function):
         ctx.cfg = cfg
         ctx.names = names
         ctx.T = T
-        ctx.saved = (pos_saved, saved_ct, attn_saved, mlp_saved)
+        ctx.saved = (saved_ct, attn_saved, mlp_saved)
         ctx.shapes = (tuple(x.shape), tuple(ct.shape) if ct is not None else None, x.dtype)
         if ct_out is None:
             ctx.mark_non_differentiable()
@@ -349,7 +430,7 @@ class HATFunction(torch.autograd.Function):
     def backward(ctx, gx, gct):
         cfg: HATCtx = ctx.cfg
         names, T = ctx.names, ctx.T
-        pos_saved, saved_ct, attn_saved, mlp_saved = ctx.saved
+        saved_ct, attn_saved, mlp_saved = ctx.saved
         x_shape, ct_shape, dt = ctx.shapes
         need = dict(zip(["x", "ct", "cfg"] + names, ctx.needs_input_grad))
         nW, Tw, _, C = x_shape
@@ -368,7 +449,7 @@ class HATFunction(torch.autograd.Function):
         need_x1 = need["x"] or any(need[f"pos.{k}"] for k in _POS_KEYS)
         gx = _c(gx)
         if cfg.carrier:
-            per = saved_ct[3]
+            per = saved_ct[2]
             gm = torch.empty((nW, Tw + per, 1, C), dtype=dt, device=dev)
             K.copy_rows(gx.view(-1, C), None, gm.view(-1, C), cfg.cat_dst_x, nW * Tw)
             if gct is not None:
@@ -389,7 +470,7 @@ class HATFunction(torch.autograd.Function):
             grads["gamma3" if k == "ls" else f"attn.{k}"] = v
         dx = dct = None
         if cfg.carrier:
-            hpos_saved, hattn_saved, hmlp_saved, per = saved_ct
+            hattn_saved, hmlp_saved, per = saved_ct
             dx1 = None
             if need_x1:
                 dx1 = torch.empty(x_shape, dtype=dt, device=dev)
@@ -406,20 +487,14 @@ class HATFunction(torch.autograd.Function):
                 for k, v in g_ha.items():
                     grads["gamma1" if k == "ls" else f"hattn.{k}"] = v
                 if need_c1:
-                    if any(need[f"hpos.{k}"] for k in _POS_KEYS):
-                        dtab = K.rowtable_grad(dc1, ct_shape[1])
-                        dw0, db0, dw2 = coord_mlp_bwd(dtab, cfg.coords_ct, T["hpos.w0"], T["hpos.b0"], T["hpos.w2"], hpos_saved,
-                                                      tuple(need[f"hpos.{k}"] for k in _POS_KEYS))
-                        grads["hpos.w0"], grads["hpos.b0"], grads["hpos.w2"] = dw0, db0, dw2
+                    if need["hpos.table"]:
+                        grads["hpos.table"] = K.rowtable_grad(dc1, ct_shape[1])
                     dct = dc1 if need["ct"] else None
         else:
             dx1 = dxc
         if need_x1 and dx1 is not None:
-            if any(need[f"pos.{k}"] for k in _POS_KEYS):
-                dtab = K.rowtable_grad(dx1, Tw)
-                dw0, db0, dw2 = coord_mlp_bwd(dtab, cfg.coords_win, T["pos.w0"], T["pos.b0"], T["pos.w2"], pos_saved,
-                                              tuple(need[f"pos.{k}"] for k in _POS_KEYS))
-                grads["pos.w0"], grads["pos.b0"], grads["pos.w2"] = dw0, db0, dw2
+            if need["pos.table"]:
+                grads["pos.table"] = K.rowtable_grad(dx1, Tw)
             dx = dx1 if need["x"] else None
         flat = [grads.get(nm) if need[nm] else None for nm in names]
         return (dx, dct, None, *flat)

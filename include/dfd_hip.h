@@ -71,7 +71,8 @@ typedef void* dfd_stream;          /* a hipStream_t */
  * dfd_bn_eval_coeffs_multi;
  * 112 = the eval / inference form of the MBConv block: dfd_pwconv_fwd_eval, dfd_dwconv_fwd_eval(_tiles),
  * dfd_se_fwd_parts;
- * 120 = MX fp8 weights (dfd_mx_*), fused window attention on bf16 MFMA (dfd_wattn_*). */
+ * 120 = MX fp8 weights (dfd_mx_*), fused window attention on bf16 MFMA (dfd_wattn_*),
+ * batched coordinate MLPs (dfd_coord_mlp_*_multi, dfd_relpos_bias_*_multi). */
 int dfd_version(void);
 
 /* Batched final summation of weight gradients.  The weight-gradient entry points whose result goes straight to the
@@ -499,6 +500,35 @@ int dfd_wattn_fwd(const void* qkv, const float* bias, void* out, float* L, int n
                   dfd_stream stream);
 int dfd_wattn_bwd(const void* qkv, const void* dout, const float* L, const float* bias, void* dqkv, float* dbias_parts,
                   int n, int T, int H, int hd, float scale, dfd_stream stream);
+
+/* -------------------------------------------- batched coordinate MLPs (FasterViT) ---
+ * PosEmbMLPSwinv1D / PosEmbMLPSwinv2D of the third-party module:  table[t][:] = W2 . relu(W0 . coords[t] + b0), f32,
+ * coords [T][2] constant, W0 [Hd][2], b0 [Hd], W2 [D][Hd] (Hd = 512).  They depend on parameters only, so a whole level's
+ * tables are computed by one call before its first block and differentiated by one call after its last
+ * (2 + 2 launches instead of ~280 per step).  `jobs` are HOST arrays (copied into kernel arguments, 24 per launch).
+ * forward reads coords / w0 / b0 / w2 and writes table [T][D]; backward reads dtable [T][D] too and writes the non-NULL ones
+ * of dw0 [Hd][2], db0 [Hd], dw2 [D][Hd] (overwriting).  T <= 176, Hd <= 1024, Hd % 4 == 0.                               */
+typedef struct dfd_cmlp_job {
+    const float *coords, *w0, *b0, *w2;
+    float* table;
+    const float* dtable;
+    float *dw0, *db0, *dw2;
+    int T, D, Hd, _pad;
+} dfd_cmlp_job;
+int dfd_coord_mlp_fwd_multi(const dfd_cmlp_job* jobs, int njobs, dfd_stream stream);
+int dfd_coord_mlp_bwd_multi(const dfd_cmlp_job* jobs, int njobs, dfd_stream stream);
+/* dfd_relpos_bias_fwd / _bwd for every attention layer of a level at once: table [T][H], idx int32 [n_local^2],
+ * full / dfull [H][S][S] with S = n_local + n_global, dtable [T][H].                                                     */
+typedef struct dfd_relpos_job {
+    const float* table;
+    const int* idx;
+    float* full;
+    const float* dfull;
+    float* dtable;
+    int H, T, n_local, n_global;
+} dfd_relpos_job;
+int dfd_relpos_bias_fwd_multi(const dfd_relpos_job* jobs, int njobs, dfd_stream stream);
+int dfd_relpos_bias_bwd_multi(const dfd_relpos_job* jobs, int njobs, dfd_stream stream);
 
 #ifdef __cplusplus
 }
