@@ -70,6 +70,7 @@ SIGNATURES: dict[str, tuple] = {
     "dfd_dwconv_bwd_data": (c_int, [c_int, P, P, P, P, P, P, c_int, P, POINTER(DwShape), P, c_int, _PI, P]),
     "dfd_dwconv_bwd_weight": (c_int, [c_int, P, P, P, P, P, c_int, P, POINTER(DwShape), c_int, P, c_size_t, P]),
     "dfd_dwconv_bwd_weight_ws": (c_size_t, [POINTER(DwShape)]),
+    "dfd_dwconv_bwd_fused": (c_int, [c_int, P, P, P, P, P, P, c_int, P, P, POINTER(DwShape), P, c_int, _PI, c_int, P, c_size_t, P]),
     "dfd_pwconv_fwd": (c_int, [c_int, P, POINTER(Prologue), P, P, P, c_int, c_int, c_int, P, c_int, _PI, P]),
     "dfd_pwconv_wgrad": (c_int, [c_int, P, POINTER(Prologue), c_int, P, POINTER(Prologue), c_int, c_int, P, c_int, P, c_size_t, P]),
     "dfd_pwconv_wgrad_ws": (c_size_t, [c_int, c_int, c_int]),

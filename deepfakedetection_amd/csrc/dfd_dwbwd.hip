@@ -16,59 +16,6 @@
 #define DFD_ABLATE 0   // timing experiments (scripts/build_variant.sh): 1 = staging only, 2 = taps only
 #endif
 
-// stage dy = ka*dz + kb*y + kc (or dz as is) for rows gy0.., cols gx0.. of the [SH][SW] dy image
-template <typename T, bool COEF, int U = 4>
-__device__ __forceinline__ void stage_dy(uint4* __restrict__ tile, const T* __restrict__ dz, const T* __restrict__ yraw,
-                                         const float* __restrict__ cf, int cvbV, int vl, long img_base, int SH, int SW, int C,
-                                         int c0, bool cvalid, int gy0, int gx0, int IH, int IW, unsigned magic, int cvb_log2) {
-    constexpr int V = Vec<T>::N, N2 = V / 2;
-    f2 ka[N2], kb[N2], kc[N2];
-    if constexpr (COEF) {
-        lds_row<N2>(cf + vl * V, ka);
-        lds_row<N2>(cf + cvbV + vl * V, kb);
-        lds_row<N2>(cf + 2 * cvbV + vl * V, kc);
-    }
-    const int total = (IH * IW) << cvb_log2;
-    for (int base = threadIdx.x; base < total; base += DFD_THREADS * U) {
-        uint4 r1[U], r2[U];
-        bool inb[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int idx = base + u * DFD_THREADS;
-            const int pix = idx >> cvb_log2;
-            const int iy = (int)(((unsigned)pix * magic) >> 20);
-            const int ix = pix - iy * IW;
-            const int gy = gy0 + iy, gx = gx0 + ix;
-            inb[u] = cvalid && idx < total && (unsigned)gy < (unsigned)SH && (unsigned)gx < (unsigned)SW;
-            if (inb[u]) {
-                const long off = img_base + ((long)gy * SW + gx) * C + c0;
-                r1[u] = *reinterpret_cast<const uint4*>(dz + off);
-                if constexpr (COEF) r2[u] = *reinterpret_cast<const uint4*>(yraw + off);
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int idx = base + u * DFD_THREADS;
-            if (idx >= total) continue;
-            uint4 q = make_uint4(0, 0, 0, 0);
-            if (inb[u]) {
-                if constexpr (!COEF) {
-                    q = r1[u];
-                } else {
-                    f2 a[N2], b[N2];
-                    unpack2(r1[u], a);
-                    unpack2(r2[u], b);
-#pragma unroll
-                    for (int j = 0; j < N2; ++j)
-                        a[j] = __builtin_elementwise_fma(ka[j], a[j], __builtin_elementwise_fma(kb[j], b[j], kc[j]));
-                    q = pack2(a);
-                }
-            }
-            tile[idx] = q;
-        }
-    }
-}
-
 template <typename T, int K, int S, int PLP, int ACT, bool COEF, bool EPI>
 __global__ void __launch_bounds__(DFD_THREADS, 4)
 k_dw_bwd_data_q(const T* __restrict__ dz, const T* __restrict__ yraw, const float* __restrict__ coef,

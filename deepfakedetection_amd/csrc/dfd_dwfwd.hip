@@ -180,7 +180,7 @@ k_dw_fwd_q(const T* __restrict__ x, const float* __restrict__ bnstate, const flo
 static int ilog2p(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 
 bool dfd_dwq_geom(const dfd_dwconv_shape* s, int vec, int max_cvb, bool centre_is_input, size_t extra_lds,
-                  int extra_centre, int lane_div, DwQGeom* g, int* tile_bytes) {
+                  int extra_centre, int lane_div, DwQGeom* g, int* tile_bytes, int halo_tiles, long lds_budget) {
     if (!s || s->N <= 0 || s->H <= 0 || s->W <= 0 || s->Ho <= 0 || s->Wo <= 0 || s->C <= 0 || s->C % 8) return false;
     if (!(s->k == 3 || s->k == 5) || !(s->stride == 1 || s->stride == 2)) return false;
     if (s->pad_top < 0 || s->pad_left < 0 || s->pad_top >= s->k || s->pad_left >= s->k) return false;
@@ -219,8 +219,8 @@ bool dfd_dwq_geom(const dfd_dwconv_shape* s, int vec, int max_cvb, bool centre_i
             const int IH = ext(TH);
             const long px = (long)IH * IW;
             if (px >= 4096) break;
-            const long lds = px * cvb * 16 + (long)extra_lds + (long)TH * TW * cvb * extra_centre;
-            if (lds > 36 * 1024 && !(TH == 1 && QW == 1)) break;
+            const long lds = px * cvb * 16 * halo_tiles + (long)extra_lds + (long)TH * TW * cvb * extra_centre;
+            if (lds > lds_budget && !(TH == 1 && QW == 1)) break;
             const long tiles = (long)((CH + TH - 1) / TH) * ((CW + TW - 1) / TW);
             const long lanes = PL / lane_div > 0 ? PL / lane_div : 1;      // lanes that share the quads of a tile
             const long rounds = ((long)TH * QW + lanes - 1) / lanes;

@@ -91,8 +91,9 @@ template <typename T> __device__ __forceinline__ f2 round2(f2 v) {
 // tile geometry chosen by a small cost model; centre_is_input selects the data-gradient form
 // extra_lds: fixed bytes; extra_centre: bytes per centre pixel per channel vector (second tile);
 // lane_div: pixel lanes are shared by this many roles (weight gradient: K kernel rows)
+// halo_tiles: staged tiles of the halo extent that live in LDS at once (the fused backward stages dy AND the activated input)
 bool dfd_dwq_geom(const dfd_dwconv_shape* s, int vec, int max_cvb, bool centre_is_input, size_t extra_lds,
-                  int extra_centre, int lane_div, DwQGeom* g, int* tile_bytes);
+                  int extra_centre, int lane_div, DwQGeom* g, int* tile_bytes, int halo_tiles = 1, long lds_budget = 36 * 1024);
 
 // stage the input tile: tile[pix][vl] = rnd(act(scale*x+shift)) or x, zero outside the image
 template <typename T, int ACT, bool PRO, int U = 4>
@@ -144,6 +145,59 @@ __device__ __forceinline__ void stage_q(uint4* __restrict__ tile, const T* __res
     }
 }
 
+
+// stage dy = ka*dz + kb*y + kc (or dz as is) for rows gy0.., cols gx0.. of the [SH][SW] dy image
+template <typename T, bool COEF, int U = 4>
+__device__ __forceinline__ void stage_dy(uint4* __restrict__ tile, const T* __restrict__ dz, const T* __restrict__ yraw,
+                                         const float* __restrict__ cf, int cvbV, int vl, long img_base, int SH, int SW, int C,
+                                         int c0, bool cvalid, int gy0, int gx0, int IH, int IW, unsigned magic, int cvb_log2) {
+    constexpr int V = Vec<T>::N, N2 = V / 2;
+    f2 ka[N2], kb[N2], kc[N2];
+    if constexpr (COEF) {
+        lds_row<N2>(cf + vl * V, ka);
+        lds_row<N2>(cf + cvbV + vl * V, kb);
+        lds_row<N2>(cf + 2 * cvbV + vl * V, kc);
+    }
+    const int total = (IH * IW) << cvb_log2;
+    for (int base = threadIdx.x; base < total; base += DFD_THREADS * U) {
+        uint4 r1[U], r2[U];
+        bool inb[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int idx = base + u * DFD_THREADS;
+            const int pix = idx >> cvb_log2;
+            const int iy = (int)(((unsigned)pix * magic) >> 20);
+            const int ix = pix - iy * IW;
+            const int gy = gy0 + iy, gx = gx0 + ix;
+            inb[u] = cvalid && idx < total && (unsigned)gy < (unsigned)SH && (unsigned)gx < (unsigned)SW;
+            if (inb[u]) {
+                const long off = img_base + ((long)gy * SW + gx) * C + c0;
+                r1[u] = *reinterpret_cast<const uint4*>(dz + off);
+                if constexpr (COEF) r2[u] = *reinterpret_cast<const uint4*>(yraw + off);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int idx = base + u * DFD_THREADS;
+            if (idx >= total) continue;
+            uint4 q = make_uint4(0, 0, 0, 0);
+            if (inb[u]) {
+                if constexpr (!COEF) {
+                    q = r1[u];
+                } else {
+                    f2 a[N2], b[N2];
+                    unpack2(r1[u], a);
+                    unpack2(r2[u], b);
+#pragma unroll
+                    for (int j = 0; j < N2; ++j)
+                        a[j] = __builtin_elementwise_fma(ka[j], a[j], __builtin_elementwise_fma(kb[j], b[j], kc[j]));
+                    q = pack2(a);
+                }
+            }
+            tile[idx] = q;
+        }
+    }
+}
 
 
 #define DISPATCH_KS(KV, SV, ...)                                                        \

@@ -299,13 +299,19 @@ class MBConvFunction(torch.autograd.Function):
         kk = geom.kernel
         dw_dw = dx = dw_exp = dg_exp = db_exp = None
         if cfg.expand:
-            dz1, parts, n = K.dwconv_bwd_data(dz2, y2, coef2, w_dw, y1, st1, ACT_SILU, y1.shape, geom.kernel,
-                                              geom.stride, geom.pad_lead, geom.pad_lead)
+            fused = need[4] and K.dwconv_bwd_fused_ok(geom.kernel, geom.stride)
+            if fused:
+                # 3x3 stride 1: data and weight gradient from one staging of (dz2, y2, y1) — csrc/dfd_dwbwdf.hip
+                dz1, parts, n, dw_dw = K.dwconv_bwd_fused(dz2, y2, coef2, w_dw, y1, st1, ACT_SILU, geom.kernel, geom.stride,
+                                                          geom.pad_lead, geom.pad_lead, _dest(ctx, 4, (Cmid, 1, kk, kk)))
+            else:
+                dz1, parts, n = K.dwconv_bwd_data(dz2, y2, coef2, w_dw, y1, st1, ACT_SILU, y1.shape, geom.kernel,
+                                                  geom.stride, geom.pad_lead, geom.pad_lead)
             coef1, dg_exp, db_exp = K.bn_bwd_finalize(parts, n, N * H * W, g_exp, st1, tr, need[2] or need[3],
                                                       _dest(ctx, 2, (Cmid,)), _dest(ctx, 3, (Cmid,)))
             pro_dy1 = K.pro_affine2(y1, coef1)
             with K.side_stream(N * Ho * Wo):
-                if need[4]:
+                if need[4] and not fused:
                     dw_dw = K.dwconv_bwd_weight(dz2, y2, coef2, y1, st1, ACT_SILU, geom.kernel, geom.stride,
                                                 geom.pad_lead, geom.pad_lead, _dest(ctx, 4, (Cmid, 1, kk, kk)))
                 if need[1]:

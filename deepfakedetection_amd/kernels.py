@@ -546,6 +546,37 @@ def dwconv_bwd_weight(dz: torch.Tensor, y: torch.Tensor | None, coef: torch.Tens
     return dw
 
 
+# measured on MI355X: the fused kernel takes 176 us where the two separate kernels take 73 + 91 us on
+# EfficientFormerV2-S1 (19.6 vs 19.3 ms/step) and is neutral on EfficientNet-B0: the two phases are issue-bound, not bandwidth-
+# bound, so sharing the staging buys less than the larger working set costs.  Kept (tested) behind DFD_FUSE_DW_BWD=1.
+_FUSE_DW_BWD = os.environ.get("DFD_FUSE_DW_BWD", "0") == "1"
+
+
+def dwconv_bwd_fused_ok(k: int, stride: int) -> bool:
+    """The one-kernel backward (csrc/dfd_dwbwdf.hip) covers 3x3 stride-1 layers."""
+    return _FUSE_DW_BWD and k == 3 and stride == 1
+
+
+def dwconv_bwd_fused(dz: torch.Tensor, y: torch.Tensor, coef: torch.Tensor, w: torch.Tensor, xin: torch.Tensor,
+                     in_state: torch.Tensor, in_act: int, k: int, stride: int, pad_top: int, pad_left: int,
+                     out_w: torch.Tensor | None = None):
+    """dwconv_bwd_data (with its epilogue) and dwconv_bwd_weight (with its prologue) from ONE staging of (dz, y, xin).
+    Returns (dzin, partials, nparts, dw)."""
+    N, H, W, C = xin.shape
+    Ho, Wo = dz.shape[1], dz.shape[2]
+    shp = _dw_shape(xin.shape, Ho, Wo, k, stride, pad_top, pad_left)
+    dzin = torch.empty((N, H, W, C), dtype=dz.dtype, device=dz.device)
+    parts = partials_buf(dz.device, C)
+    nbytes = _L().dfd_dwconv_bwd_weight_ws(ctypes.byref(shp))
+    ws = scratch(dz.device, "wgrad_ws", nbytes)
+    dw = _dst(out_w, (C, 1, k, k), dz.device)
+    n = ctypes.c_int(0)
+    check(_L().dfd_dwconv_bwd_fused(_dt(dz), _p(dz), _p(y), _p(coef), _p(w), _p(xin), _p(in_state), in_act, _p(dzin), _p(dw),
+                                    ctypes.byref(shp), _p(parts), MAX_PARTIALS, ctypes.byref(n), 0, _p(ws), ws.numel() * 4, _stream()),
+          "dfd_dwconv_bwd_fused", f"{tuple(xin.shape)} k{k}s{stride}")
+    return dzin, parts, n.value, dw
+
+
 # ------------------------------------------------------------------ pointwise
 def _pro(mode: int = PRO_NONE, act: int = ACT_NONE, HW: int = 1, a2=None, coef=None, gate=None) -> Prologue:
     pr = Prologue(mode, act, HW, 0, _p(a2), _p(coef), _p(gate))
@@ -1382,7 +1413,7 @@ class DeviceRng:
 # the DESIGN.md per-kernel figure, not counter traffic.
 _profile_sink: list | None = None
 _TIMED = ("bn_act_apply", "bn_bwd_reduce", "act_bn_bwd", "pool_act", "pool_bwd_reduce", "scale_rows", "dwconv_fwd",
-          "dwconv_bwd_data", "dwconv_bwd_weight", "pwconv", "pwconv_wgrad", "stem_conv_fwd", "stem_conv_wgrad",
+          "dwconv_bwd_data", "dwconv_bwd_weight", "dwconv_bwd_fused", "pwconv", "pwconv_wgrad", "stem_conv_fwd", "stem_conv_wgrad",
           "se_fc_fwd", "se_fc_bwd", "linear_fwd", "linear_bwd", "ce_loss", "adamw_step", "prep_weights", "bn_finalize",
           "bn_bwd_finalize", "bn_bwd_finalize_ex", "dropout", "bgemm", "attn_softmax_fwd", "attn_softmax_bwd", "im2col", "col2im",
           "wattn_fwd", "wattn_bwd", "mx_quant_rows", "mx_gemm",

@@ -416,12 +416,16 @@ class ConvMlpFunction(torch.autograd.Function):
         nbd = need[7] or need[8]
         outs = (_slot(gd, nbd, (Cm,)), _slot(bed, nbd, (Cm,)), None, _slot(bd, need[6], (Cm,)))
         coef2, dgd, dbed, _, dbd = K.bn_bwd_finalize_ex(parts, n, rows, gd, bed, None, st2, tr, nbd, False, need[6], outs)
-        dz1, parts, n = K.dwconv_bwd_data(dz2, y2, coef2, wd, y1, st1, ACT_GELU, tuple(y1.shape), 3, 1, 1, 1)
+        dwd = None
+        fused = need[5] and K.dwconv_bwd_fused_ok(3, 1)
+        if fused:       # data and weight gradient from one staging of (dz2, y2, y1): csrc/dfd_dwbwdf.hip
+            dz1, parts, n, dwd = K.dwconv_bwd_fused(dz2, y2, coef2, wd, y1, st1, ACT_GELU, 3, 1, 1, 1, _slot(wd, True, (Cm, 1, 3, 3)))
+        else:
+            dz1, parts, n = K.dwconv_bwd_data(dz2, y2, coef2, wd, y1, st1, ACT_GELU, tuple(y1.shape), 3, 1, 1, 1)
         nb1 = need[3] or need[4]
         outs = (_slot(g1, nb1, (Cm,)), _slot(be1, nb1, (Cm,)), None, _slot(b1, need[2], (Cm,)))
         coef1, dg1, dbe1, _, db1 = K.bn_bwd_finalize_ex(parts, n, rows, g1, be1, None, st1, tr, nb1, False, need[2], outs)
-        dwd = None
-        if need[5]:
+        if need[5] and not fused:
             dwd = K.dwconv_bwd_weight(dz2, y2, coef2, y1, st1, ACT_GELU, 3, 1, 1, 1, _slot(wd, True, (Cm, 1, 3, 3)))
         pro1 = K.pro_affine2(y1, coef1)
         dw1 = dx = None

@@ -72,7 +72,7 @@ typedef void* dfd_stream;          /* a hipStream_t */
  * 112 = the eval / inference form of the MBConv block: dfd_pwconv_fwd_eval, dfd_dwconv_fwd_eval(_tiles),
  * dfd_se_fwd_parts;
  * 120 = MX fp8 weights (dfd_mx_*), fused window attention on bf16 MFMA (dfd_wattn_*),
- * batched coordinate MLPs (dfd_coord_mlp_*_multi, dfd_relpos_bias_*_multi). */
+ * batched coordinate MLPs (dfd_coord_mlp_*_multi, dfd_relpos_bias_*_multi), dfd_dwconv_bwd_fused. */
 int dfd_version(void);
 
 /* Batched final summation of weight gradients.  The weight-gradient entry points whose result goes straight to the
@@ -244,6 +244,14 @@ int dfd_se_fwd_parts(const float* parts, int splits, int N, int HW, int C, const
                      const float* w2, const float* b2, int R, int act, float* pooled, float* hpre, float* gate,
                      float* w2t, dfd_stream stream);
 size_t dfd_dwconv_bwd_weight_ws(const dfd_dwconv_shape* s);
+/* Data gradient AND weight gradient of a 3x3 stride-1 depthwise convolution in one kernel (dfd_dwconv_bwd_data with its
+ * epilogue + dfd_dwconv_bwd_weight with its prologue, same arguments): dz / y / xin cross HBM once instead of twice.
+ * ws as for dfd_dwconv_bwd_weight (dfd_dwconv_bwd_weight_ws bytes).  DFD_EUNSUPPORTED for other kernel sizes / strides:
+ * callers then use the two separate entry points.                                                                      */
+int dfd_dwconv_bwd_fused(int dtype, const void* dz, const void* y, const float* coef, const float* w, const void* xin,
+                         const float* in_bnstate, int in_act, void* dzin, float* dw, const dfd_dwconv_shape* s,
+                         float* partials, int pcap, int* nparts, int accumulate, float* ws, size_t ws_bytes,
+                         dfd_stream stream);
 
 /* ----------------------------------------------------------- pointwise conv ---
  * 1x1 convolutions (_expand_conv, _project_conv, _conv_head; timm conv_pw/conv_pwl/

@@ -67,6 +67,9 @@ DW_CASES = [
     (2, 7, 7, 1152, 5, 1, 2, 2),
     (1, 56, 56, 96, 3, 2, 1, 1),     # timm symmetric stride 2
     (3, 9, 9, 8, 3, 1, 1, 1),        # smallest channel count
+    (5, 56, 56, 144, 3, 1, 1, 1),    # several tiles per image, channel chunks sharing cache lines (B0 block 2)
+    (4, 7, 7, 896, 3, 1, 1, 1),      # EfficientFormerV2 stage 3 ConvMlp
+    (2, 29, 31, 192, 3, 1, 1, 1),    # ragged tile edges
 ]
 
 
@@ -125,6 +128,14 @@ def test_dwconv_bwd(case, rd):
     close(dzin2, R.rnd(da2, rd), tol(rd), "dwconv_bwd_data plain")
     got_dw = K.dwconv_bwd_weight(dev(dz), dev(yraw), dev(coef), dev(xin), dev(st), R.ACT_SILU, k, s, pt, pl)
     close(got_dw, dw, 5e-3 if rd == torch.bfloat16 else 2e-4, "dwconv_bwd_weight")
+    if k == 3 and s == 1:
+        # the one-kernel form (csrc/dfd_dwbwdf.hip): same per-element arithmetic -> dzin bit for bit; its sums follow its own tiling
+        fz, fparts, fn, fdw = K.dwconv_bwd_fused(dev(dz), dev(yraw), dev(coef), dev(w), dev(xin), dev(st), R.ACT_SILU, k, s, pt, pl)
+        assert torch.equal(fz, dzin), "fused data gradient differs from the two-kernel path"
+        close(sum_parts(fparts, fn, C), want_sums, 2e-3, "dwconv_bwd_fused stats")
+        close(fdw, dw, 5e-3 if rd == torch.bfloat16 else 2e-4, "dwconv_bwd_fused weight gradient")
+        fz2, _, _, fdw2 = K.dwconv_bwd_fused(dev(dz), dev(yraw), dev(coef), dev(w), dev(xin), dev(st), R.ACT_SILU, k, s, pt, pl)
+        assert torch.equal(fz, fz2) and torch.equal(fdw, fdw2), "fused backward is not reproducible"
 
 
 PW_CASES = [
