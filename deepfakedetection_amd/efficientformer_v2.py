@@ -113,8 +113,46 @@ class HipConvMlp(nn.Module):
         self.fc2 = ConvNorm(hidden, dim, 1)
 
     def run(self, x, ls: LayerScale2d, row_scale, training: bool, counters, derived=None) -> torch.Tensor:
+        from .hooks import has_hooks
+
+        if has_hooks(self.fc2.conv):
+            return self._hooked_run(x, ls, training)
         cfg = ConvMlpCtx(_bnref(self.fc1.bn), _bnref(self.mid.bn), _bnref(self.fc2.bn), training, counters, derived)
         return ConvMlpFunction.apply(x, *self.fc1.tensors(), *self.mid.tensors(), *self.fc2.tensors(), ls.gamma, row_scale, cfg)
+
+    def _hooked_run(self, x, ls: LayerScale2d, training: bool) -> torch.Tensor:
+        """Forward hooks on fc2's convolution (Grad-CAM's "last nn.Conv2d" for this family, web_ui.py:95-114): the MLP runs
+        unfused in eval mode so that the hooks see (module, (input,), output) as NCHW tensors and the output is wired to the
+        logits:  a = GELU(BN(dw(GELU(BN(fc1 x)))))  [no graph]  ->  y = conv(a) + bias  [hooked]  ->  x + ls * BN(y)."""
+        from . import kernels as K
+        from ._lib import ACT_GELU, ACT_NONE
+        from .functions import HeadConvFunction, _bn_state
+        from .hooks import ChannelAffineFunction, call_hooks
+
+        if training:
+            raise NotImplementedError("forward hooks on mlp.fc2.conv are supported in eval mode only (the training path "
+                                      "keeps the whole ConvMlp in one fused stage)")
+        N, H, W, C = x.shape
+        rows = N * H * W
+        w1, b1, g1, be1 = self.fc1.tensors()
+        wd, bd, gd, bed = self.mid.tensors()
+        w2, b2, g2, be2 = self.fc2.tensors()
+        with torch.no_grad():
+            w1_nk, _ = K.prep_weights(w1, x.dtype, True, False)
+            y1, _, _ = K.pwconv(x, None, w1_nk, None, stats=False)
+            st1 = _bn_state(None, 0, rows, _bnref(self.fc1.bn), g1, be1, False, None, conv_bias=b1)
+            y2, _, _ = K.dwconv_fwd(y1, st1, ACT_GELU, wd, 3, 1, 1, 1, H, W, stats=False)
+            st2 = _bn_state(None, 0, rows, _bnref(self.mid.bn), gd, bed, False, None, conv_bias=bd)
+            a = K.bn_act_apply(y2, st2, ACT_GELU)
+            bn = self.fc2.bn
+            scale = g2 / torch.sqrt(bn.running_var + bn.eps)
+            shift = be2 - bn.running_mean * scale
+            ones = torch.ones_like(scale)
+            bias = b2 if b2 is not None else torch.zeros_like(scale)
+        y = HeadConvFunction.apply(a, w2)                                   # raw 1x1 convolution, NHWC
+        y = ChannelAffineFunction.apply(y, ones, bias, None)                # + conv bias: what the module's forward returns
+        y = call_hooks(self.fc2.conv, a, y)
+        return ChannelAffineFunction.apply(y, (ls.gamma * scale).detach(), (ls.gamma * shift).detach(), x.detach())
 
 
 class HipBlock(nn.Module):

@@ -216,7 +216,25 @@ class HipTokenInitializer(nn.Module):
         self.to_global_feature = to_global
 
     def forward(self, x):
+        from .hooks import has_hooks
+
+        if has_hooks(self.pos_embed):
+            return self._hooked_forward(x)
         return TokenInitFunction.apply(x, self.pos_embed.weight, self.pos_embed.bias, self.kernel, self.stride)
+
+    def _hooked_forward(self, x):
+        """Forward hooks on `pos_embed` (Grad-CAM's "last nn.Conv2d" of FasterViT, web_ui.py:95-114): the depthwise
+        convolution runs as its own stage so that its output (+ bias, NCHW) is an autograd tensor wired to the logits
+        through the average pool; eval mode only."""
+        from .hooks import AvgPoolFunction, DwConvOutFunction, call_hooks
+
+        if self.training:
+            raise NotImplementedError("forward hooks on global_tokenizer.pos_embed are supported in eval mode only")
+        xd = x.detach()
+        y = DwConvOutFunction.apply(xd, self.pos_embed.weight, self.pos_embed.bias)
+        y = call_hooks(self.pos_embed, xd, y)
+        p = AvgPoolFunction.apply(y, self.kernel, self.stride)
+        return p.reshape(p.shape[0], p.shape[1] * p.shape[2], 1, p.shape[3])
 
 
 def _window_maps(B: int, res: int, device: torch.device):

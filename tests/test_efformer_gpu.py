@@ -247,3 +247,59 @@ def test_refuses_cpu_and_wrong_resolution():
         m(torch.zeros(1, 3, 224, 224))
     with pytest.raises(ValueError, match="224x224"):
         m.cuda()(torch.zeros(1, 3, 192, 192).cuda())
+
+
+def test_grad_cam_hooks_on_the_last_conv2d():
+    """web_ui.py:95-114: without a `_conv_head` the Grad-CAM target is the LAST nn.Conv2d of model.modules() — for
+    EfficientFormerV2 `stages.3.blocks.<last>.mlp.fc2.conv`, a convolution in the middle of a fused stage.  With forward
+    hooks on it the HIP module runs that MLP unfused (eval mode): the hook sees the conv output (NCHW, bias included) and
+    its gradient with respect to a class logit; both must match the oracle's."""
+    import torch.nn.functional as F
+
+    ref, hip = make_pair("s1", 2, 224, seed=4)
+    ref.eval(); hip.eval()
+    last = lambda m: [c for c in m.modules() if isinstance(c, torch.nn.Conv2d)][-1]     # noqa: E731 - web_ui._find_last_conv_layer
+    names = {id(c): n for n, c in hip.named_modules()}
+    assert names[id(last(hip))] == "stages.3.blocks.5.mlp.fc2.conv"
+    # the oracle's ConvBN calls F.conv2d on the weights: route this one through the module so that its hooks fire
+    fc2 = ref.stages[3].blocks[-1].mlp.fc2
+
+    def via_module(x):
+        y = fc2.conv(x)
+        return F.batch_norm(y, fc2.bn.running_mean, fc2.bn.running_var, fc2.bn.weight, fc2.bn.bias, False, fc2.bn.momentum, fc2.bn.eps)
+
+    fc2.forward = via_module
+    kept = {}
+
+    def make_hook(tag):
+        def hook(module, inputs, output):
+            kept[tag + "_in"] = inputs[0]
+            kept[tag + "_act"] = output
+            if output.requires_grad:
+                output.register_hook(lambda grad: kept.__setitem__(tag + "_grad", grad))
+        return hook
+
+    x = torch.randn(2, 3, 224, 224, generator=torch.Generator().manual_seed(12))
+    h1 = last(ref).register_forward_hook(make_hook("ref"))
+    h2 = last(hip).register_forward_hook(make_hook("hip"))
+    try:
+        ref_logits = ref(x)
+        ref_logits[:, 1].sum().backward()
+        hip_logits = hip(x.cuda())
+        hip_logits[:, 1].sum().backward()
+    finally:
+        h1.remove(); h2.remove()
+    assert rel_err(hip_logits, ref_logits) <= 1e-3
+    assert tuple(kept["hip_act"].shape) == tuple(kept["ref_act"].shape) == (2, 224, 7, 7)
+    assert rel_err(kept["hip_in"], kept["ref_in"]) <= 1e-3
+    assert rel_err(kept["hip_act"], kept["ref_act"]) <= 1e-3
+    assert rel_err(kept["hip_grad"], kept["ref_grad"]) <= 2e-3
+    with torch.no_grad():
+        assert rel_err(hip(x.cuda()), ref_logits) <= 1e-3                 # hooks gone: the fused stage is back
+    hip.train()
+    h3 = last(hip).register_forward_hook(make_hook("t"))
+    try:
+        with pytest.raises(NotImplementedError):
+            hip(x.cuda())
+    finally:
+        h3.remove()

@@ -272,3 +272,39 @@ def test_batched_eval_coefficients_replay_equals_per_layer_path():
         b = hip(x)                          # replays them
     assert torch.isfinite(a).all() and torch.isfinite(b).all()
     assert (True, torch.bfloat16) in hip.__dict__["_bn_eval_batches"]
+
+
+def test_grad_cam_hooks_on_the_last_conv2d():
+    """web_ui.py:95-114 targets the last nn.Conv2d of model.modules(): for FasterViT that is the depthwise
+    `levels.2.global_tokenizer.pos_embed` (level 3 has no convolution).  With forward hooks on it the tokenizer runs
+    unfused in eval mode; activation (NCHW, bias included) and its gradient with respect to a logit match the oracle's."""
+    ref, hip = make_pair("0", 2, seed=6)
+    ref.eval(); hip.eval()
+    last = lambda m: [c for c in m.modules() if isinstance(c, torch.nn.Conv2d)][-1]     # noqa: E731
+    names = {id(c): n for n, c in hip.named_modules()}
+    assert names[id(last(hip))].endswith("global_tokenizer.pos_embed") or names[id(last(hip))].endswith("to_global_feature.pos")
+    kept = {}
+
+    def make_hook(tag):
+        def hook(module, inputs, output):
+            kept[tag + "_act"] = output
+            if output.requires_grad:
+                output.register_hook(lambda grad: kept.__setitem__(tag + "_grad", grad))
+        return hook
+
+    x = torch.randn(2, 3, 224, 224, generator=torch.Generator().manual_seed(13))
+    h1 = last(ref).register_forward_hook(make_hook("ref"))
+    h2 = last(hip).register_forward_hook(make_hook("hip"))
+    try:
+        ref_logits = ref(x)
+        ref_logits[:, 1].sum().backward()
+        hip_logits = hip(x.cuda())
+        hip_logits[:, 1].sum().backward()
+    finally:
+        h1.remove(); h2.remove()
+    assert rel_err(hip_logits, ref_logits) <= 1e-3
+    assert tuple(kept["hip_act"].shape) == tuple(kept["ref_act"].shape) == (2, 256, 14, 14)
+    assert rel_err(kept["hip_act"], kept["ref_act"]) <= 1e-3
+    assert rel_err(kept["hip_grad"], kept["ref_grad"]) <= 2e-3
+    with torch.no_grad():
+        assert rel_err(hip(x.cuda()), ref_logits) <= 1e-3
