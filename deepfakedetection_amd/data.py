@@ -233,6 +233,83 @@ class ToUint8HWC:
         return torch.from_numpy(np.array(img.convert("RGB"), dtype=np.uint8))       # np.array: a writable copy
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# Resize / crop on the device (csrc/dfd_resize.hip).  The worker decodes the file and PLANS the
+# geometric transform — same decisions, same RNG calls as the PIL transforms above — but leaves the pixels alone; the batch
+# crosses PCIe as the decoded uint8 images packed back to back plus one 56-byte descriptor per image, and ONE kernel resizes
+# and crops every image, bit-exact with Pillow's bilinear `Image.resize`.
+_JOB_DTYPE = np.dtype([("offset", "<i8"), ("H", "<i4"), ("W", "<i4"), ("bx", "<i4"), ("by", "<i4"), ("bw", "<i4"), ("bh", "<i4"),
+                       ("rw", "<i4"), ("rh", "<i4"), ("cx", "<i4"), ("cy", "<i4"), ("_p0", "<i4"), ("_p1", "<i4")])
+assert _JOB_DTYPE.itemsize == 56            # struct dfd_resize_job (include/dfd_hip.h)
+
+
+def plan_resize(w: int, h: int, size: int | tuple[int, int] | None) -> tuple[int, int]:
+    """(new width, new height) of `Resize(size)` applied to a w x h image (None: unchanged)."""
+    if size is None:
+        return w, h
+    if isinstance(size, int):
+        short, long = (w, h) if w <= h else (h, w)
+        if short == size:
+            return w, h
+        new_short, new_long = size, int(size * long / short)
+        return (new_short, new_long) if w <= h else (new_long, new_short)
+    return size[1], size[0]
+
+
+def plan_window(rw: int, rh: int, th: int, tw: int, *, random: bool) -> tuple[int, int]:
+    """Origin (cx, cy) of the th x tw crop window in a rw x rh image after `_pad_to` — CenterCrop (random=False) or
+    RandomCrop; negative when the image had to be padded (the kernel writes zeros there, as the black canvas does)."""
+    pw, ph = max(rw, tw), max(rh, th)
+    pad_left, pad_top = (pw - rw) // 2, (ph - rh) // 2
+    if random:
+        top = int(torch.randint(0, ph - th + 1, (1,)).item())
+        left = int(torch.randint(0, pw - tw + 1, (1,)).item())
+    else:
+        top, left = int(round((ph - th) / 2.0)), int(round((pw - tw) / 2.0))
+    return left - pad_left, top - pad_top
+
+
+class PlanGeometry:
+    """Stand-in for [Resize] -> [CenterCrop | RandomCrop] or RandomResizedCrop at the end of a worker pipeline: returns
+    (uint8 [H, W, 3] tensor of the DECODED image, int64 plan [bx, by, bw, bh, rw, rh, cx, cy, OH, OW]).
+    mode: "center" (Resize(resize) + CenterCrop(out)), "random" (Resize(resize) + RandomCrop(out)), "rrc" (RandomResizedCrop)."""
+
+    def __init__(self, mode: str, out: int, resize: int | None = None, rrc: "RandomResizedCrop | None" = None) -> None:
+        if mode not in ("center", "random", "rrc") or (mode == "rrc") != (rrc is not None):
+            raise ValueError("PlanGeometry: mode is center | random | rrc (the last one with its RandomResizedCrop)")
+        self.mode, self.out, self.resize, self.rrc = mode, out, resize, rrc
+
+    def __call__(self, img: Image.Image):
+        img = img.convert("RGB")
+        w, h = img.size
+        if self.mode == "rrc":
+            bx, by, bw, bh = self.rrc._box(w, h)
+            plan = (bx, by, bw, bh, self.out, self.out, 0, 0)
+        else:
+            rw, rh = plan_resize(w, h, self.resize)
+            cx, cy = plan_window(rw, rh, self.out, self.out, random=self.mode == "random")
+            plan = (0, 0, w, h, rw, rh, cx, cy)
+        return torch.from_numpy(np.array(img, dtype=np.uint8)), torch.tensor([*plan, self.out, self.out], dtype=torch.int64)
+
+
+def collate_raw(batch):
+    """[((uint8 HWC, plan), label), ...] -> ((flat uint8 bytes, job bytes, meta int64 [OH, OW, max_shrink]), labels)."""
+    imgs = [item[0][0] for item in batch]
+    plans = torch.stack([item[0][1] for item in batch]).numpy()
+    labels = torch.tensor([item[1] for item in batch], dtype=torch.int64)
+    jobs = np.zeros(len(batch), dtype=_JOB_DTYPE)
+    at, shrink = 0, 1
+    for i, (im, pl) in enumerate(zip(imgs, plans)):
+        H, W = int(im.shape[0]), int(im.shape[1])
+        bx, by, bw, bh, rw, rh, cx, cy = (int(v) for v in pl[:8])
+        jobs[i] = (at, H, W, bx, by, bw, bh, rw, rh, cx, cy, 0, 0)
+        at += H * W * 3
+        shrink = max(shrink, -(-bw // rw), -(-bh // rh))
+    flat = torch.cat([im.reshape(-1) for im in imgs])
+    meta = torch.tensor([int(plans[0][8]), int(plans[0][9]), shrink], dtype=torch.int64)
+    return (flat, torch.from_numpy(jobs.view(np.uint8).copy()), meta), labels
+
+
 class GpuInputTail:
     """RandomHorizontalFlip -> ToTensor -> Normalize -> RandomErasing(value=0) on the device, for a uint8
     NHWC batch.  The random decisions use the same distributions and the same
@@ -270,6 +347,15 @@ class GpuInputTail:
     def __call__(self, batch_u8: torch.Tensor, device) -> torch.Tensor:
         from . import kernels as K
 
+        if isinstance(batch_u8, (tuple, list)):          # collate_raw: decoded images + plans -> resize / crop on the device
+            flat, jobs, meta = batch_u8
+            oh, ow, shrink = (int(v) for v in meta)
+            n = jobs.numel() // _JOB_DTYPE.itemsize
+            flip, erase = self.sample(n, oh, ow)
+            dev = K.resize_crop_u8(flat.to(device, non_blocking=True), jobs.to(device, non_blocking=True), n, oh, ow, shrink)
+            return K.image_prep(dev, self.mean, self.std,
+                                flip.to(device, non_blocking=True) if flip is not None else None,
+                                erase.to(device, non_blocking=True) if erase is not None else None)
         if batch_u8.dim() != 4 or batch_u8.shape[3] != 3 or batch_u8.dtype != torch.uint8:
             raise ValueError("GpuInputTail expects a uint8 [N, H, W, 3] batch (ToUint8HWC at the end of the CPU pipeline)")
         n, h, w, _ = batch_u8.shape

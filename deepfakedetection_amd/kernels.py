@@ -403,6 +403,17 @@ def scale_rows(x: torch.Tensor, row_scale: torch.Tensor) -> torch.Tensor:
 
 
 # ------------------------------------------------------------------ input tail
+def resize_crop_u8(flat_u8: torch.Tensor, jobs_u8: torch.Tensor, n: int, oh: int, ow: int, max_shrink: int) -> torch.Tensor:
+    """Decoded uint8 RGB images packed back to back (`flat_u8`) + n 56-byte dfd_resize_job descriptors (`jobs_u8`, uint8 view)
+    -> uint8 [n, oh, ow, 3]: Pillow-exact bilinear resize of each image's box, cropped to the output window."""
+    if flat_u8.dtype != torch.uint8 or jobs_u8.dtype != torch.uint8 or jobs_u8.numel() != 56 * n:
+        raise ValueError("resize_crop_u8: expected uint8 pixel bytes and n 56-byte job descriptors")
+    out = torch.empty((n, oh, ow, 3), dtype=torch.uint8, device=flat_u8.device)
+    check(_L().dfd_resize_crop_u8(_p(flat_u8), _p(jobs_u8), _p(out), n, oh, ow, int(max_shrink), _stream()), "dfd_resize_crop_u8",
+          f"n={n} out={oh}x{ow} shrink<={max_shrink}")
+    return out
+
+
 def image_prep(src_u8: torch.Tensor, mean, std, flip: torch.Tensor | None, erase: torch.Tensor | None) -> torch.Tensor:
     """uint8 [N, H, W, 3] on the device -> f32, returned as an [N, 3, H, W] channels_last view of the
     NHWC result (zero-copy: exactly what HipEfficientNet.forward turns back into NHWC)."""

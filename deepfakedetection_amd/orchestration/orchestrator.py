@@ -163,7 +163,7 @@ _TRAIN_ENV = (("batch_size", "BATCH_SIZE"), ("epochs", "EPOCHS"), ("num_workers"
               ("weight_decay", "WEIGHT_DECAY"), ("accum_steps", "ACCUM_STEPS"), ("warmup_epochs", "WARMUP_EPOCHS"),
               ("early_stop_patience", "EARLY_STOP_PATIENCE"))
 _EXTRA_TRAIN_ENV = (("ft_batch_size", "FT_BATCH_SIZE"), ("pretrained", "PRETRAINED"), ("gpu_input_tail", "GPU_INPUT_TAIL"),
-                    ("graph_step", "GRAPH_STEP"), ("fp8_weights", "FP8_WEIGHTS"))
+                    ("graph_step", "GRAPH_STEP"), ("fp8_weights", "FP8_WEIGHTS"), ("gpu_resize", "GPU_RESIZE"))
 
 
 def _first_set(*values: Any) -> Any:
@@ -282,8 +282,14 @@ def load_model(model_name: str, num_classes: int, weights_path: Path | None, dev
     return model
 
 
+_GPU_EVAL_TAIL = D.GpuInputTail(IMAGENET_MEAN, IMAGENET_STD)
+
+
 def build_inference_loader(*, dataset, batch_size: int, num_workers: int) -> DataLoader:
     extra = {"prefetch_factor": 2} if num_workers > 0 else {}
+    tf = getattr(dataset, "transform", None)
+    if tf is not None and any(isinstance(op, D.PlanGeometry) for op in getattr(tf, "ops", ())):
+        extra["collate_fn"] = D.collate_raw         # device-side resize: decoded images + plans (data.PlanGeometry)
     return DataLoader(dataset, batch_size=batch_size, shuffle=False, num_workers=num_workers, pin_memory=True,
                       persistent_workers=num_workers > 0, **extra)
 
@@ -292,6 +298,8 @@ def class_probabilities(model: nn.Module, images: torch.Tensor, device: torch.de
     """logits -> (softmax probabilities, arg-max) for one batch (orchestrator.py:589-592).  amp: run the forward in a
     bf16 autocast region (opt-in `inference.amp: bf16`; the reference's inference is f32, which stays the default)."""
     with torch.inference_mode(), torch.autocast(device_type=device.type, dtype=torch.bfloat16, enabled=amp and device.type == "cuda"):
+        if isinstance(images, (tuple, list)):          # data.collate_raw batch: resize / crop / normalise on the device
+            images = _GPU_EVAL_TAIL(images, device)
         logits = model(images.to(device, non_blocking=True))
         if logits.is_cuda:
             from .. import kernels  # HIP softmax/argmax epilogue
@@ -415,6 +423,10 @@ def _run_inference_job(*, config_path: Path, config: dict[str, Any], model_cfg: 
     if str(infer_cfg.get("fp8_weights", "")).lower() in ("1", "true", "yes", "on") and hasattr(model, "fp8_weights"):
         model.fp8_weights = True       # extra key (FasterViT, with `amp: bf16`): Linear weights as MX fp8 on the scaled fp8 MFMA
     transform = build_eval_transforms(image_size, toggles=resolve_transform_mapping(model_cfg, phase="eval"))
+    if str(infer_cfg.get("gpu_resize", "")).lower() in ("1", "true", "yes", "on") and device.type == "cuda":
+        # extra key: the workers only decode; Resize + CenterCrop + ToTensor + Normalize run on the device (bit-exact with the
+        # PIL pipeline above, tests/test_ops_gpu.py::test_resize_crop_matches_pillow_bit_for_bit).  Default toggles only.
+        transform = D.Compose([D.Lambda(_to_rgb), D.PlanGeometry("center", image_size, image_size)])
     root = Path(data_cfg.get("root")).expanduser()
     if not root.is_absolute():
         root = (Path.cwd() / root).resolve()

@@ -205,7 +205,8 @@ def run(spec: TrainerSpec) -> None:  # noqa: PLR0915
         console.print(f"Expected: {data_root}/{train_split}/<class> and {data_root}/{val_split}/<class>")
         raise SystemExit(1)
     try:
-        gpu_tail = use_cuda and env_str("GPU_INPUT_TAIL", "0").lower() in {"1", "true", "yes"}
+        gpu_tail = use_cuda and (env_str("GPU_INPUT_TAIL", "0").lower() in {"1", "true", "yes"}
+                                 or env_str("GPU_RESIZE", "0").lower() in {"1", "true", "yes"})     # device resize implies the device tail
         train_dl, val_dl, *tails = _base.get_loaders(data_root, train_split, val_split, img_size, batch_size, num_workers,
                                                      expected_classes=num_classes, rank=rank, world=world, seed=env.seed or 0,
                                                      gpu_tail=gpu_tail, transform_kwargs=spec.transform_kwargs)

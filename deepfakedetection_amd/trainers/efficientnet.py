@@ -67,13 +67,17 @@ class EvalResult:
 
 
 def build_transforms(img_size: int, gpu_tail: bool = False, *, rotation_default: bool | None = None,
-                     erasing_default: bool | None = None, jitter=(0.2, 0.2, 0.2, 0.05), rotation_after_flip: bool = False):
+                     erasing_default: bool | None = None, jitter=(0.2, 0.2, 0.2, 0.05), rotation_after_flip: bool = False,
+                     gpu_resize: bool = False):
     """(train, val) pipelines from the toggle defaults of the reference + $TRANSFORMS.
     gpu_tail=True: the pipelines end in uint8 HWC tensors and (train, val, train_tail, val_tail) is
     returned, the tails being `D.GpuInputTail`s that do flip / to-float / normalise / erasing on the GPU.
     The keyword arguments carry what differs between the reference's three trainers (efficientnet.py:128-187 vs
     efficientformer_v2.py:105-165 / fastervit.py:119-180): rotation / erasing off by default, ColorJitter 0.1,
-    rotation placed after the horizontal flip."""
+    rotation placed after the horizontal flip.
+    gpu_resize (with gpu_tail): Resize / CenterCrop / RandomCrop / RandomResizedCrop move onto the device as well
+    (D.PlanGeometry + csrc/dfd_resize.hip, bit-exact with PIL): always for the validation pipeline, and for the training
+    pipeline when nothing between the crop and ToTensor needs a PIL image (no rotation, no colour jitter)."""
     small = img_size <= 64
     toggles = load_transform_toggles(
         {
@@ -115,7 +119,22 @@ def build_transforms(img_size: int, gpu_tail: bool = False, *, rotation_default:
             train.append(D.RandomHorizontalFlip())
         if on("train_random_rotation", False):
             train.append(D.RandomRotation(10))
-    if gpu_tail:
+    train_on_gpu = (gpu_tail and gpu_resize and not on("train_random_rotation", False) and not on("train_color_jitter", False))
+    if train_on_gpu:
+        # the geometric head of the pipeline as a PLAN (same decisions, same RNG calls), pixels untouched
+        train = [D.Lambda(_rgb)] if on("ensure_rgb", True) else []
+        if small:
+            mode = "random" if on("train_random_crop", True) else "center"
+            train.append(D.PlanGeometry(mode, img_size, img_size + 4 if on("train_resize", True) else None))
+        elif on("train_random_resized_crop", True):
+            train.append(D.PlanGeometry("rrc", img_size, rrc=D.RandomResizedCrop(img_size, scale=(0.9, 1.0))))
+        else:
+            train.append(D.PlanGeometry("center", img_size, enlarged if on("train_resize", True) else None))
+        train_tail = D.GpuInputTail(mean if on("train_normalize", True) else [0.0] * 3,
+                                    std if on("train_normalize", True) else [1.0] * 3,
+                                    flip_p=0.5 if on("train_random_horizontal_flip", True) else 0.0,
+                                    erase_p=0.5 if on("train_random_erasing", False) else 0.0)
+    elif gpu_tail:
         if rotation_after_flip and on("train_random_rotation", False):
             train.append(D.RandomRotation(10))      # rotation by a random angle commutes in distribution with the flip
         # flip commutes with the per-pixel colour jitter, so it can move behind it onto the device
@@ -139,6 +158,10 @@ def build_transforms(img_size: int, gpu_tail: bool = False, *, rotation_default:
             train.append(D.RandomErasing(p=0.5, scale=(0.02, 0.33), ratio=(0.3, 3.3), value=0))
 
     val: list = [D.Lambda(_rgb)] if on("ensure_rgb", True) else []
+    if gpu_tail and gpu_resize and on("val_center_crop", True):
+        val.append(D.PlanGeometry("center", img_size, (img_size if small else enlarged) if on("val_resize", True) else None))
+        val_tail = D.GpuInputTail(mean if on("val_normalize", True) else [0.0] * 3, std if on("val_normalize", True) else [1.0] * 3)
+        return D.Compose(train), D.Compose(val), train_tail, val_tail
     if on("val_resize", True):
         val.append(D.Resize(img_size if small else enlarged))
     if on("val_center_crop", True):
@@ -159,18 +182,25 @@ def make_loader(dataset, batch_size: int, num_workers: int, *, shuffle: bool, ra
     extra = {"prefetch_factor": 2} if num_workers > 0 else {}
     # training shards are padded to equal length (equal step counts for the all-reduce); validation shards are not
     sampler = ShardedSampler(len(dataset), rank, world, shuffle=shuffle, seed=seed, pad=shuffle) if world > 1 else None
+    # pipelines that end in D.PlanGeometry ship variable-size decoded images: packed by D.collate_raw
+    tf = getattr(dataset, "transform", None)
+    if tf is not None and any(isinstance(op, D.PlanGeometry) for op in getattr(tf, "ops", ())):
+        extra["collate_fn"] = D.collate_raw
     return DataLoader(dataset, batch_size=batch_size, shuffle=shuffle and sampler is None, sampler=sampler,
                       num_workers=num_workers, pin_memory=True, persistent_workers=num_workers > 0, **extra)
 
 
 def get_loaders(data_root: Path, train_split: str, val_split: str, img_size: int, batch_size: int, num_workers: int, *,
                 expected_classes: int | None = None, rank: int = 0, world: int = 1, seed: int = 0, gpu_tail: bool = False,
-                transform_kwargs: dict | None = None):
-    """(train loader, val loader); with gpu_tail also (train tail, val tail) to apply to each uint8 batch."""
+                transform_kwargs: dict | None = None, gpu_resize: bool | None = None):
+    """(train loader, val loader); with gpu_tail also (train tail, val tail) to apply to each uint8 batch.
+    gpu_resize (default $GPU_RESIZE, YAML training.gpu_resize): resize / crop on the device too (implies the GPU tail)."""
     tails = ()
     tk = transform_kwargs or {}
+    if gpu_resize is None:
+        gpu_resize = env_str("GPU_RESIZE", "0").lower() in {"1", "true", "yes"}
     if gpu_tail:
-        train_t, val_t, *tails = build_transforms(img_size, gpu_tail=True, **tk)
+        train_t, val_t, *tails = build_transforms(img_size, gpu_tail=True, gpu_resize=gpu_resize, **tk)
     else:
         train_t, val_t = build_transforms(img_size, **tk)
     train_ds = D.ImageFolder(data_root / train_split, transform=train_t)
@@ -419,7 +449,8 @@ def main() -> None:  # noqa: PLR0915
     try:
         # $GPU_INPUT_TAIL (YAML training.gpu_input_tail): loaders ship uint8 batches, the device does
         # flip / to-float / normalise / erasing
-        gpu_tail = use_cuda and env_str("GPU_INPUT_TAIL", "0").lower() in {"1", "true", "yes"}
+        gpu_tail = use_cuda and (env_str("GPU_INPUT_TAIL", "0").lower() in {"1", "true", "yes"}
+                                 or env_str("GPU_RESIZE", "0").lower() in {"1", "true", "yes"})     # device resize implies the device tail
         train_dl, val_dl, *tails = get_loaders(data_root, train_split, val_split, img_size, batch_size, num_workers,
                                                expected_classes=num_classes, rank=rank, world=world, seed=env.seed or 0,
                                                gpu_tail=gpu_tail)

@@ -72,7 +72,7 @@ typedef void* dfd_stream;          /* a hipStream_t */
  * 112 = the eval / inference form of the MBConv block: dfd_pwconv_fwd_eval, dfd_dwconv_fwd_eval(_tiles),
  * dfd_se_fwd_parts;
  * 120 = MX fp8 weights (dfd_mx_*), fused window attention on bf16 MFMA (dfd_wattn_*),
- * batched coordinate MLPs (dfd_coord_mlp_*_multi, dfd_relpos_bias_*_multi), dfd_dwconv_bwd_fused. */
+ * batched coordinate MLPs (dfd_coord_mlp_*_multi, dfd_relpos_bias_*_multi), dfd_dwconv_bwd_fused, dfd_resize_crop_u8. */
 int dfd_version(void);
 
 /* Batched final summation of weight gradients.  The weight-gradient entry points whose result goes straight to the
@@ -326,6 +326,21 @@ int dfd_ce_loss(const float* logits, const int64_t* targets, int N, int J,
                 float* dlogits, dfd_stream stream);
 int dfd_softmax_argmax(const float* logits, int N, int J, float* probs, int64_t* preds,
                        dfd_stream stream);
+/* Resize + CenterCrop / RandomResizedCrop of decoded uint8 RGB images on the device, bit-exact with Pillow's bilinear
+ * Image.resize (two passes, 8-bit intermediate, anti-aliased when shrinking) — trainers/efficientnet.py:111-234,
+ * orchestrator.py:316-347.  src: the batch's images, tightly packed HWC, one after the other in one buffer.  Per image:
+ * out = window (cx, cy, OW x OH) of  crop(bx, by, bw, bh).resize((rw, rh)); pixels outside the resized image are 0.
+ * jobs_dev: DEVICE array of N descriptors.  max_shrink: ceil of the largest bw/rw, bh/rh of the batch (<= 46).        */
+typedef struct dfd_resize_job {
+    long offset;            /* byte offset of the image in src                                  */
+    int H, W;               /* source size                                                       */
+    int bx, by, bw, bh;     /* box of the source that is resized                                 */
+    int rw, rh;             /* size it is resized to                                             */
+    int cx, cy;             /* origin of the output window in the resized image (may be < 0)    */
+    int _pad[2];
+} dfd_resize_job;
+int dfd_resize_crop_u8(const unsigned char* src, const dfd_resize_job* jobs_dev, unsigned char* dst, int N, int OH, int OW,
+                       int max_shrink, dfd_stream stream);
 /* Input tail on the device (trainers/efficientnet.py:111-234): a uint8 NHWC
  * batch [N][H][W][3] -> RandomHorizontalFlip -> ToTensor (/255) -> Normalize((x-mean)/std) ->
  * RandomErasing(value 0) -> f32 NHWC, which is the stem kernel's input layout.  The random decisions

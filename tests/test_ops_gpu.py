@@ -666,3 +666,58 @@ def test_se_from_tile_sums(case):
     close(pooled, want_pooled, 1e-6, "pooled")
     _, want_gate = R.se_fc(want_pooled, w1.cpu(), b1.cpu(), w2.cpu(), b2.cpu(), R.ACT_SILU)
     close(gate, want_gate, 1e-5, "gate")
+
+
+def test_resize_crop_matches_pillow_bit_for_bit():
+    """csrc/dfd_resize.hip restates Pillow's bilinear Image.resize (anti-aliased two-pass resampling with an 8-bit
+    intermediate, fixed-point coefficients): BYTE work, so the device result must equal PIL's exactly — for the eval pipeline
+    (Resize(shorter side) + CenterCrop, trainers/efficientnet.py:196-203), RandomResizedCrop boxes, up- and down-scaling,
+    odd sizes, images smaller than the crop (black padding) and a 20x shrink."""
+    import numpy as np
+    from PIL import Image
+
+    from deepfakedetection_amd import data as D
+
+    K = _k()
+    rng = np.random.default_rng(5)
+    sizes = [(500, 375), (375, 500), (224, 224), (257, 257), (640, 427), (97, 131), (60, 40), (1, 1), (3000, 2000), (301, 299)]
+    imgs = [Image.fromarray(rng.integers(0, 256, (h, w, 3), dtype=np.uint8)) for w, h in sizes]
+    # smooth content too (random noise hides off-by-one coefficient errors less well than gradients hide rounding ones)
+    yy, xx = np.mgrid[0:333, 0:517]
+    imgs.append(Image.fromarray(np.stack([(xx * 255 // 516), (yy * 255 // 332), ((xx + yy) % 256)], -1).astype(np.uint8)))
+    out, enlarged = 224, 257
+    # ---- eval pipeline: Resize(enlarged) -> CenterCrop(out)
+    plan = D.PlanGeometry("center", out, enlarged)
+    want = [np.array(D.CenterCrop(out)(D.Resize(enlarged)(im))) for im in imgs]
+    (flat, jobs, meta), _ = D.collate_raw([(plan(im), 0) for im in imgs])
+    got = K.resize_crop_u8(flat.cuda(), jobs.cuda(), len(imgs), out, out, int(meta[2])).cpu().numpy()
+    for i, w in enumerate(want):
+        assert np.array_equal(got[i], w), (i, imgs[i].size, int(np.abs(got[i].astype(int) - w.astype(int)).max()))
+    # ---- RandomResizedCrop: same RNG calls, same boxes
+    rrc = D.RandomResizedCrop(out, scale=(0.3, 1.0))
+    torch.manual_seed(3); import random; random.seed(3); np.random.seed(3)
+    state = torch.get_rng_state()
+    want = [np.array(rrc(im)) for im in imgs]
+    torch.set_rng_state(state); random.seed(3); np.random.seed(3)
+    planr = D.PlanGeometry("rrc", out, rrc=rrc)
+    (flat, jobs, meta), _ = D.collate_raw([(planr(im), 0) for im in imgs])
+    got = K.resize_crop_u8(flat.cuda(), jobs.cuda(), len(imgs), out, out, int(meta[2])).cpu().numpy()
+    for i, w in enumerate(want):
+        assert np.array_equal(got[i], w), ("rrc", i, imgs[i].size)
+    # ---- small-image branch: Resize(size + 4) + RandomCrop(size)
+    torch.manual_seed(4)
+    state = torch.get_rng_state()
+    want = [np.array(D.RandomCrop(32)(D.Resize(36)(im))) for im in imgs[:6]]
+    torch.set_rng_state(state)
+    plans = D.PlanGeometry("random", 32, 36)
+    (flat, jobs, meta), _ = D.collate_raw([(plans(im), 0) for im in imgs[:6]])
+    got = K.resize_crop_u8(flat.cuda(), jobs.cuda(), 6, 32, 32, int(meta[2])).cpu().numpy()
+    for i, w in enumerate(want):
+        assert np.array_equal(got[i], w), ("small", i, imgs[i].size)
+    # ---- and through the whole tail: same f32 tensor as ToTensor + Normalize of the PIL result
+    mean, std = [0.485, 0.456, 0.406], [0.229, 0.224, 0.225]
+    tail = D.GpuInputTail(mean, std)
+    (raw, _) = D.collate_raw([(plan(im), 0) for im in imgs[:4]])
+    x = tail(raw, "cuda").cpu()
+    ref = torch.stack([D.Normalize(mean, std)(D.ToTensor()(D.CenterCrop(out)(D.Resize(enlarged)(im)))) for im in imgs[:4]])
+    assert torch.equal(x, ref)

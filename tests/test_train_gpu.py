@@ -19,6 +19,7 @@ pytestmark = pytest.mark.gpu
 @pytest.mark.parametrize("model_name,weights_file,gpu_tail", [("efficientnet_b0", "EfficientNetModel.pth", False),
                                                              ("efficientnet_b3", "EfficientNetModel.pth", False),
                                                              ("efficientnet_b0", "EfficientNetModel.pth", True),
+                                                             ("efficientnet_b0", "EfficientNetModel.pth", "resize"),
                                                              ("efficientformerv2_s1", "EfficientFormerV2_S1.pth", False),
                                                              ("faster_vit_0_224", "FasterVitModel.pth", False)])
 def test_orchestrated_training_and_inference_on_gpu(tmp_path, monkeypatch, model_name, weights_file, gpu_tail):
@@ -37,7 +38,12 @@ def test_orchestrated_training_and_inference_on_gpu(tmp_path, monkeypatch, model
     out_dir = str(tmp_path / "runs" / model_name)
     train_cfg = {**base, "models": {model_name: {"output_dir": out_dir, "training": {
         "epochs": 1, "batch_size": 8, "ft_batch_size": 8, "accum_steps": 2, "num_workers": 0, "resume": "auto", "pretrained": False,
-        "gpu_input_tail": gpu_tail}}}}       # True: loaders ship uint8, flip / normalise / erasing run in dfd_image_prep
+        "gpu_input_tail": bool(gpu_tail), "gpu_resize": gpu_tail == "resize"}}}}
+    # gpu_tail True: loaders ship uint8, flip / normalise / erasing run in dfd_image_prep; "resize": the workers only decode and
+    # plan, Resize / RandomResizedCrop / CenterCrop run in dfd_resize_crop_u8 (rotation and jitter off so that the TRAINING
+    # pipeline qualifies too; the validation pipeline always does)
+    if gpu_tail == "resize":
+        train_cfg["models"][model_name]["transforms"] = {"train": {"train_color_jitter": False, "train_random_rotation": False}}
     path = tmp_path / "train.yaml"
     path.write_text(yaml.safe_dump(train_cfg))
     orchestrate(path, mode="training")
@@ -64,6 +70,15 @@ def test_orchestrated_training_and_inference_on_gpu(tmp_path, monkeypatch, model
     run2 = sorted(Path(out_dir).iterdir())[-1]
     row = json.loads((run2 / "logs" / "metrics.jsonl").read_text().splitlines()[0])
     assert row["model"] == model_name and 0.0 <= row["accuracy"] <= 1.0 and "threshold" in row
+    # device-side resize for inference (`inference.gpu_resize: true`): bit-exact input pipeline -> the very same metrics row
+    infer_cfg["models"][model_name]["inference"]["gpu_resize"] = True
+    path2.write_text(yaml.safe_dump(infer_cfg))
+    orchestrate(path2, mode="inference")
+    run2b = sorted(Path(out_dir).iterdir())[-1]
+    row_b = json.loads((run2b / "logs" / "metrics.jsonl").read_text().splitlines()[-1])
+    assert row_b["accuracy"] == row["accuracy"] and row_b["confusion_matrix"] == row["confusion_matrix"]
+    assert row_b.get("roc_auc") == row.get("roc_auc") and row_b.get("threshold") == row.get("threshold")
+    infer_cfg["models"][model_name]["inference"]["gpu_resize"] = False
     # opt-in bf16 inference (`inference.amp: bf16`, an extra key of this engine): same plumbing
     infer_cfg["models"][model_name]["inference"]["amp"] = "bf16"
     path2.write_text(yaml.safe_dump(infer_cfg))
