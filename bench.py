@@ -467,9 +467,9 @@ def main() -> None:
         if world == 1 and not args.no_cpu_baseline:
             progress(f"{value:.0f} images/sec measured; timing the CPU oracle on {usable_cores()} host cores (bounded)")
             line["cpu_baseline"] = cpu_baseline(args)
-        if world == 1 and args.extra_models and (args.model, args.variant, args.flavour) == ("efficientnet", "b0", "timm"):
+        if world == 1 and args.extra_models not in ("", "none") and (args.model, args.variant, args.flavour) == ("efficientnet", "b0", "timm"):
             line["models"] = {}
-            for name in [m for m in args.extra_models.split(",") if m]:
+            for name in [m for m in args.extra_models.split(",") if m and m != "none"]:
                 progress(f"extra model {name} (child process, outside the timed region)")
                 line["models"][name] = extra_model_line(name, args)
         print(json.dumps(line), flush=True)

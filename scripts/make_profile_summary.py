@@ -15,7 +15,21 @@ import sys
 from pathlib import Path
 
 tag, prof_dir, pmc_dir, bench_json = sys.argv[1], Path(sys.argv[2]), Path(sys.argv[3]), Path(sys.argv[4])
-out = Path(__file__).resolve().parents[1] / "profiles"
+ROOT = Path(__file__).resolve().parents[1]
+out = ROOT / "profiles"
+sys.path.insert(0, str(ROOT))
+from deepfakedetection_amd.build import source_digest  # noqa: E402
+
+SOURCE_DIGEST = source_digest()
+# the digest the PMC passes themselves recorded on the GPU box (profile_pmc.sh) wins over the local one
+if (pmc_dir / "csrc_sha256.txt").exists():
+    SOURCE_DIGEST = (pmc_dir / "csrc_sha256.txt").read_text().strip()
+try:
+    import subprocess
+
+    GIT_COMMIT = subprocess.run(["git", "rev-parse", "HEAD"], cwd=ROOT, capture_output=True, text=True, timeout=10).stdout.strip() or None
+except Exception:  # noqa: BLE001
+    GIT_COMMIT = None
 FAM = collections.OrderedDict([
     ("pwconv", ("k_pw_ntw", "k_pw_nt<")), ("pwconv_wgrad", ("k_pw_tnw", "k_pw_tn<")),
     ("dwconv_bwd_data", ("k_dw_bwd_data_q",)), ("dwconv_bwd_weight", ("k_dw_bwd_weight_q",)), ("dwconv_fwd", ("k_dw_fwd_q",)),
@@ -80,7 +94,9 @@ doc = {"_about": "HBM traffic per kernel family and training step (EfficientNet-
                  "--no-cpu-baseline --no-graph --profile-steps 0` (6 eager steps; sums divided by 6). FETCH_SIZE is the raw counter "
                  "(KB -> bytes): on gfx950 it under-reports reads by 2x for every family here — TCC_EA0_RDREQ (128-byte requests x 128 B) "
                  "gives twice its bytes — so read traffic = ea_read. WRITE_SIZE agrees with TCC_EA0_WRREQ.",
-       "steps": PMC_STEPS, "families": traffic}
+       "steps": PMC_STEPS, "families": traffic,
+       # provenance: bench.py refuses to quote these counters once the kernel sources differ from the ones measured
+       "csrc_sha256": SOURCE_DIGEST, "git_commit": GIT_COMMIT}
 (out / f"{tag}_pmc_traffic.json").write_text(json.dumps(doc, indent=1))
 # ---- SQ / GRBM group: MFMA busy cycles, effective clock, how waves spend their life
 N_SIMD = 256 * 4
@@ -118,7 +134,7 @@ shutil.copy(stats_path, out / f"{tag}_bench_kernel_stats.csv")
 line = json.loads(bench_json.read_text().strip().splitlines()[-1])
 (out / f"{tag}_bench_default_line.json").write_text(json.dumps(line) + "\n")
 live = {k["kernel"]: k for k in line["kernels"]}
-L = [f"# Round 2, build {tag} — rocprofv3 kernel stats next to bench.py's live numbers\n",
+L = [f"# Build {tag} — rocprofv3 kernel stats next to bench.py's live numbers\n",
      "Commands (MI355X, one GPU):\n",
      f"* `python bench.py` → `profiles/{tag}_bench_default_line.json` ({line['value']} images/sec, {line['ms_per_step']} ms/step, "
      f"launch: {line['config']['launch']}; f32 eval forward {line['config'].get('eval_f32_images_per_sec_per_gpu')} images/sec).",
