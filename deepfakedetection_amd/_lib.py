@@ -106,6 +106,7 @@ SIGNATURES: dict[str, tuple] = {
     "dfd_bn_add_act_bwd": (c_int, [c_int, P, P, P, P, c_int, P, c_long, c_int, P, c_int, _PI, P]),
     "dfd_channel_stats": (c_int, [c_int, P, c_long, c_int, P, c_int, _PI, P]),
     "dfd_sum_rows": (c_int, [P, c_int, c_long, P, c_int, P]),
+    "dfd_sum_rows_deferred": (c_int, [P, c_int, c_long, P, c_int, P]),
     "dfd_up2_act_fwd": (c_int, [c_int, P, c_int, P, c_int, c_int, c_int, c_int, P]),
     "dfd_up2_act_bwd": (c_int, [c_int, P, P, c_int, P, c_int, c_int, c_int, c_int, P, P]),
     "dfd_subsample_add": (c_int, [c_int, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
@@ -123,7 +124,7 @@ SIGNATURES: dict[str, tuple] = {
     "dfd_col2im": (c_int, [c_int, P, P, POINTER(DwShape), P]),
     "dfd_conv_weight_perm": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P]),
     "dfd_layernorm_fwd": (c_int, [c_int, P, P, P, c_float, P, P, c_long, c_int, P]),
-    "dfd_layernorm_bwd": (c_int, [c_int, P, P, P, P, P, P, c_int, _PI, c_long, c_int, P]),
+    "dfd_layernorm_bwd": (c_int, [c_int, P, P, P, P, P, P, P, c_int, _PI, c_long, c_int, P]),
     "dfd_copy_rows": (c_int, [c_int, P, P, P, P, c_long, c_int, P]),
     "dfd_add_rowtable": (c_int, [c_int, P, P, P, c_long, c_int, c_int, P]),
     "dfd_rowtable_grad_ws": (c_size_t, [c_int, c_int]),

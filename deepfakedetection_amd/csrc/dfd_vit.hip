@@ -329,6 +329,12 @@ extern "C" int dfd_sum_rows(float* partials, int P, long L, float* out, int accu
     // the caller's next launch may read `out`: never left to an open batch
     return dfd_launch_sum_partials(partials, P, L, out, accumulate, (hipStream_t)stream, false);
 }
+// the same, but inside dfd_sum_batch_begin / _end the sum is recorded and launched with the batch: for results nobody reads
+// before the end of the block (a parameter gradient summed straight into its gradient-arena slot)
+extern "C" int dfd_sum_rows_deferred(float* partials, int P, long L, float* out, int accumulate, dfd_stream stream) {
+    if (!partials || !out || P < 1 || L < 1) return DFD_EINVAL;
+    return dfd_launch_sum_partials(partials, P, L, out, accumulate, (hipStream_t)stream, true);
+}
 
 // ===========================================================================
 // bilinear x2 upsampling (align_corners = False), fused with the activation that follows it
@@ -1179,120 +1185,269 @@ extern "C" int dfd_conv_weight_perm(const float* src, float* dst, int O, int I, 
 //   fwd: y = (x - mu) * rstd * gamma + beta; saves (mu, rstd) per row
 //   bwd: dx = rstd * (gh - mean(gh) - xhat * mean(gh * xhat)), gh = g * gamma; partial slabs of (g*xhat, g) per workgroup
 // ===========================================================================
-template <typename T>
+// Register-resident form (NV = 16-byte vectors per lane, 1 or 2): the row stays in registers between the statistics and the
+// output (one read of x — and of g in the backward — instead of three / two), gamma / beta are loaded once per lane, the
+// backward keeps its dgamma / dbeta partial sums in registers instead of 32 LDS read-modify-writes per row, and SHORT rows
+// share a wave: with CV = C / V vectors per row, lpr = the power of two >= CV lanes form a row group and a wave walks
+// 64 / lpr rows at once (C = 256 in bf16 is 32 vectors: two rows per wave instead of 32 idle lanes).  NV = 0: rows longer
+// than 128 vectors — the streaming form.
+__device__ __forceinline__ int ln_lpr(int CV) { int l = 1; while (l < CV && l < 64) l <<= 1; return l; }
+template <typename T, int NV>
 __global__ void __launch_bounds__(DFD_THREADS)
 k_layernorm_fwd(const T* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                 T* __restrict__ y, float* __restrict__ stats, long rows, int C) {
     constexpr int V = Vec<T>::N;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int CV = C / V;
-    for (long r = (long)blockIdx.x * 4 + wave; r < rows; r += (long)gridDim.x * 4) {
-        float s = 0.f;
-        for (int cv = lane; cv < CV; cv += 64) {
-            float v[V];
-            Vec<T>::load(x + r * C + cv * V, v);
+    if constexpr (NV > 0) {
+        const int lpr = NV == 1 ? ln_lpr(CV) : 64, rpw = 64 / lpr;        // lanes per row, rows per wave
+        const int sub = lane / lpr, cl = lane - sub * lpr;
+        float gm[NV][V], bt[NV][V];
 #pragma unroll
-            for (int j = 0; j < V; ++j) s += v[j];
+        for (int i = 0; i < NV; ++i) {
+            const int cv = cl + 64 * i;
+            if (cv < CV) { load_f32<V>(gamma + cv * V, gm[i]); load_f32<V>(beta + cv * V, bt[i]); }
         }
+        for (long r0 = ((long)blockIdx.x * 4 + wave) * rpw; r0 < rows; r0 += (long)gridDim.x * 4 * rpw) {
+            const long r = r0 + sub;
+            const bool ron = r < rows;
+            float v[NV][V];
+            float s = 0.f;
 #pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);
-        const float mu = s / (float)C;
-        float q = 0.f;
-        for (int cv = lane; cv < CV; cv += 64) {
-            float v[V];
-            Vec<T>::load(x + r * C + cv * V, v);
+            for (int i = 0; i < NV; ++i) {
+                const int cv = cl + 64 * i;
+                if (ron && cv < CV) {
+                    Vec<T>::load(x + r * C + cv * V, v[i]);
 #pragma unroll
-            for (int j = 0; j < V; ++j) { const float d = v[j] - mu; q = fmaf(d, d, q); }
+                    for (int j = 0; j < V; ++j) s += v[i][j];
+                }
+            }
+            for (int o = lpr >> 1; o >= 1; o >>= 1) s += __shfl_xor(s, o);
+            const float mu = s / (float)C;
+            float q = 0.f;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                if (ron && cl + 64 * i < CV) {
+#pragma unroll
+                    for (int j = 0; j < V; ++j) { const float d = v[i][j] - mu; q = fmaf(d, d, q); }
+                }
+            }
+            for (int o = lpr >> 1; o >= 1; o >>= 1) q += __shfl_xor(q, o);
+            const float rstd = 1.0f / sqrtf(q / (float)C + eps);
+            if (ron && cl == 0 && stats) { stats[2 * r] = mu; stats[2 * r + 1] = rstd; }
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int cv = cl + 64 * i;
+                if (ron && cv < CV) {
+#pragma unroll
+                    for (int j = 0; j < V; ++j) v[i][j] = fmaf((v[i][j] - mu) * rstd, gm[i][j], bt[i][j]);
+                    Vec<T>::store(y + r * C + cv * V, v[i]);
+                }
+            }
         }
+    } else {
+        for (long r = (long)blockIdx.x * 4 + wave; r < rows; r += (long)gridDim.x * 4) {
+            float s = 0.f;
+            for (int cv = lane; cv < CV; cv += 64) {
+                float v[V];
+                Vec<T>::load(x + r * C + cv * V, v);
 #pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) q += __shfl_xor(q, o);
-        const float rstd = 1.0f / sqrtf(q / (float)C + eps);
-        if (lane == 0 && stats) { stats[2 * r] = mu; stats[2 * r + 1] = rstd; }
-        for (int cv = lane; cv < CV; cv += 64) {
-            float v[V], gm[V], bt[V];
-            Vec<T>::load(x + r * C + cv * V, v);
-            load_f32<V>(gamma + cv * V, gm);
-            load_f32<V>(beta + cv * V, bt);
+                for (int j = 0; j < V; ++j) s += v[j];
+            }
 #pragma unroll
-            for (int j = 0; j < V; ++j) v[j] = fmaf((v[j] - mu) * rstd, gm[j], bt[j]);
-            Vec<T>::store(y + r * C + cv * V, v);
+            for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);
+            const float mu = s / (float)C;
+            float q = 0.f;
+            for (int cv = lane; cv < CV; cv += 64) {
+                float v[V];
+                Vec<T>::load(x + r * C + cv * V, v);
+#pragma unroll
+                for (int j = 0; j < V; ++j) { const float d = v[j] - mu; q = fmaf(d, d, q); }
+            }
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) q += __shfl_xor(q, o);
+            const float rstd = 1.0f / sqrtf(q / (float)C + eps);
+            if (lane == 0 && stats) { stats[2 * r] = mu; stats[2 * r + 1] = rstd; }
+            for (int cv = lane; cv < CV; cv += 64) {
+                float v[V], gm[V], bt[V];
+                Vec<T>::load(x + r * C + cv * V, v);
+                load_f32<V>(gamma + cv * V, gm);
+                load_f32<V>(beta + cv * V, bt);
+#pragma unroll
+                for (int j = 0; j < V; ++j) v[j] = fmaf((v[j] - mu) * rstd, gm[j], bt[j]);
+                Vec<T>::store(y + r * C + cv * V, v);
+            }
         }
     }
 }
-template <typename T>
+// residual (optional): dx = LN-backward(g) + residual — the skip connection's gradient, which used to be a separate add kernel
+template <typename T, int NV>
 __global__ void __launch_bounds__(DFD_THREADS)
 k_layernorm_bwd(const T* __restrict__ g, const T* __restrict__ x, const float* __restrict__ gamma,
-                const float* __restrict__ stats, T* __restrict__ dx, float* __restrict__ partials, long rows, int C) {
+                const float* __restrict__ stats, const T* __restrict__ residual, T* __restrict__ dx, float* __restrict__ partials,
+                long rows, int C) {
     constexpr int V = Vec<T>::N;
     extern __shared__ float sacc[];            // [4 waves][2][C]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int CV = C / V;
     float* mine = sacc + (long)wave * 2 * C;
-    for (int i = lane; i < 2 * C; i += 64) mine[i] = 0.f;
-    for (long r = (long)blockIdx.x * 4 + wave; r < rows; r += (long)gridDim.x * 4) {
-        const float mu = stats[2 * r], rstd = stats[2 * r + 1];
-        float s1 = 0.f, s2 = 0.f;
-        for (int cv = lane; cv < CV; cv += 64) {
-            float gv[V], xv[V], gm[V];
-            Vec<T>::load(g + r * C + cv * V, gv);
-            Vec<T>::load(x + r * C + cv * V, xv);
-            load_f32<V>(gamma + cv * V, gm);
+    if constexpr (NV > 0) {
+        const int lpr = NV == 1 ? ln_lpr(CV) : 64, rpw = 64 / lpr;
+        const int sub = lane / lpr, cl = lane - sub * lpr;
+        float gm[NV][V], dg[NV][V], db[NV][V];
 #pragma unroll
-            for (int j = 0; j < V; ++j) {
-                const float xh = (xv[j] - mu) * rstd, gh = gv[j] * gm[j];
-                s1 += gh; s2 = fmaf(gh, xh, s2);
-                mine[cv * V + j] += gv[j] * xh;            // dgamma partial (this lane owns these channels)
-                mine[C + cv * V + j] += gv[j];             // dbeta partial
+        for (int i = 0; i < NV; ++i) {
+            const int cv = cl + 64 * i;
+            if (cv < CV) load_f32<V>(gamma + cv * V, gm[i]);
+#pragma unroll
+            for (int j = 0; j < V; ++j) { dg[i][j] = 0.f; db[i][j] = 0.f; }
+        }
+        for (long r0 = ((long)blockIdx.x * 4 + wave) * rpw; r0 < rows; r0 += (long)gridDim.x * 4 * rpw) {
+            const long r = r0 + sub;
+            const bool ron = r < rows;
+            const float mu = ron ? stats[2 * r] : 0.f, rstd = ron ? stats[2 * r + 1] : 0.f;
+            float gv[NV][V], xh[NV][V];
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int cv = cl + 64 * i;
+                if (ron && cv < CV) {
+                    Vec<T>::load(g + r * C + cv * V, gv[i]);
+                    Vec<T>::load(x + r * C + cv * V, xh[i]);
+#pragma unroll
+                    for (int j = 0; j < V; ++j) {
+                        xh[i][j] = (xh[i][j] - mu) * rstd;
+                        const float gh = gv[i][j] * gm[i][j];
+                        s1 += gh; s2 = fmaf(gh, xh[i][j], s2);
+                        dg[i][j] += gv[i][j] * xh[i][j];
+                        db[i][j] += gv[i][j];
+                    }
+                }
+            }
+            for (int o = lpr >> 1; o >= 1; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+            const float m1 = s1 / (float)C, m2 = s2 / (float)C;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int cv = cl + 64 * i;
+                if (ron && cv < CV) {
+                    float o[V];
+#pragma unroll
+                    for (int j = 0; j < V; ++j) o[j] = rstd * (gv[i][j] * gm[i][j] - m1 - xh[i][j] * m2);
+                    if (residual) {
+                        float rv[V];
+                        Vec<T>::load(residual + r * C + cv * V, rv);
+#pragma unroll
+                        for (int j = 0; j < V; ++j) o[j] = round_to<T>(o[j]) + rv[j];      // the unfused pipeline stored dx, then added
+                    }
+                    Vec<T>::store(dx + r * C + cv * V, o);
+                }
             }
         }
+        // the row groups of a wave hold partial sums of the SAME channels: add them in group order (xor lpr, 2 lpr, ...)
 #pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
-        const float m1 = s1 / (float)C, m2 = s2 / (float)C;
-        for (int cv = lane; cv < CV; cv += 64) {
-            float gv[V], xv[V], gm[V];
-            Vec<T>::load(g + r * C + cv * V, gv);
-            Vec<T>::load(x + r * C + cv * V, xv);
-            load_f32<V>(gamma + cv * V, gm);
+        for (int i = 0; i < NV; ++i)
 #pragma unroll
-            for (int j = 0; j < V; ++j) {
-                const float xh = (xv[j] - mu) * rstd;
-                gv[j] = rstd * (gv[j] * gm[j] - m1 - xh * m2);
+            for (int j = 0; j < V; ++j)
+                for (int o = lpr; o < 64; o <<= 1) { dg[i][j] += __shfl_xor(dg[i][j], o); db[i][j] += __shfl_xor(db[i][j], o); }
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int cv = cl + 64 * i;
+            if (sub == 0 && cv < CV) {
+#pragma unroll
+                for (int j = 0; j < V; ++j) { mine[cv * V + j] = dg[i][j]; mine[C + cv * V + j] = db[i][j]; }
             }
-            Vec<T>::store(dx + r * C + cv * V, gv);
+        }
+    } else {
+        for (int i = lane; i < 2 * C; i += 64) mine[i] = 0.f;
+        for (long r = (long)blockIdx.x * 4 + wave; r < rows; r += (long)gridDim.x * 4) {
+            const float mu = stats[2 * r], rstd = stats[2 * r + 1];
+            float s1 = 0.f, s2 = 0.f;
+            for (int cv = lane; cv < CV; cv += 64) {
+                float gv[V], xv[V], gm[V];
+                Vec<T>::load(g + r * C + cv * V, gv);
+                Vec<T>::load(x + r * C + cv * V, xv);
+                load_f32<V>(gamma + cv * V, gm);
+#pragma unroll
+                for (int j = 0; j < V; ++j) {
+                    const float xh = (xv[j] - mu) * rstd, gh = gv[j] * gm[j];
+                    s1 += gh; s2 = fmaf(gh, xh, s2);
+                    mine[cv * V + j] += gv[j] * xh;            // dgamma partial (this lane owns these channels)
+                    mine[C + cv * V + j] += gv[j];             // dbeta partial
+                }
+            }
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+            const float m1 = s1 / (float)C, m2 = s2 / (float)C;
+            for (int cv = lane; cv < CV; cv += 64) {
+                float gv[V], xv[V], gm[V];
+                Vec<T>::load(g + r * C + cv * V, gv);
+                Vec<T>::load(x + r * C + cv * V, xv);
+                load_f32<V>(gamma + cv * V, gm);
+#pragma unroll
+                for (int j = 0; j < V; ++j) {
+                    const float xh = (xv[j] - mu) * rstd;
+                    gv[j] = rstd * (gv[j] * gm[j] - m1 - xh * m2);
+                }
+                if (residual) {
+                    float rv[V];
+                    Vec<T>::load(residual + r * C + cv * V, rv);
+#pragma unroll
+                    for (int j = 0; j < V; ++j) gv[j] = round_to<T>(gv[j]) + rv[j];
+                }
+                Vec<T>::store(dx + r * C + cv * V, gv);
+            }
         }
     }
     __syncthreads();
     float* p = partials + (long)blockIdx.x * 2 * C;
     for (int i = threadIdx.x; i < 2 * C; i += DFD_THREADS) p[i] = sacc[i] + sacc[2 * C + i] + sacc[4 * C + i] + sacc[6 * C + i];
 }
+#define LN_DISPATCH(KERN, T, ...)                                                                         \
+    do {                                                                                                  \
+        const int nv_ = (C / Vec<T>::N + 63) / 64;                                                        \
+        if (nv_ <= 1) hipLaunchKernelGGL((KERN<T, 1>), __VA_ARGS__);                                      \
+        else if (nv_ == 2) hipLaunchKernelGGL((KERN<T, 2>), __VA_ARGS__);                                 \
+        else hipLaunchKernelGGL((KERN<T, 0>), __VA_ARGS__);                                               \
+    } while (0)
+static inline int ln_rows_per_wave(int dtype, int C) {
+    const int cv = C / (dtype == DFD_BF16 ? 8 : 4);
+    if (cv > 64) return 1;
+    int l = 1;
+    while (l < cv) l <<= 1;
+    return 64 / l;
+}
 extern "C" int dfd_layernorm_fwd(int dtype, const void* x, const float* gamma, const float* beta, float eps, void* y,
                                  float* stats, long rows, int C, dfd_stream stream) {
     if (!x || !gamma || !beta || !y || rows < 1 || C < 8 || C % 8) return DFD_EINVAL;
-    long grid = (rows + 3) / 4;
+    const int rpw = ln_rows_per_wave(dtype, C);
+    long grid = (rows + 4 * rpw - 1) / (4 * rpw);
     if (grid > 8192) grid = 8192;
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == DFD_BF16) hipLaunchKernelGGL((k_layernorm_fwd<bf16>), dim3((unsigned)grid), dim3(DFD_THREADS), 0, st, (const bf16*)x, gamma, beta, eps, (bf16*)y, stats, rows, C);
-    else if (dtype == DFD_F32) hipLaunchKernelGGL((k_layernorm_fwd<float>), dim3((unsigned)grid), dim3(DFD_THREADS), 0, st, (const float*)x, gamma, beta, eps, (float*)y, stats, rows, C);
+    if (dtype == DFD_BF16) LN_DISPATCH(k_layernorm_fwd, bf16, dim3((unsigned)grid), dim3(DFD_THREADS), 0, st, (const bf16*)x, gamma, beta, eps, (bf16*)y, stats, rows, C);
+    else if (dtype == DFD_F32) LN_DISPATCH(k_layernorm_fwd, float, dim3((unsigned)grid), dim3(DFD_THREADS), 0, st, (const float*)x, gamma, beta, eps, (float*)y, stats, rows, C);
     else return DFD_EINVAL;
     return DFD_CHECK_LAUNCH();
 }
-// partials: [nparts][2][C] with row 0 = dgamma, row 1 = dbeta partial sums; sum them with dfd_sum_rows
-extern "C" int dfd_layernorm_bwd(int dtype, const void* g, const void* x, const float* gamma, const float* stats, void* dx,
-                                 float* partials, int pcap, int* nparts, long rows, int C, dfd_stream stream) {
+// partials: [nparts][2][C] with row 0 = dgamma, row 1 = dbeta partial sums; sum them with dfd_sum_rows (or dfd_sum_rows_deferred)
+// residual (may be NULL): added to dx — the gradient of the skip connection around the normalised branch
+extern "C" int dfd_layernorm_bwd(int dtype, const void* g, const void* x, const float* gamma, const float* stats, const void* residual,
+                                 void* dx, float* partials, int pcap, int* nparts, long rows, int C, dfd_stream stream) {
     if (!g || !x || !gamma || !stats || !dx || !partials || !nparts || pcap < 1 || rows < 1 || C < 8 || C % 8) return DFD_EINVAL;
     if ((size_t)8 * C * 4 > 64 * 1024) return DFD_EUNSUPPORTED;
-    long grid = (rows + 15) / 16;
+    const int rpw = ln_rows_per_wave(dtype, C);
+    long grid = (rows + 16 * rpw - 1) / (16 * rpw);
     if (grid > pcap) grid = pcap;
     if (grid > DFD_MAX_PARTIALS) grid = DFD_MAX_PARTIALS;
     if (grid < 1) grid = 1;
     *nparts = (int)grid;
     const size_t lds = (size_t)8 * C * 4;
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == DFD_BF16) hipLaunchKernelGGL((k_layernorm_bwd<bf16>), dim3((unsigned)grid), dim3(DFD_THREADS), lds, st, (const bf16*)g, (const bf16*)x, gamma, stats, (bf16*)dx, partials, rows, C);
-    else if (dtype == DFD_F32) hipLaunchKernelGGL((k_layernorm_bwd<float>), dim3((unsigned)grid), dim3(DFD_THREADS), lds, st, (const float*)g, (const float*)x, gamma, stats, (float*)dx, partials, rows, C);
+    if (dtype == DFD_BF16) LN_DISPATCH(k_layernorm_bwd, bf16, dim3((unsigned)grid), dim3(DFD_THREADS), lds, st, (const bf16*)g, (const bf16*)x, gamma, stats, (const bf16*)residual, (bf16*)dx, partials, rows, C);
+    else if (dtype == DFD_F32) LN_DISPATCH(k_layernorm_bwd, float, dim3((unsigned)grid), dim3(DFD_THREADS), lds, st, (const float*)g, (const float*)x, gamma, stats, (const float*)residual, (float*)dx, partials, rows, C);
     else return DFD_EINVAL;
     return DFD_CHECK_LAUNCH();
 }
+#undef LN_DISPATCH
 
 // ===========================================================================
 // token bookkeeping for windowed attention (fastervit faster_vit.py: window_partition / window_reverse,

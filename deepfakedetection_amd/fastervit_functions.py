@@ -274,12 +274,33 @@ def attn_sub_bwd(g, saved, P, spec: AttnSpec, ls, row_scale, need: dict, need_dx
                                                      need["qkv_w"], need["qkv_b"])
     dx = None
     if need_xn:
-        dx_ln, dg, db = K.layernorm_bwd(dxn, x, P["ln_w"], lnst)
-        grads["ln_w"] = _to_slot(dg, P["ln_w"], need["ln_w"])
-        grads["ln_b"] = _to_slot(db, P["ln_b"], need["ln_b"])
-        if need_dx:
-            dx = K.add(dx_ln, g)
+        dx, grads["ln_w"], grads["ln_b"] = _ln_bwd(dxn, x, P["ln_w"], P["ln_b"], lnst, need["ln_w"], need["ln_b"],
+                                                   g if need_dx else None)
+        if not need_dx:
+            dx = None
     return dx, grads
+
+
+def _ln_bwd(dxn, x, ln_w, ln_b, lnst, need_w: bool, need_b: bool, residual=None):
+    """LayerNorm backward with the skip connection's gradient added in the same kernel; (dgamma, dbeta) are summed straight
+    into the parameters' gradient-arena slots when both are wanted and the slots are adjacent (weight, bias: they are)."""
+    C = ln_w.numel()
+    sw = _slot(ln_w, need_w, (C,)) if need_w else None
+    sb = _slot(ln_b, need_b, (C,)) if need_b else None
+    if sw is not None and sb is not None and sb.data_ptr() == sw.data_ptr() + 4 * C:
+        both = torch.as_strided(sw, (2, C), (C, 1))
+        dx, dg, db = K.layernorm_bwd(dxn, x, ln_w, lnst, residual, both)
+        return dx, dg, db
+    dx, dg, db = K.layernorm_bwd(dxn, x, ln_w, lnst, residual)
+
+    def place(val, slot, need):
+        if not need:
+            return None
+        if slot is None:
+            return val
+        return K.axpby(val.reshape(-1), None, 1.0, 0.0, out=slot.view(-1)).view(slot.shape)
+
+    return dx, place(dg, sw, need_w), place(db, sb, need_b)
 
 
 def _to_slot(val: torch.Tensor, param: torch.Tensor, need: bool):
@@ -340,11 +361,10 @@ def mlp_sub_bwd(g, saved, P, ls, row_scale, need: dict, need_dx: bool):
     dx = None
     if need_dx or need["ln_w"] or need["ln_b"]:
         dxn, _, _ = K.pwconv(dz1, None, w1_kn, None, stats=False)
-        dx_ln, dg, db = K.layernorm_bwd(dxn, x, P["ln_w"], lnst)
-        grads["ln_w"] = _to_slot(dg, P["ln_w"], need["ln_w"])
-        grads["ln_b"] = _to_slot(db, P["ln_b"], need["ln_b"])
-        if need_dx:
-            dx = K.add(dx_ln, g)
+        dx, grads["ln_w"], grads["ln_b"] = _ln_bwd(dxn, x, P["ln_w"], P["ln_b"], lnst, need["ln_w"], need["ln_b"],
+                                                   g if need_dx else None)
+        if not need_dx:
+            dx = None
     return dx, grads
 
 

@@ -1285,13 +1285,22 @@ def layernorm_fwd(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps:
     return y, stats
 
 
-def layernorm_bwd(g: torch.Tensor, x: torch.Tensor, gamma: torch.Tensor, stats: torch.Tensor, out_dgamma=None, out_dbeta=None):
+def layernorm_bwd(g: torch.Tensor, x: torch.Tensor, gamma: torch.Tensor, stats: torch.Tensor, residual: torch.Tensor | None = None,
+                  out2: torch.Tensor | None = None):
+    """-> (dx [+ residual], dgamma, dbeta).  out2: an f32 [2, C] destination for (dgamma, dbeta) that nobody reads before the
+    end of the enclosing block (two adjacent gradient-arena slots): the final sum of the partial rows then goes straight
+    there and may be left to the block's batched sums (dfd_sum_rows_deferred) — no temporary, no copy kernels."""
     rows, C = _rows_c(x)
     dx = torch.empty_like(x)
     parts = partials_buf(x.device, C)
     n = ctypes.c_int(0)
-    check(_L().dfd_layernorm_bwd(_dt(x), _p(g), _p(x), _p(gamma), _p(stats), _p(dx), _p(parts), MAX_PARTIALS, ctypes.byref(n),
-                                 rows, C, _stream()), "dfd_layernorm_bwd")
+    check(_L().dfd_layernorm_bwd(_dt(x), _p(g), _p(x), _p(gamma), _p(stats), _p(residual), _p(dx), _p(parts), MAX_PARTIALS,
+                                 ctypes.byref(n), rows, C, _stream()), "dfd_layernorm_bwd")
+    if out2 is not None:
+        if tuple(out2.shape) != (2, C) or out2.dtype != torch.float32 or not out2.is_contiguous():
+            raise ValueError("layernorm_bwd: out2 must be a contiguous f32 [2, C] tensor")
+        check(_L().dfd_sum_rows_deferred(_p(parts), n.value, 2 * C, _p(out2), 0, _stream()), "dfd_sum_rows_deferred")
+        return dx, out2[0], out2[1]
     both = torch.empty((2, C), dtype=torch.float32, device=x.device)
     sum_rows(parts, n.value, 2 * C, both)
     return dx, both[0], both[1]

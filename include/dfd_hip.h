@@ -376,6 +376,9 @@ int dfd_channel_stats(int dtype, const void* x, long rows, int C, float* partial
                       dfd_stream stream);
 /* out[i] (+)= sum_p partials[p][i], fixed order; `partials` needs room for P + ceil(P/32) rows of L floats  */
 int dfd_sum_rows(float* partials, int P, long L, float* out, int accumulate, dfd_stream stream);
+/* dfd_sum_rows whose launch may be left to an open dfd_sum_batch_begin / _end (results nobody reads inside the batch:
+ * parameter gradients summed straight into their destination)                                                    */
+int dfd_sum_rows_deferred(float* partials, int P, long L, float* out, int accumulate, dfd_stream stream);
 /* out [N][2h][2w][C] = act(bilinear_x2(s [N][h][w][C])), align_corners = False (nn.Upsample in Attention2d) */
 int dfd_up2_act_fwd(int dtype, const void* s, int act, void* out, int N, int h, int w, int C, dfd_stream stream);
 /* ws (optional): scratch of the size and type of g; with it the activation derivative is evaluated once per output
@@ -443,7 +446,8 @@ int dfd_conv_weight_perm(const float* src, float* dst, int O, int I, int k, int 
 int dfd_layernorm_fwd(int dtype, const void* x, const float* gamma, const float* beta, float eps, void* y,
                       float* stats, long rows, int C, dfd_stream stream);
 int dfd_layernorm_bwd(int dtype, const void* g, const void* x, const float* gamma, const float* stats,
-                      void* dx, float* partials, int pcap, int* nparts, long rows, int C, dfd_stream stream);
+                      const void* residual, void* dx, float* partials, int pcap, int* nparts, long rows, int C,
+                      dfd_stream stream);
 
 /* Token bookkeeping of windowed attention (fastervit faster_vit.py window_partition / window_reverse /
  * ct_dewindow / ct_window / cat / split): dst[didx[r]] = src[sidx[r]], r < n, rows of C elements; a NULL index

@@ -313,7 +313,7 @@ def test_conv_weight_perm_roundtrip_and_dense_conv_through_gemm():
 
 # ------------------------------------------------------------------ LayerNorm
 @pytest.mark.parametrize("rd", DT)
-@pytest.mark.parametrize("C", [64, 256, 512])
+@pytest.mark.parametrize("C", [64, 256, 512, 1024, 2048])      # 1, 1, 1 | 2, 2 | 0 (streaming) vectors per lane
 def test_layernorm_fwd_bwd(rd, C):
     K = _k()
     x = (gen((37, C), 1, rd).float() * 1.5 + 0.2).to(rd)
@@ -329,6 +329,13 @@ def test_layernorm_fwd_bwd(rd, C):
     close(dx, xr.grad, tol(rd), "ln dx")
     close(dg, gr.grad, 2e-4 if rd == torch.float32 else 5e-3, "ln dgamma")
     close(db, br.grad, 2e-4 if rd == torch.float32 else 5e-3, "ln dbeta")
+    # residual fused into the kernel (the skip connection's gradient) and (dgamma, dbeta) summed straight into a [2, C]
+    # destination: same values as the separate add / the temporary
+    res = gen((37, C), 4, rd)
+    out2 = torch.empty((2, C), dtype=torch.float32, device="cuda")
+    dx2, dg2, db2 = K.layernorm_bwd(g.cuda(), x.cuda(), gamma.cuda(), stats, res.cuda(), out2)
+    assert torch.equal(dx2, K.add(dx, res.cuda())), "fused residual differs from dx + residual"
+    assert torch.equal(dg2, dg) and torch.equal(db2, db) and dg2.data_ptr() == out2.data_ptr()
 
 
 # ------------------------------------------------------------------ bookkeeping
