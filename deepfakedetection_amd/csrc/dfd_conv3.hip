@@ -1,0 +1,177 @@
+// dfd_conv3.hip — dense 3x3 stride-1 convolution (pad 1) as a DIRECT MFMA kernel, bf16.
+//
+// FasterViT's ConvBlocks (levels 0-1: 56x56x64 and 28x28x128 at 224 px) run two such convolutions forward and — the data
+// gradient of a stride-1 convolution being the forward convolution of the output gradient with the flipped, transposed weight
+// — two more backward (reference call sites: the third-party module's forward / backward at trainers/fastervit.py:271, :274).
+// The implicit-GEMM form (k_pw_nt<.., CONV>) gathers its operand chunk by chunk with two magic divisions per 16 bytes and
+// applies the producer's BatchNorm + GELU to every gathered copy (nine times per element): 133-516 us per call, 5.2 of
+// FasterViT-0's 30.6 ms, at ~450 TFLOP/s and 1.6 TB/s — neither roofline.  Here:
+//   * a workgroup owns an 8 x 16 tile of output pixels and 64 output channels (grid.y = Cout / 64); the input tile with halo
+//     (10 x 18 pixels x C channels) is staged in LDS ONCE, the producer's BN + activation applied once per element, zero padding
+//     in the activated domain; pixel pitch C*2 + 16 bytes makes the 16-byte fragment reads conflict-free;
+//   * wave w owns output channels 16 w .. 16 w + 15 of the group: its WEIGHTS — 9 taps x C/32 k-steps of 16x32 fragments —
+//     stay in registers for the whole persistent loop (72 VGPRs at C = 64, 144 at C = 128): no weight traffic after the prologue;
+//   * per (tap, k-step) and 16-pixel row of the tile: one ds_read_b128 (the pixel fragment, shifted by the tap) + one
+//     v_mfma_f32_16x16x32_bf16 with the weight as the A operand, so a lane ends up with 4 consecutive output channels of one
+//     pixel: 8-byte stores;
+//   * BatchNorm partial sums (sum, sum of squares of the ROUNDED outputs) per channel: registers over the persistent loop, a
+//     16-lane butterfly at the end, one partial row per workgroup slot (waves own disjoint channels: no cross-wave step).
+// Bound: LDS read rate (1 KB per MFMA) at ~2x the MFMA time — ~55-60 us per convolution at batch 256 against 100+ MB of
+// activations (input + output once): HBM ~4 TB/s equivalent.  Shapes outside (k 3, stride 1, pad 1, C in {64, 96, 128}, Cout % 64
+// == 0, bf16) keep the implicit-GEMM path (DFD_EUNSUPPORTED from the launcher, checked by dfd_conv_fwd).
+#include "dfd_common.h"
+#include "dfd_pw.h"
+
+#define C3_TH 8
+#define C3_TW 16
+#define C3_IH (C3_TH + 2)
+#define C3_IW (C3_TW + 2)
+
+template <int CK, int ACT, bool PRO, bool STATS>        // CK = C / 32
+__global__ void __launch_bounds__(DFD_THREADS, 2)
+k_conv3_direct(const unsigned short* __restrict__ x, const float* __restrict__ in_bn, const unsigned short* __restrict__ w,
+               unsigned short* __restrict__ y, float* __restrict__ partials, int N, int H, int W, int Cout, int tiles_y, int tiles_x) {
+    constexpr int C = 32 * CK, CP = C + 8;              // pixel pitch in elements
+    extern __shared__ __attribute__((aligned(16))) unsigned short tile[];         // [C3_IH][C3_IW][CP]
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, c16 = lane & 15, g = lane >> 4;
+    const int co0 = blockIdx.y * 64 + wave * 16;        // this wave's 16 output channels
+    // resident weights: A operand fragment (row = output channel co0 + c16, k = input channels 32 ks + 8 g ..) per tap
+    bf16x8_t wf[9][CK];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int ks = 0; ks < CK; ++ks)
+            wf[t][ks] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(w + (long)(co0 + c16) * 9 * C + t * C + 32 * ks + 8 * g));
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+    const int tiles = tiles_y * tiles_x;
+    const long nwork = (long)N * tiles;
+    constexpr int VPP = C / 8;                          // 16-byte vectors per pixel
+    for (long work = blockIdx.x; work < nwork; work += gridDim.x) {
+        const int n = (int)(work / tiles), tr = (int)(work - (long)n * tiles);
+        const int ty = tr / tiles_x, tx = tr - ty * tiles_x;
+        const int h0 = ty * C3_TH, w0 = tx * C3_TW;
+        __syncthreads();                                 // previous tile's fragment reads are done
+        // ---- stage the input tile with halo; the producer's BN + activation once per element; zeros outside the image
+        for (int i0 = threadIdx.x; i0 < C3_IH * C3_IW * VPP; i0 += 4 * DFD_THREADS) {
+            uint4 r[4];
+            bool ok[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + u * DFD_THREADS;
+                const int pix = i / VPP, v = i - pix * VPP;
+                const int iy = pix / C3_IW, ix = pix - iy * C3_IW;
+                const int gy = h0 - 1 + iy, gx = w0 - 1 + ix;
+                ok[u] = i < C3_IH * C3_IW * VPP && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+                r[u] = make_uint4(0, 0, 0, 0);
+                if (ok[u]) r[u] = *reinterpret_cast<const uint4*>(x + (((long)n * H + gy) * W + gx) * C + v * 8);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + u * DFD_THREADS;
+                if (i >= C3_IH * C3_IW * VPP) continue;
+                const int pix = i / VPP, v = i - pix * VPP;
+                uint4 q = r[u];
+                if constexpr (PRO) {
+                    if (ok[u]) {
+                        float f[8], sc[8], sh[8];
+                        Vec<bf16>::unpack(q, f);
+                        load_f32<8>(in_bn + v * 8, sc);
+                        load_f32<8>(in_bn + C + v * 8, sh);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) f[j] = act_fwd<ACT>(fmaf(sc[j], f[j], sh[j]));
+                        q = Vec<bf16>::pack(f);
+                    }
+                }
+                *reinterpret_cast<uint4*>(tile + pix * CP + v * 8) = q;
+            }
+        }
+        __syncthreads();
+        // ---- 8 rows of 16 pixels x this wave's 16 channels
+        f32x4_t acc[C3_TH];
+#pragma unroll
+        for (int r = 0; r < C3_TH; ++r) acc[r] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        // blocks of (tap, k-step): the next block's eight pixel fragments (B operand: column = pixel c16 of a tile row, k =
+        // channels 32 ks + 8 g ..) are read while the current block's MFMAs issue; the scheduling barrier keeps the compiler from
+        // hoisting every read of the tile to the top (that spills the resident weights)
+        constexpr int NB = 9 * CK;
+        bf16x8_t pf[2][C3_TH];
+        const unsigned short* lane_base = tile + c16 * CP + 8 * g;
+#pragma unroll
+        for (int r = 0; r < C3_TH; ++r) pf[0][r] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(lane_base + r * C3_IW * CP));
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            if (b + 1 < NB) {
+                const int t = (b + 1) / CK, ks = (b + 1) - t * CK, kh = t / 3, kw = t - 3 * kh;
+                const unsigned short* base = lane_base + (kh * C3_IW + kw) * CP + 32 * ks;
+#pragma unroll
+                for (int r = 0; r < C3_TH; ++r) pf[(b + 1) & 1][r] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(base + r * C3_IW * CP));
+            }
+            const int t = b / CK, ks = b - t * CK;
+#pragma unroll
+            for (int r = 0; r < C3_TH; ++r) acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[t][ks], pf[b & 1][r], acc[r], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // ---- store: lane holds output channels co0 + 4 g .. + 3 of pixel (h0 + r, w0 + c16)
+        const int ox = w0 + c16;
+#pragma unroll
+        for (int r = 0; r < C3_TH; ++r) {
+            const int oy = h0 + r;
+            if (oy < H && ox < W) {
+                const unsigned lo = pack_bf2(acc[r][0], acc[r][1]), hi = pack_bf2(acc[r][2], acc[r][3]);
+                *reinterpret_cast<uint2*>(y + (((long)n * H + oy) * W + ox) * Cout + co0 + 4 * g) = make_uint2(lo, hi);
+                if constexpr (STATS) {
+                    const float v0 = __uint_as_float(lo << 16), v1 = __uint_as_float(lo & 0xffff0000u);
+                    const float v2 = __uint_as_float(hi << 16), v3 = __uint_as_float(hi & 0xffff0000u);
+                    s1[0] += v0; s1[1] += v1; s1[2] += v2; s1[3] += v3;
+                    s2[0] = fmaf(v0, v0, s2[0]); s2[1] = fmaf(v1, v1, s2[1]); s2[2] = fmaf(v2, v2, s2[2]); s2[3] = fmaf(v3, v3, s2[3]);
+                }
+            }
+        }
+    }
+    if constexpr (STATS) {
+        // the 16 lanes of a group g hold the same 4 channels for 16 different pixels: butterfly over the low 4 lane bits
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int o = 8; o >= 1; o >>= 1) { s1[j] += __shfl_xor(s1[j], o); s2[j] += __shfl_xor(s2[j], o); }
+        if (c16 == 0) {
+            float* p = partials + (long)blockIdx.x * 2 * Cout;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { p[co0 + 4 * g + j] = s1[j]; p[Cout + co0 + 4 * g + j] = s2[j]; }
+        }
+    }
+}
+
+// DFD_EUNSUPPORTED: the shape is not this kernel's (the caller falls back to the implicit GEMM)
+int dfd_conv3_direct(const void* x, const dfd_dwconv_shape* s, const float* in_bnstate, int in_act, const void* w_nk, int Cout,
+                     void* y, float* partials, int pcap, int* nparts, hipStream_t st) {
+    if (s->k != 3 || s->stride != 1 || s->pad_top != 1 || s->pad_left != 1 || s->Ho != s->H || s->Wo != s->W) return DFD_EUNSUPPORTED;
+    if (Cout % 64 || !(s->C == 64 || s->C == 96 || s->C == 128)) return DFD_EUNSUPPORTED;
+    const int tiles_y = (s->H + C3_TH - 1) / C3_TH, tiles_x = (s->W + C3_TW - 1) / C3_TW;
+    const long nwork = (long)s->N * tiles_y * tiles_x;
+    const bool stats = partials != nullptr;
+    long gx = 512;                                       // two workgroups per CU, persistent
+    if (stats) { const long cap = pcap < DFD_MAX_PARTIALS ? pcap : DFD_MAX_PARTIALS; if (gx > cap) gx = cap; }
+    if (gx > nwork) gx = nwork;
+    if (stats) *nparts = (int)gx;
+    const dim3 grid((unsigned)gx, Cout / 64);
+    const size_t lds = (size_t)C3_IH * C3_IW * (s->C + 8) * 2;
+#define C3_LAUNCH(CK, PRO, STATS)                                                                                          \
+    hipLaunchKernelGGL((k_conv3_direct<CK, ACT, PRO, STATS>), grid, dim3(DFD_THREADS), lds, st, (const unsigned short*)x,  \
+                       in_bnstate, (const unsigned short*)w_nk, (unsigned short*)y, partials, s->N, s->H, s->W, Cout, tiles_y, tiles_x)
+#define C3_CK(CK)                                                                                                          \
+    do {                                                                                                                   \
+        if (!in_bnstate) {                                                                                                 \
+            constexpr int ACT = DFD_ACT_NONE;                                                                              \
+            if (stats) C3_LAUNCH(CK, false, true); else C3_LAUNCH(CK, false, false);                                       \
+        } else {                                                                                                           \
+            DISPATCH_ACT_PW(in_act, { if (stats) C3_LAUNCH(CK, true, true); else C3_LAUNCH(CK, true, false); });           \
+        }                                                                                                                  \
+    } while (0)
+    if (s->C == 64) C3_CK(2);
+    else if (s->C == 96) C3_CK(3);
+    else C3_CK(4);
+#undef C3_CK
+#undef C3_LAUNCH
+    return DFD_CHECK_LAUNCH();
+}

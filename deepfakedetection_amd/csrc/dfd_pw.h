@@ -187,6 +187,11 @@ int dfd_pw_ntw(int dtype, const void* a, const dfd_prologue* pro, const void* w,
                int K, int Nout, float* partials, int pcap, int* nparts, hipStream_t st, const float* ebn = nullptr,
                int eact = DFD_ACT_NONE);
 
+// direct 3x3 stride-1 pad-1 dense convolution with resident weights (dfd_conv3.hip, bf16 only); DFD_EUNSUPPORTED when the shape
+// does not qualify (dfd_conv_fwd then runs the implicit GEMM)
+int dfd_conv3_direct(const void* x, const dfd_dwconv_shape* s, const float* in_bnstate, int in_act, const void* w_nk, int Cout,
+                     void* y, float* partials, int pcap, int* nparts, hipStream_t st);
+
 // wave-autonomous TN (weight-gradient) kernel for large-M layers with a narrow and a wide operand
 // (dfd_pwtnw.hip, bf16 only); DFD_EUNSUPPORTED when the shape does not qualify
 int dfd_pw_tnw(const void* p, const dfd_prologue* pro_p, int Ni, const void* q, const dfd_prologue* pro_q, int Nj, int M,

@@ -803,6 +803,10 @@ extern "C" int dfd_conv_fwd(int dtype, const void* x, const dfd_dwconv_shape* s,
     if (partials && (!nparts || pcap < 1)) return DFD_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     const long M = (long)s->N * s->Ho * s->Wo;
+    if (dtype == DFD_BF16) {                             // 3x3 stride 1: direct kernel, weights resident in registers
+        const int rc = dfd_conv3_direct(x, s, in_bnstate, in_act, w_nk, Cout, y, partials, pcap, nparts, st);
+        if (rc != DFD_EUNSUPPORTED) return rc;
+    }
     const bool small = ((M + 127) / 128) * ((Cout + 127) / 128) < 256;
 #define CONV_GO(TT, BNV) return small ? conv_nt_launch<TT, BNV, 64>(x, s, in_bnstate, in_act, w_nk, y, Cout, partials, pcap, nparts, st) \
                                       : conv_nt_launch<TT, BNV, 128>(x, s, in_bnstate, in_act, w_nk, y, Cout, partials, pcap, nparts, st)
