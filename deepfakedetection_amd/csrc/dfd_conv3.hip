@@ -175,3 +175,170 @@ int dfd_conv3_direct(const void* x, const dfd_dwconv_shape* s, const float* in_b
 #undef C3_LAUNCH
     return DFD_CHECK_LAUNCH();
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// weight gradient of the same layers: dw[co][tap][ci] = sum over output pixels of P(dy)[pix][co] * act(x)[pix + tap][ci]
+// (P = the BatchNorm-backward map c0 dy + c1 y + c2 of the layer's own BN, or nothing).  The implicit TN GEMM
+// (k_pw_tn<.., CONV>) re-gathers and re-activates x for each of the 9 taps and runs at ~150 TFLOP/s (212-390 us per layer).
+// Here the OUTPUT stays in registers instead: a workgroup owns 64 output channels x 64 input channels x 9 taps (36 16x16
+// accumulator tiles per wave: wave w owns input-channel tile w, all four output-channel tiles and all taps) for the whole
+// persistent loop over 4 x 32 pixel tiles; per tile the activated x (with halo) and the mapped dy are staged in LDS once and
+// both MFMA operands — k = 32 pixels of one tile row — come from transposed LDS reads (ds_read_tr16_b64: 4 pixels x 16
+// channels per 16 lanes), the tap being nothing but an address offset.  Per 32-pixel step: 8 + 18 transposed reads for 36
+// MFMAs.  Each workgroup writes its 64 x 9 x 64 partial block at the end; dfd_sum_partials adds the rows in a fixed order.
+typedef __attribute__((address_space(3))) short4_t c3_lds_short4;
+#define C3W_TH 4
+#define C3W_TW 32
+#define C3W_IH (C3W_TH + 2)
+#define C3W_IW (C3W_TW + 2)
+#define C3W_PITCH 80             // elements per staged pixel (64 channels + 16: pixels 40 banks apart, conflict-free 8-byte reads)
+
+template <int ACT, bool PROX, bool PROP>
+__global__ void __launch_bounds__(DFD_THREADS, 2)
+k_conv3_wgrad(const unsigned short* __restrict__ dy, const unsigned short* __restrict__ y2, const float* __restrict__ coefp,
+              const unsigned short* __restrict__ x, const float* __restrict__ in_bn, float* __restrict__ slab,
+              int N, int H, int W, int C, int Cout, int tiles_y, int tiles_x) {
+    __shared__ __attribute__((aligned(16))) unsigned short xt[C3W_IH * C3W_IW * C3W_PITCH];
+    __shared__ __attribute__((aligned(16))) unsigned short dt[C3W_TH * C3W_TW * C3W_PITCH];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, c16 = lane & 15, g = lane >> 4, q = c16 >> 2, p = c16 & 3;
+    const int cgroups = C >> 6;
+    const int cig = blockIdx.y % cgroups, cog = blockIdx.y / cgroups;
+    const int ci0 = cig * 64, co0 = cog * 64;
+    f32x4_t acc[9][4];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int o = 0; o < 4; ++o) acc[t][o] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    const int tiles = tiles_y * tiles_x;
+    const long nwork = (long)N * tiles;
+    for (long work = blockIdx.x; work < nwork; work += gridDim.x) {
+        const int n = (int)(work / tiles), tr = (int)(work - (long)n * tiles);
+        const int ty = tr / tiles_x, tx = tr - ty * tiles_x;
+        const int h0 = ty * C3W_TH, w0 = tx * C3W_TW;
+        __syncthreads();
+        // ---- x tile with halo (this workgroup's 64 input channels), producer's BN + activation once per element
+        for (int i = threadIdx.x; i < C3W_IH * C3W_IW * 8; i += DFD_THREADS) {
+            const int pix = i >> 3, v = i & 7;
+            const int iy = pix / C3W_IW, ix = pix - iy * C3W_IW;
+            const int gy = h0 - 1 + iy, gx = w0 - 1 + ix;
+            uint4 r = make_uint4(0, 0, 0, 0);
+            if ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) {
+                r = *reinterpret_cast<const uint4*>(x + (((long)n * H + gy) * W + gx) * C + ci0 + v * 8);
+                if constexpr (PROX) {
+                    float f[8], sc[8], sh[8];
+                    Vec<bf16>::unpack(r, f);
+                    load_f32<8>(in_bn + ci0 + v * 8, sc);
+                    load_f32<8>(in_bn + C + ci0 + v * 8, sh);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) f[j] = act_fwd<ACT>(fmaf(sc[j], f[j], sh[j]));
+                    r = Vec<bf16>::pack(f);
+                }
+            }
+            *reinterpret_cast<uint4*>(xt + pix * C3W_PITCH + v * 8) = r;
+        }
+        // ---- dy tile (this workgroup's 64 output channels), BatchNorm-backward map once per element; zero outside the image
+        for (int i = threadIdx.x; i < C3W_TH * C3W_TW * 8; i += DFD_THREADS) {
+            const int pix = i >> 3, v = i & 7;
+            const int iy = pix / C3W_TW, ix = pix - iy * C3W_TW;
+            const int gy = h0 + iy, gx = w0 + ix;
+            uint4 r = make_uint4(0, 0, 0, 0);
+            if (gy < H && gx < W) {
+                const long off = (((long)n * H + gy) * W + gx) * Cout + co0 + v * 8;
+                r = *reinterpret_cast<const uint4*>(dy + off);
+                if constexpr (PROP) {
+                    const uint4 r2 = *reinterpret_cast<const uint4*>(y2 + off);
+                    float f[8], f2[8], k0[8], k1[8], k2[8];
+                    Vec<bf16>::unpack(r, f);
+                    Vec<bf16>::unpack(r2, f2);
+                    load_f32<8>(coefp + co0 + v * 8, k0);
+                    load_f32<8>(coefp + Cout + co0 + v * 8, k1);
+                    load_f32<8>(coefp + 2 * Cout + co0 + v * 8, k2);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) f[j] = fmaf(k0[j], f[j], fmaf(k1[j], f2[j], k2[j]));
+                    r = Vec<bf16>::pack(f);
+                }
+            }
+            *reinterpret_cast<uint4*>(dt + pix * C3W_PITCH + v * 8) = r;
+        }
+        __syncthreads();
+        // ---- k-step = one tile row of 32 pixels; slot (g, j) = pixel column 16 (j >> 2) + 4 g + (j & 3)
+        // transposed read: lane 4 q + p of group g supplies the address of pixel 4 g + q, channels 4 p .. 4 p + 3
+        const unsigned short* da = dt + (4 * g + q) * C3W_PITCH + 4 * p;
+        const unsigned short* xa = xt + (4 * g + q) * C3W_PITCH + 16 * wave + 4 * p;
+#pragma unroll
+        for (int ks = 0; ks < C3W_TH; ++ks) {
+            bf16x8_t af[4];
+#pragma unroll
+            for (int o = 0; o < 4; ++o) {
+                const unsigned short* a = da + ks * C3W_TW * C3W_PITCH + 16 * o;
+                const short4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((c3_lds_short4*)(a));
+                const short4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((c3_lds_short4*)(a + 16 * C3W_PITCH));
+                af[o] = __builtin_bit_cast(bf16x8_t, (short8_t){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]});
+            }
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int kh = t / 3, kw = t - 3 * kh;
+                const unsigned short* b = xa + ((ks + kh) * C3W_IW + kw) * C3W_PITCH;
+                const short4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((c3_lds_short4*)(b));
+                const short4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((c3_lds_short4*)(b + 16 * C3W_PITCH));
+                const bf16x8_t bfrag = __builtin_bit_cast(bf16x8_t, (short8_t){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]});
+#pragma unroll
+                for (int o = 0; o < 4; ++o) acc[t][o] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[o], bfrag, acc[t][o], 0, 0, 0);
+            }
+        }
+    }
+    // ---- partial block: lane holds dw[co0 + 16 o + 4 g + r][tap][ci0 + 16 wave + c16]
+    float* out = slab + (long)blockIdx.x * Cout * 9 * C;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int o = 0; o < 4; ++o)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                out[(long)(co0 + 16 * o + 4 * g + r) * 9 * C + t * C + ci0 + 16 * wave + c16] = acc[t][o][r];
+}
+
+static bool conv3_wgrad_shape_ok(const dfd_dwconv_shape* s, int Cout) {
+    return s->k == 3 && s->stride == 1 && s->pad_top == 1 && s->pad_left == 1 && s->Ho == s->H && s->Wo == s->W && s->C % 64 == 0 &&
+           Cout % 64 == 0 && s->C <= 512 && Cout <= 512;
+}
+static int conv3_wgrad_rows(const dfd_dwconv_shape* s, int Cout) {
+    const int gy = (s->C / 64) * (Cout / 64);
+    const long nwork = (long)s->N * ((s->H + C3W_TH - 1) / C3W_TH) * ((s->W + C3W_TW - 1) / C3W_TW);
+    long gx = 512 / gy;
+    if (gx < 1) gx = 1;
+    if (gx > nwork) gx = nwork;
+    return (int)gx;
+}
+// workspace floats' bytes the direct kernel needs (0: shape not served)
+size_t dfd_conv3_wgrad_ws(const dfd_dwconv_shape* s, int Cout) {
+    if (!conv3_wgrad_shape_ok(s, Cout)) return 0;
+    const int gx = conv3_wgrad_rows(s, Cout);
+    return (size_t)(gx + gx / 32 + 2) * Cout * 9 * s->C * 4;
+}
+// DFD_EUNSUPPORTED: the shape / prologue is not this kernel's (the caller falls back to the implicit TN GEMM)
+int dfd_conv3_wgrad(const void* p, const dfd_prologue* pro_p, int Cout, const void* x, const dfd_dwconv_shape* s,
+                    const float* in_bnstate, int in_act, float* dw, int accumulate, float* ws, size_t ws_bytes, hipStream_t st) {
+    if (!conv3_wgrad_shape_ok(s, Cout)) return DFD_EUNSUPPORTED;
+    const int mp = pro_p ? pro_p->mode : DFD_PRO_NONE;
+    if (!(mp == DFD_PRO_NONE || mp == DFD_PRO_AFFINE2)) return DFD_EUNSUPPORTED;
+    if (dfd_conv3_wgrad_ws(s, Cout) > ws_bytes) return DFD_EWORKSPACE;
+    const int gx = conv3_wgrad_rows(s, Cout);
+    const int tiles_y = (s->H + C3W_TH - 1) / C3W_TH, tiles_x = (s->W + C3W_TW - 1) / C3W_TW;
+    const dim3 grid(gx, (s->C / 64) * (Cout / 64));
+    const unsigned short* y2 = mp == DFD_PRO_AFFINE2 ? (const unsigned short*)pro_p->a2 : nullptr;
+    const float* coefp = mp == DFD_PRO_AFFINE2 ? pro_p->coef : nullptr;
+#define C3W_LAUNCH(PROX, PROP)                                                                                              \
+    hipLaunchKernelGGL((k_conv3_wgrad<ACT, PROX, PROP>), grid, dim3(DFD_THREADS), 0, st, (const unsigned short*)p, y2, coefp, \
+                       (const unsigned short*)x, in_bnstate, ws, s->N, s->H, s->W, s->C, Cout, tiles_y, tiles_x)
+    if (!in_bnstate) {
+        constexpr int ACT = DFD_ACT_NONE;
+        if (mp == DFD_PRO_AFFINE2) C3W_LAUNCH(false, true); else C3W_LAUNCH(false, false);
+    } else {
+        DISPATCH_ACT_PW(in_act, { if (mp == DFD_PRO_AFFINE2) C3W_LAUNCH(true, true); else C3W_LAUNCH(true, false); });
+    }
+#undef C3W_LAUNCH
+    if (hipGetLastError() != hipSuccess) return DFD_ELAUNCH;
+    // dw is in GEMM layout: the caller's dfd_conv_weight_perm reads it next, so the sum is not left to an open batch
+    return dfd_launch_sum_partials(ws, gx, (long)Cout * 9 * s->C, dw, accumulate, st, false);
+}

@@ -191,6 +191,10 @@ int dfd_pw_ntw(int dtype, const void* a, const dfd_prologue* pro, const void* w,
 // does not qualify (dfd_conv_fwd then runs the implicit GEMM)
 int dfd_conv3_direct(const void* x, const dfd_dwconv_shape* s, const float* in_bnstate, int in_act, const void* w_nk, int Cout,
                      void* y, float* partials, int pcap, int* nparts, hipStream_t st);
+// its weight gradient (output block resident in registers); ws bytes it needs (0: shape not served)
+size_t dfd_conv3_wgrad_ws(const dfd_dwconv_shape* s, int Cout);
+int dfd_conv3_wgrad(const void* p, const dfd_prologue* pro_p, int Cout, const void* x, const dfd_dwconv_shape* s,
+                    const float* in_bnstate, int in_act, float* dw, int accumulate, float* ws, size_t ws_bytes, hipStream_t st);
 
 // wave-autonomous TN (weight-gradient) kernel for large-M layers with a narrow and a wide operand
 // (dfd_pwtnw.hip, bf16 only); DFD_EUNSUPPORTED when the shape does not qualify

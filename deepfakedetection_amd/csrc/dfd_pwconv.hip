@@ -355,6 +355,9 @@ k_pw_nt(const T* __restrict__ a, ProArgs pa, const T* __restrict__ w, T* __restr
 // tile rows are m (the reduction index); bf16: 64 rows x 256 B, f32: 32 rows x (512+64) B
 // ===========================================================================
 #define TN_B 128   // output tile edge (channels of p and of q)
+#ifndef TN_TARGET_WGS
+#define TN_TARGET_WGS 512   // workgroups a weight-gradient launch aims for (tiles x row splits)
+#endif
 #ifndef TN_MIN_STEPS
 #define TN_MIN_STEPS 8   // reduction steps a row split must have (fewer splits = fewer partial rows, less parallelism)
 #endif
@@ -846,7 +849,7 @@ static void tn_plan(int dtype, int M, int Ni, int Nj, int* i_tiles, int* j_tiles
     *i_tiles = (Ni + TN_B - 1) / TN_B;
     *j_tiles = (Nj + TN_B - 1) / TN_B;
     const int tiles = *i_tiles * *j_tiles;
-    int s = 1024 / tiles;
+    int s = TN_TARGET_WGS / tiles;
     if (s < 1) s = 1;
     // keep the slab under 64 MiB and give each split at least 8 reduction steps
     const long per = (long)Ni * Nj * 4;
@@ -949,7 +952,8 @@ static int conv_tn_t(const void* p, const dfd_prologue* pro_p, int Cout, const v
 
 extern "C" size_t dfd_conv_wgrad_ws(const dfd_dwconv_shape* s, int Cout) {
     if (!s || Cout < 1) return 0;
-    return dfd_pwconv_wgrad_ws(s->N * s->Ho * s->Wo, Cout, s->k * s->k * s->C);
+    const size_t a = dfd_pwconv_wgrad_ws(s->N * s->Ho * s->Wo, Cout, s->k * s->k * s->C), b = dfd_conv3_wgrad_ws(s, Cout);
+    return a > b ? a : b;
 }
 extern "C" int dfd_conv_wgrad(int dtype, const void* p, const dfd_prologue* pro_p, int Cout, const void* x,
                               const dfd_dwconv_shape* s, const float* in_bnstate, int in_act, float* dw, int accumulate,
@@ -957,7 +961,11 @@ extern "C" int dfd_conv_wgrad(int dtype, const void* p, const dfd_prologue* pro_
     if (!p || !x || !s || !dw || !ws || Cout < 8 || Cout % 8 || s->C < 8 || s->C % 8 || !pro_ok(pro_p)) return DFD_EINVAL;
     if (s->N < 1 || s->Ho < 1 || s->Wo < 1 || (long)s->N * s->Ho * s->Wo > (1l << 30)) return DFD_EINVAL;
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == DFD_BF16) return conv_tn_t<bf16>(p, pro_p, Cout, x, s, in_bnstate, in_act, dw, accumulate, ws, ws_bytes, st);
+    if (dtype == DFD_BF16) {                             // 3x3 stride 1: direct kernel, output block resident in registers
+        const int rc = dfd_conv3_wgrad(p, pro_p, Cout, x, s, in_bnstate, in_act, dw, accumulate, ws, ws_bytes, st);
+        if (rc != DFD_EUNSUPPORTED) return rc;
+        return conv_tn_t<bf16>(p, pro_p, Cout, x, s, in_bnstate, in_act, dw, accumulate, ws, ws_bytes, st);
+    }
     if (dtype == DFD_F32) return conv_tn_t<float>(p, pro_p, Cout, x, s, in_bnstate, in_act, dw, accumulate, ws, ws_bytes, st);
     return DFD_EINVAL;
 }

@@ -536,13 +536,16 @@ def test_dense_conv_as_implicit_gemm(rd, cfg):
 
 
 @pytest.mark.parametrize("rd", DT)
-@pytest.mark.parametrize("cfg", [(3, 1, 1, 64, 64, 28, 6), (3, 2, 1, 24, 48, 15, 3), (3, 1, 1, 128, 128, 9, 5), (3, 2, 1, 96, 192, 14, 2)])
+@pytest.mark.parametrize("cfg", [(3, 1, 1, 64, 64, 28, 6), (3, 2, 1, 24, 48, 15, 3), (3, 1, 1, 128, 128, 9, 5), (3, 2, 1, 96, 192, 14, 2),
+                                 (3, 1, 1, 64, 128, 56, 3), (3, 1, 1, 128, 64, 33, 2), (3, 1, 1, 192, 64, 7, 40), (3, 1, 1, 96, 64, 14, 3)])
 def test_dense_conv_weight_gradient_as_implicit_gemm(rd, cfg):
-    """dfd_conv_wgrad (the TN kernel gathers the im2col operand) against im2col + dfd_pwconv_wgrad: same kernel, same
-    split of the rows, same summation order -> identical; with the BN-backward map on the gradient operand and the
-    producer's BN + GELU on the gathered one."""
+    """dfd_conv_wgrad against im2col + dfd_pwconv_wgrad; with the BN-backward map on the gradient operand and the producer's
+    BN + GELU on the gathered one.  The TN kernel that gathers the im2col operand: same kernel, same split of the rows, same
+    summation order -> identical.  bf16 3x3 stride-1 layers with channel counts that are multiples of 64 run the direct kernel
+    (dfd_conv3.hip, output block resident in registers): another f32 summation order -> 1e-5 of the largest entry."""
     K = _k()
     k, s, p, C, Co, H, N = cfg
+    direct = rd == torch.bfloat16 and k == 3 and s == 1 and p == 1 and C % 64 == 0 and Co % 64 == 0
     Ho = (H + 2 * p - k) // s + 1
     x = gen((N, H, H, C), 1, rd).cuda()
     st = rand_state(C, 2).cuda()
@@ -553,7 +556,10 @@ def test_dense_conv_weight_gradient_as_implicit_gemm(rd, cfg):
             col = K.im2col(x, state, act, k, s, p, Ho, Ho)
             want = K.pwconv_wgrad(dz, pro_p, col, None)
             got = K.conv_wgrad(dz, pro_p, x, state, act, k, s, p)
-            assert torch.equal(want, got), float((want - got).abs().max())
+            if direct:
+                assert float((want - got).abs().max()) <= 1e-5 * float(want.abs().max()), (float((want - got).abs().max()), float(want.abs().max()))
+            else:
+                assert torch.equal(want, got), float((want - got).abs().max())
 
 
 @pytest.mark.parametrize("rd", DT)
