@@ -216,15 +216,36 @@ k_conv3_wgrad(const unsigned short* __restrict__ dy, const unsigned short* __res
         const int ty = tr / tiles_x, tx = tr - ty * tiles_x;
         const int h0 = ty * C3W_TH, w0 = tx * C3W_TW;
         __syncthreads();
-        // ---- x tile with halo (this workgroup's 64 input channels), producer's BN + activation once per element
-        for (int i = threadIdx.x; i < C3W_IH * C3W_IW * 8; i += DFD_THREADS) {
-            const int pix = i >> 3, v = i & 7;
+        // ---- every global load of the tile is issued before the first use (one exposed memory latency per tile, not eleven)
+        constexpr int XV = (C3W_IH * C3W_IW * 8 + DFD_THREADS - 1) / DFD_THREADS, DV = C3W_TH * C3W_TW * 8 / DFD_THREADS;
+        uint4 xr[XV], dr[DV], d2[PROP ? DV : 1];
+        bool xok[XV], dok[DV];
+#pragma unroll
+        for (int u = 0; u < XV; ++u) {
+            const int i = threadIdx.x + u * DFD_THREADS, pix = i >> 3, v = i & 7;
             const int iy = pix / C3W_IW, ix = pix - iy * C3W_IW;
             const int gy = h0 - 1 + iy, gx = w0 - 1 + ix;
-            uint4 r = make_uint4(0, 0, 0, 0);
-            if ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) {
-                r = *reinterpret_cast<const uint4*>(x + (((long)n * H + gy) * W + gx) * C + ci0 + v * 8);
-                if constexpr (PROX) {
+            xok[u] = i < C3W_IH * C3W_IW * 8 && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+            xr[u] = make_uint4(0, 0, 0, 0);
+            if (xok[u]) xr[u] = *reinterpret_cast<const uint4*>(x + (((long)n * H + gy) * W + gx) * C + ci0 + v * 8);
+        }
+#pragma unroll
+        for (int u = 0; u < DV; ++u) {
+            const int i = threadIdx.x + u * DFD_THREADS, pix = i >> 3, v = i & 7;
+            const int iy = pix / C3W_TW, ix = pix - iy * C3W_TW;
+            const int gy = h0 + iy, gx = w0 + ix;
+            dok[u] = gy < H && gx < W;
+            dr[u] = make_uint4(0, 0, 0, 0);
+            if (dok[u]) dr[u] = *reinterpret_cast<const uint4*>(dy + (((long)n * H + gy) * W + gx) * Cout + co0 + v * 8);
+        }
+        // ---- x tile with halo (this workgroup's 64 input channels), producer's BN + activation once per element
+#pragma unroll
+        for (int u = 0; u < XV; ++u) {
+            const int i = threadIdx.x + u * DFD_THREADS, pix = i >> 3, v = i & 7;
+            if (i >= C3W_IH * C3W_IW * 8) continue;
+            uint4 r = xr[u];
+            if constexpr (PROX) {
+                if (xok[u]) {
                     float f[8], sc[8], sh[8];
                     Vec<bf16>::unpack(r, f);
                     load_f32<8>(in_bn + ci0 + v * 8, sc);
@@ -237,19 +258,24 @@ k_conv3_wgrad(const unsigned short* __restrict__ dy, const unsigned short* __res
             *reinterpret_cast<uint4*>(xt + pix * C3W_PITCH + v * 8) = r;
         }
         // ---- dy tile (this workgroup's 64 output channels), BatchNorm-backward map once per element; zero outside the image
-        for (int i = threadIdx.x; i < C3W_TH * C3W_TW * 8; i += DFD_THREADS) {
-            const int pix = i >> 3, v = i & 7;
-            const int iy = pix / C3W_TW, ix = pix - iy * C3W_TW;
-            const int gy = h0 + iy, gx = w0 + ix;
-            uint4 r = make_uint4(0, 0, 0, 0);
-            if (gy < H && gx < W) {
-                const long off = (((long)n * H + gy) * W + gx) * Cout + co0 + v * 8;
-                r = *reinterpret_cast<const uint4*>(dy + off);
-                if constexpr (PROP) {
-                    const uint4 r2 = *reinterpret_cast<const uint4*>(y2 + off);
+        if constexpr (PROP) {                            // the map's second operand: loaded once the x registers are free again
+#pragma unroll
+            for (int u = 0; u < DV; ++u) {
+                const int i = threadIdx.x + u * DFD_THREADS, pix = i >> 3, v = i & 7;
+                const int iy = pix / C3W_TW, ix = pix - iy * C3W_TW;
+                d2[u] = make_uint4(0, 0, 0, 0);
+                if (dok[u]) d2[u] = *reinterpret_cast<const uint4*>(y2 + (((long)n * H + h0 + iy) * W + w0 + ix) * Cout + co0 + v * 8);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < DV; ++u) {
+            const int i = threadIdx.x + u * DFD_THREADS, pix = i >> 3, v = i & 7;
+            uint4 r = dr[u];
+            if constexpr (PROP) {
+                if (dok[u]) {
                     float f[8], f2[8], k0[8], k1[8], k2[8];
                     Vec<bf16>::unpack(r, f);
-                    Vec<bf16>::unpack(r2, f2);
+                    Vec<bf16>::unpack(d2[u], f2);
                     load_f32<8>(coefp + co0 + v * 8, k0);
                     load_f32<8>(coefp + Cout + co0 + v * 8, k1);
                     load_f32<8>(coefp + 2 * Cout + co0 + v * 8, k2);
