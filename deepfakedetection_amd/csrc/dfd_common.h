@@ -183,6 +183,12 @@ __device__ __forceinline__ void reduce_rowlanes(float (&acc)[NV], float* red, in
     __syncthreads();
 }
 
+// stem convolution on the matrix cores (dfd_stem.hip, bf16); DFD_EUNSUPPORTED: shape not served, the f32-FMA kernels run
+int dfd_stem_fwd_mfma(const float* x, const float* w, void* y, const dfd_stem_shape* s, float* partials, int pcap, int* nparts,
+                      hipStream_t st);
+int dfd_stem_wgrad_mfma(const float* x, const void* dz, const void* yraw, const float* coef, const dfd_stem_shape* s, float* ws,
+                        int max_rows, int* rows, hipStream_t st);
+
 #define DFD_CHECK_LAUNCH() (hipGetLastError() == hipSuccess ? DFD_OK : DFD_ELAUNCH)
 
 // dispatch a runtime activation code to a constexpr int ACT inside the body

@@ -684,7 +684,11 @@ extern "C" int dfd_stem_conv_fwd(int dtype, const float* x, const float* w, void
     if (!stem_ok(s)) return s && s->k != 3 ? DFD_EUNSUPPORTED : DFD_EINVAL;
     if (partials && (!nparts || pcap < 1)) return DFD_EINVAL;
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == DFD_BF16) return stem_fwd_t<bf16>(x, w, y, s, partials, pcap, nparts, st);
+    if (dtype == DFD_BF16) {
+        const int rc = dfd_stem_fwd_mfma(x, w, y, s, partials, pcap, nparts, st);
+        if (rc != DFD_EUNSUPPORTED) return rc;
+        return stem_fwd_t<bf16>(x, w, y, s, partials, pcap, nparts, st);
+    }
     if (dtype == DFD_F32) return stem_fwd_t<float>(x, w, y, s, partials, pcap, nparts, st);
     return DFD_EINVAL;
 }
@@ -708,6 +712,12 @@ extern "C" int dfd_stem_conv_wgrad(int dtype, const float* x, const void* dz, co
     const int P = stem_wgrad_blocks(s);
     if ((size_t)(P + P / 32 + 2) * s->Cout * 27 * 4 > ws_bytes) return DFD_EWORKSPACE;
     hipStream_t st = (hipStream_t)stream;
+    if (dtype == DFD_BF16) {
+        int rows = 0;
+        const int rc = dfd_stem_wgrad_mfma(x, dz, y, coef, s, ws, 1024, &rows, st);
+        if (rc == DFD_OK) return dfd_launch_sum_partials(ws, rows, (long)s->Cout * 27, dw, accumulate, st);
+        if (rc != DFD_EUNSUPPORTED) return rc;
+    }
     if (dtype == DFD_BF16)
         hipLaunchKernelGGL((k_stem_wgrad<bf16, 3>), dim3(P), dim3(DFD_THREADS), 0, st, x, (const bf16*)dz, (const bf16*)y, coef, *s, ws);
     else if (dtype == DFD_F32)

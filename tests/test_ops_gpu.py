@@ -448,8 +448,12 @@ def test_se_branch_in_one_call_each_way(rd, case):
 
 
 @pytest.mark.parametrize("rd", DT)
-@pytest.mark.parametrize("case", [(2, 32, 32, 32, 0), (2, 33, 31, 40, 1), (1, 224, 224, 32, 1)])
+@pytest.mark.parametrize("case", [(2, 32, 32, 32, 0), (2, 33, 31, 40, 1), (1, 224, 224, 32, 1), (3, 64, 60, 64, 1), (2, 50, 36, 16, 1),
+                                  (2, 40, 44, 48, 0), (5, 224, 224, 64, 1), (2, 38, 300, 32, 1)])
 def test_stem(case, rd):
+    """stem convolution and its weight gradient.  bf16 with Cout % 16 == 0 and W % 4 == 0 runs the matrix-core kernels
+    (dfd_stem.hip: ragged last 16- / 32-pixel tile, odd row counts, 48 channels, rows wider than one staging pass), everything
+    else the f32-FMA kernels."""
     K = _k()
     N, H, W, Co, pad = case
     Ho, Wo = -(-H // 2), -(-W // 2)
@@ -466,6 +470,9 @@ def test_stem(case, rd):
     want_dw = R.stem_conv_wgrad(x, dy, 3, 2, pad, pad, rd)
     got = K.stem_conv_wgrad(dev(x), dev(dz), dev(yraw), dev(coef), 3, 2, pad, pad)
     close(got, want_dw, 5e-3 if rd == torch.bfloat16 else 2e-4, "stem wgrad")
+    want_plain = R.stem_conv_wgrad(x, dz.float(), 3, 2, pad, pad, rd)
+    got_plain = K.stem_conv_wgrad(dev(x), dev(dz), None, None, 3, 2, pad, pad)
+    close(got_plain, want_plain, 5e-3 if rd == torch.bfloat16 else 2e-4, "stem wgrad without the BN-backward map")
 
 
 @pytest.mark.parametrize("J", [2, 10, 1000])
