@@ -346,13 +346,16 @@ def mlp_sub_bwd(g, saved, P, ls, row_scale, need: dict, need_dx: bool):
     coef2, _, db2, dls, _ = K.bn_bwd_finalize_ex(parts, n, _rows(y2), ones2, P["fc2_b"], ls, st2, False, need["fc2_b"] or True, need["ls"],
                                                  False, outs)
     grads["fc2_b"], grads["ls"] = (db2 if need["fc2_b"] else None), dls
-    pro2 = K.pro_affine2(y2, coef2)
+    # fc2 has no BatchNorm: the backward map of its identity statistic is dz = ls * g.  Without layer scale that is g itself;
+    # with it the scaled gradient is materialised once (as a GEMM prologue it was evaluated once per 128-column tile of the
+    # data gradient — 8 times per element at hidden 1024 — and read y2 only to multiply it by zero)
+    dz2 = gb if ls is None else K.affine2_apply(gb, y2, coef2)
     upstream = need_dx or any(need[k] for k in ("ln_w", "ln_b", "fc1_w", "fc1_b"))
     if need["fc2_w"]:
-        grads["fc2_w"] = K.pwconv_wgrad(gb, pro2, a, None, _slot(P["fc2_w"], True, (C, hid))).view(P["fc2_w"].shape)
+        grads["fc2_w"] = K.pwconv_wgrad(dz2, None, a, None, _slot(P["fc2_w"], True, (C, hid))).view(P["fc2_w"].shape)
     if not upstream:
         return None, grads
-    D, _, _ = K.pwconv(gb, pro2, w2_kn, None, stats=False)
+    D, _, _ = K.pwconv(dz2, None, w2_kn, None, stats=False)
     dz1, parts, n = K.act_bn_bwd(D, h, None, None, st1, ACT_GELU)
     if need["fc1_b"]:
         ones1, _ = ident(dev, hid)
@@ -569,25 +572,25 @@ class ConvBlockFunction(torch.autograd.Function):
         outs = (_slot(g2, nb2, (C,)), _slot(be2, nb2, (C,)), _slot(gamma, need[9], (C,)), _slot(b2, need[6], (C,)))
         coef2, dg2, dbe2, dgam, db2 = K.bn_bwd_finalize_ex(parts, n, rows, g2, be2, gamma, st2, tr, nb2, need[9] and gamma is not None,
                                                            need[6], outs)
-        pro2 = K.pro_affine2(y2, coef2)
+        dz2 = K.affine2_apply(gb, y2, coef2)              # the BN-backward-mapped gradient, once for both consumers
         dw2 = None
         if need[5]:
-            dwg = K.conv_wgrad(gb, pro2, y1, st1, ACT_GELU, 3, 1, 1)
+            dwg = K.conv_wgrad(dz2, None, y1, st1, ACT_GELU, 3, 1, 1)
             dw2 = K.conv_wgrad_from_gemm(dwg, tuple(w2.shape), _slot(w2, True, tuple(w2.shape)))
-        # data gradient of a stride-1 convolution = the forward (implicit-GEMM) convolution of the BN-backward-mapped
-        # gradient with the flipped, transposed weight: no [M][9C] column matrix, no col2im
-        da1, _, _ = K.conv_fwd(K.affine2_apply(gb, y2, coef2), None, ACT_NONE, w2_kn, 3, 1, 1, H, W, stats=False)
+        # data gradient of a stride-1 convolution = the forward convolution of the BN-backward-mapped gradient with the
+        # flipped, transposed weight: no [M][9C] column matrix, no col2im
+        da1, _, _ = K.conv_fwd(dz2, None, ACT_NONE, w2_kn, 3, 1, 1, H, W, stats=False)
         dz1, parts, n = K.act_bn_bwd(da1, y1, None, None, st1, ACT_GELU)
         nb1 = need[3] or need[4]
         outs = (_slot(g1, nb1, (C,)), _slot(be1, nb1, (C,)), None, _slot(b1, need[2], (C,)))
         coef1, dg1, dbe1, _, db1 = K.bn_bwd_finalize_ex(parts, n, rows, g1, be1, None, st1, tr, nb1, False, need[2], outs)
-        pro1 = K.pro_affine2(y1, coef1)
         dw1 = dx = None
+        dzm1 = K.affine2_apply(dz1, y1, coef1) if (need[0] or need[1]) else None
         if need[1]:
-            dwg = K.conv_wgrad(dz1, pro1, x, None, ACT_NONE, 3, 1, 1)
+            dwg = K.conv_wgrad(dzm1, None, x, None, ACT_NONE, 3, 1, 1)
             dw1 = K.conv_wgrad_from_gemm(dwg, tuple(w1.shape), _slot(w1, True, tuple(w1.shape)))
         if need[0]:
-            dx0, _, _ = K.conv_fwd(K.affine2_apply(dz1, y1, coef1), None, ACT_NONE, w1_kn, 3, 1, 1, H, W, stats=False)
+            dx0, _, _ = K.conv_fwd(dzm1, None, ACT_NONE, w1_kn, 3, 1, 1, H, W, stats=False)
             dx = K.add(dx0, g)
         return (dx, dw1, db1 if need[2] else None, dg1, dbe1, dw2, db2 if need[6] else None, dg2, dbe2, dgam, None, None)
 
