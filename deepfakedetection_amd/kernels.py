@@ -220,6 +220,7 @@ class _SumBatchState(threading.local):
 
 
 _sum_batch = _SumBatchState()
+_DEFER_SUMS = os.environ.get("DFD_DEFER_SUMS", "1") != "0"      # A/B switch: 0 = every weight gradient sums its slab at once
 
 
 @contextlib.contextmanager
@@ -228,7 +229,7 @@ def sum_batch():
     one pair of launches adds them all (dfd_sum_batch_begin / _end): the returned gradient tensors are valid only after
     the block.  Nothing inside may read them, and nothing else that sums partial rows may run inside.  No-op when
     nested or when the side stream is enabled (the sums would be launched on the wrong stream)."""
-    if _sum_batch.open or _side_enabled:
+    if _sum_batch.open or _side_enabled or not _DEFER_SUMS:
         yield
         return
     check(_L().dfd_sum_batch_begin(), "dfd_sum_batch_begin")
