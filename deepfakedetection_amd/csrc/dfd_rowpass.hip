@@ -55,7 +55,7 @@ k_scale_rows(const T* __restrict__ x, const float* __restrict__ rs, T* __restric
 
 // ------------------------------------------------------------------ bn_bwd_reduce
 // partials[pb][0][c] = sum g*rs ; partials[pb][1][c] = sum g*rs*xhat
-template <typename T, bool HAS_RS>
+template <typename T, bool HAS_RS, bool HAS_Y = true>      // HAS_Y false: only sum g (second sum 0): layers without statistics
 __global__ void __launch_bounds__(DFD_THREADS)
 k_bn_bwd_reduce(const T* __restrict__ g, const T* __restrict__ y, const float* __restrict__ bnstate,
                 const float* __restrict__ rs, long rows, int HW, int C, ChanMap cm, float* __restrict__ partials) {
@@ -79,7 +79,7 @@ k_bn_bwd_reduce(const T* __restrict__ g, const T* __restrict__ y, const float* _
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 Vec<T>::load(g + (r + u * step) * C + c0, gv[u]);
-                Vec<T>::load(y + (r + u * step) * C + c0, yv[u]);
+                if constexpr (HAS_Y) Vec<T>::load(y + (r + u * step) * C + c0, yv[u]);
                 sv[u] = 1.f;
                 if constexpr (HAS_RS) sv[u] = rs[(r + u * step) / HW];
             }
@@ -90,13 +90,13 @@ k_bn_bwd_reduce(const T* __restrict__ g, const T* __restrict__ y, const float* _
                     float gg = gv[u][j];
                     if constexpr (HAS_RS) gg *= sv[u];
                     acc[j] += gg;
-                    acc[V + j] += gg * (yv[u][j] - mean[j]) * rstd[j];
+                    if constexpr (HAS_Y) acc[V + j] += gg * (yv[u][j] - mean[j]) * rstd[j];
                 }
         }
         for (; r < rows; r += step) {
             float gv[V], yv[V];
             Vec<T>::load(g + r * C + c0, gv);
-            Vec<T>::load(y + r * C + c0, yv);
+            if constexpr (HAS_Y) Vec<T>::load(y + r * C + c0, yv);
             float s = 1.f;
             if constexpr (HAS_RS) s = rs[r / HW];
 #pragma unroll
@@ -104,7 +104,7 @@ k_bn_bwd_reduce(const T* __restrict__ g, const T* __restrict__ y, const float* _
                 float gg = gv[j];
                 if constexpr (HAS_RS) gg *= s;
                 acc[j] += gg;
-                acc[V + j] += gg * (yv[j] - mean[j]) * rstd[j];
+                if constexpr (HAS_Y) acc[V + j] += gg * (yv[j] - mean[j]) * rstd[j];
             }
         }
     }
@@ -472,17 +472,16 @@ static int bn_bwd_reduce_t(const void* g, const void* y, const float* bnstate, c
     const int P = pick_parts(rows, cm.rpb, pcap);
     *nparts = P;
     dim3 grid(P, cm.nvc);
-    if (rs)
-        hipLaunchKernelGGL((k_bn_bwd_reduce<T, true>), grid, dim3(DFD_THREADS), 0, st, (const T*)g, (const T*)y, bnstate, rs,
-                           rows, HW, C, cm, partials);
-    else
-        hipLaunchKernelGGL((k_bn_bwd_reduce<T, false>), grid, dim3(DFD_THREADS), 0, st, (const T*)g, (const T*)y, bnstate, rs,
-                           rows, HW, C, cm, partials);
+#define LAUNCH_BBR(RS, HY) hipLaunchKernelGGL((k_bn_bwd_reduce<T, RS, HY>), grid, dim3(DFD_THREADS), 0, st, (const T*)g, (const T*)y, bnstate, rs, \
+                                             rows, HW, C, cm, partials)
+    if (rs) { if (y) LAUNCH_BBR(true, true); else LAUNCH_BBR(true, false); }
+    else { if (y) LAUNCH_BBR(false, true); else LAUNCH_BBR(false, false); }
+#undef LAUNCH_BBR
     return DFD_CHECK_LAUNCH();
 }
 extern "C" int dfd_bn_bwd_reduce(int dtype, const void* g, const void* y, const float* bnstate, const float* row_scale,
                                  int N, int HW, int C, float* partials, int pcap, int* nparts, dfd_stream stream) {
-    if (!shape_ok(dtype, N, HW, C) || !g || !y || !bnstate || !partials || !nparts || pcap < 1) return DFD_EINVAL;
+    if (!shape_ok(dtype, N, HW, C) || !g || !bnstate || !partials || !nparts || pcap < 1) return DFD_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     return dtype == DFD_BF16 ? bn_bwd_reduce_t<bf16>(g, y, bnstate, row_scale, N, HW, C, partials, pcap, nparts, st)
                              : bn_bwd_reduce_t<float>(g, y, bnstate, row_scale, N, HW, C, partials, pcap, nparts, st);

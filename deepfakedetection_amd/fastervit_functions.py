@@ -340,7 +340,7 @@ def mlp_sub_bwd(g, saved, P, ls, row_scale, need: dict, need_dx: bool):
     C, hid = P["fc2_w"].shape[0], P["fc1_w"].shape[0]
     dev = x.device
     gb = K.scale_rows(g, row_scale) if row_scale is not None else g
-    parts, n = K.bn_bwd_reduce(gb, y2, st2, None)
+    parts, n = K.bn_bwd_reduce(gb, None if (ls is None and not need["ls"]) else y2, st2, None)
     ones2, _ = ident(dev, C)
     outs = (None, _slot(P["fc2_b"], need["fc2_b"], (C,)), _slot(ls, need["ls"], (C,)), None)
     coef2, _, db2, dls, _ = K.bn_bwd_finalize_ex(parts, n, _rows(y2), ones2, P["fc2_b"], ls, st2, False, need["fc2_b"] or True, need["ls"],

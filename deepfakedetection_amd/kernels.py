@@ -343,13 +343,14 @@ def bn_act_apply(y: torch.Tensor, state: torch.Tensor, act: int, residual: torch
     return out
 
 
-def bn_bwd_reduce(g: torch.Tensor, y: torch.Tensor, state: torch.Tensor, row_scale: torch.Tensor | None = None):
-    _chk_nhwc(y)
-    N, H, W, C = y.shape
-    parts = partials_buf(y.device, C)
+def bn_bwd_reduce(g: torch.Tensor, y: torch.Tensor | None, state: torch.Tensor, row_scale: torch.Tensor | None = None):
+    """y None: only the sums of g (the second partial sum is written as zero)."""
+    _chk_nhwc(g if y is None else y)
+    N, H, W, C = g.shape if y is None else y.shape
+    parts = partials_buf(g.device, C)
     n = ctypes.c_int(0)
-    check(_L().dfd_bn_bwd_reduce(_dt(y), _p(g), _p(y), _p(state), _p(row_scale), N, H * W, C, _p(parts), MAX_PARTIALS,
-                                 ctypes.byref(n), _stream()), "dfd_bn_bwd_reduce", str(tuple(y.shape)))
+    check(_L().dfd_bn_bwd_reduce(_dt(g), _p(g), _p(y), _p(state), _p(row_scale), N, H * W, C, _p(parts), MAX_PARTIALS,
+                                 ctypes.byref(n), _stream()), "dfd_bn_bwd_reduce", str(tuple(g.shape)))
     return parts, n.value
 
 

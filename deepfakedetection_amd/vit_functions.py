@@ -72,7 +72,9 @@ def pwbn_bwd(g, x, y, st, w_kn, w_shape, w, b, gamma, beta, ls, act, training, n
     if row_scale is not None:
         g = K.scale_rows(g, row_scale)
     if act == ACT_NONE:
-        parts, n = K.bn_bwd_reduce(g, y, st, None)
+        # a Linear layer without layer scale needs only the bias gradient (sum of g): y is not read
+        plain = identity and not training and ls is None and not need_ls
+        parts, n = K.bn_bwd_reduce(g, None if plain else y, st, None)
         dz = g
     else:
         dz, parts, n = K.act_bn_bwd(g, y, None, None, st, act)

@@ -137,7 +137,8 @@ int dfd_bn_bwd_finalize_ex(const float* partials, int nparts, int C, double coun
 int dfd_bn_act_apply(int dtype, const void* y, const float* bnstate, int act,
                      const void* residual, const float* row_scale, void* out,
                      int N, int HW, int C, dfd_stream stream);
-/* partial sums of (g*rs, g*rs*xhat) per channel, xhat = (y-mean)*rstd            */
+/* partial sums of (g*rs, g*rs*xhat) per channel, xhat = (y-mean)*rstd; y == NULL: (g*rs, 0) — layers whose
+ * "statistic" is the identity (Linear + bias) need only the bias gradient and skip the second operand            */
 int dfd_bn_bwd_reduce(int dtype, const void* g, const void* y, const float* bnstate,
                       const float* row_scale, int N, int HW, int C,
                       float* partials, int pcap, int* nparts, dfd_stream stream);

@@ -300,6 +300,13 @@ def test_rowpass(case, rd):
     coef2, _, _ = K.bn_bwd_finalize(parts, n, N * H * W, dev(gamma), dev(st), True)
     wc2, _, _ = R.bn_bwd_coef(g.float() * rs[:, None, None, None], y.float(), gamma, st)
     close(coef2, wc2, 2e-3, "bn bwd coef rs")
+    # without the second operand (layers whose statistic is the identity): the same sums of g, zeros for the second sum
+    for scale in (None, dev(rs)):
+        p_full, n_full = K.bn_bwd_reduce(dev(g), dev(y), dev(st), scale)
+        full = p_full[:n_full * 2 * C].view(n_full, 2, C).clone()
+        p_g, n_g = K.bn_bwd_reduce(dev(g), None, dev(st), scale)
+        only = p_g[:n_g * 2 * C].view(n_g, 2, C)
+        assert n_g == n_full and torch.equal(only[:, 0], full[:, 0]) and not only[:, 1].any()
     # act_bn_bwd, three modes
     gate = torch.rand((N, C), generator=torch.Generator().manual_seed(37))
     dpool = torch.randn((N, C), generator=torch.Generator().manual_seed(38))
