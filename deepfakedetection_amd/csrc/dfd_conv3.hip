@@ -77,8 +77,7 @@ k_conv3_direct(const unsigned short* __restrict__ x, const float* __restrict__ i
                         Vec<bf16>::unpack(q, f);
                         load_f32<8>(in_bn + v * 8, sc);
                         load_f32<8>(in_bn + C + v * 8, sh);
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) f[j] = act_fwd<ACT>(fmaf(sc[j], f[j], sh[j]));
+                        bn_act_array<ACT, 8>(f, sc, sh);
                         q = Vec<bf16>::pack(f);
                     }
                 }
@@ -250,8 +249,7 @@ k_conv3_wgrad(const unsigned short* __restrict__ dy, const unsigned short* __res
                     Vec<bf16>::unpack(r, f);
                     load_f32<8>(in_bn + ci0 + v * 8, sc);
                     load_f32<8>(in_bn + C + ci0 + v * 8, sh);
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) f[j] = act_fwd<ACT>(fmaf(sc[j], f[j], sh[j]));
+                    bn_act_array<ACT, 8>(f, sc, sh);
                     r = Vec<bf16>::pack(f);
                 }
             }

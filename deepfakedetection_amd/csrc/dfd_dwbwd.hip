@@ -160,7 +160,7 @@ k_dw_bwd_data_q(const T* __restrict__ dz, const T* __restrict__ yraw, const floa
                                 const f2 sg = (f2){__builtin_amdgcn_rcpf(d1.x), __builtin_amdgcn_rcpf(d1.y)};
                                 gr = sg * ((f2){1.f, 1.f} + z * ((f2){1.f, 1.f} - sg));
                             } else {
-                                gr = (f2){act_grad<ACT>(z.x), act_grad<ACT>(z.y)};
+                                gr = act_grad2<ACT>(z);
                             }
                             const f2 d = round2<T>(acc[o][j] * gr);
                             acc[o][j] = d;

@@ -134,7 +134,7 @@ k_dw_fwd_q(const T* __restrict__ x, const float* __restrict__ bnstate, const flo
                         f2 r = round2<T>(acc[o][j]);
                         if constexpr (EACT >= 0) {
                             const f2 z = __builtin_elementwise_fma(esc[j], r, esh[j]);
-                            r = round2<T>((f2){act_fwd<EACT>(z.x), act_fwd<EACT>(z.y)});
+                            r = round2<T>(act_fwd2<EACT>(z));
                             pool[j] += r;
                         }
                         acc[o][j] = r;

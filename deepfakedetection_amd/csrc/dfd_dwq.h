@@ -134,7 +134,7 @@ __device__ __forceinline__ void stage_q(uint4* __restrict__ tile, const T* __res
                             const f2 d = e + (f2){1.f, 1.f};
                             v[j] = z * (f2){__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
                         } else {
-                            v[j] = (f2){act_fwd<ACT>(z.x), act_fwd<ACT>(z.y)};
+                            v[j] = act_fwd2<ACT>(z);
                         }
                     }
                     q = pack2(v);

@@ -74,8 +74,7 @@ __device__ __forceinline__ uint4 apply_pro(uint4 q, uint4 q2, const float* __res
 #pragma unroll
             for (int j = 0; j < E; ++j) v[j] = fmaf(c0[j], v[j], fmaf(c1[j], v2[j], c2[j]));
         } else {
-#pragma unroll
-            for (int j = 0; j < E; ++j) v[j] = act_fwd<ACT>(fmaf(c0[j], v[j], c1[j]));
+            bn_act_array<ACT, E>(v, c0, c1);
             if constexpr (PRO == DFD_PRO_BN_ACT_GATE) {
                 float gt[E];
                 load_f32<E>(gate_row + k, gt);
@@ -104,8 +103,7 @@ __device__ __forceinline__ uint4 apply_pro_c(uint4 q, uint4 q2, const float (&c0
 #pragma unroll
             for (int j = 0; j < E; ++j) v[j] = fmaf(c0[j], v[j], fmaf(c1[j], v2[j], c2[j]));
         } else {
-#pragma unroll
-            for (int j = 0; j < E; ++j) v[j] = act_fwd<ACT>(fmaf(c0[j], v[j], c1[j]));
+            bn_act_array<ACT, E>(v, c0, c1);
             if constexpr (PRO == DFD_PRO_BN_ACT_GATE) {
                 float gt[E];
                 load_f32<E>(gate_k, gt);
@@ -132,8 +130,7 @@ __device__ __forceinline__ uint4 apply_pro_v(uint4 q, uint4 q2, const float (&c0
 #pragma unroll
             for (int j = 0; j < E; ++j) v[j] = fmaf(c0[j], v[j], fmaf(c1[j], v2[j], c2[j]));
         } else {
-#pragma unroll
-            for (int j = 0; j < E; ++j) v[j] = act_fwd<ACT>(fmaf(c0[j], v[j], c1[j]));
+            bn_act_array<ACT, E>(v, c0, c1);
             if constexpr (PRO == DFD_PRO_BN_ACT_GATE) {
 #pragma unroll
                 for (int j = 0; j < E; ++j) v[j] = round_to<T>(v[j]) * gt[j];

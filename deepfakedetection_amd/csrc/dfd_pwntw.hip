@@ -157,8 +157,7 @@ k_pw_ntw(const T* __restrict__ a, ProArgs pa, const T* __restrict__ w, T* __rest
 #pragma unroll
                         for (int x = 0; x < E; ++x) v[x] = fmaf(c0[x], v[x], fmaf(c1[x], v2[x], c2[x]));
                     } else {
-#pragma unroll
-                        for (int x = 0; x < E; ++x) v[x] = act_fwd<ACT>(fmaf(c0[x], v[x], c1[x]));
+                        bn_act_array<ACT, E>(v, c0, c1);
                         if constexpr (PRO == DFD_PRO_BN_ACT_GATE) {
                             // the activated tensor is rounded to T before the gate multiply, as an
                             // unfused pipeline would store it

@@ -129,13 +129,13 @@ k_pw_tnw(const bf16* __restrict__ a, ProArgs pa, int Na, const bf16* __restrict_
                 for (int j = 0; j < 8; ++j) v[j] = fmaf(c0[j], v[j], fmaf(c1[j], v2[j], c2[j]));
             } else if constexpr (MODE == DFD_PRO_BN_ACT) {
                 // BN + activation without a squeeze-excite gate (EfficientFormerV2 ConvMlp: GELU(BN(mid conv)))
-#pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = act_fwd<ACT>(fmaf(c0[j], v[j], c1[j]));
+                bn_act_array<ACT, 8>(v, c0, c1);
             } else {
                 float gt[8];
                 load_f32<8>(gc + (pro_image(pr, m) - gimg) * N + ch * 8, gt);
+                bn_act_array<ACT, 8>(v, c0, c1);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = round_to<bf16>(act_fwd<ACT>(fmaf(c0[j], v[j], c1[j]))) * gt[j];
+                for (int j = 0; j < 8; ++j) v[j] = round_to<bf16>(v[j]) * gt[j];
             }
             return f_to_q(v);
         }

@@ -27,9 +27,10 @@ k_bn_act_apply(const T* __restrict__ y, const float* __restrict__ bnstate, const
         if constexpr (HAS_RS) r = rs[i / vec_per_img];
         float q[V];
         if constexpr (HAS_RES) Vec<T>::load(res + i * V, q);
+        bn_act_array<ACT, V>(v, sc, sh);
 #pragma unroll
         for (int j = 0; j < V; ++j) {
-            float z = act_fwd<ACT>(fmaf(sc[j], v[j], sh[j]));
+            float z = v[j];
             if constexpr (HAS_RS) z *= r;
             if constexpr (HAS_RES) z += q[j];
             v[j] = z;
@@ -150,14 +151,20 @@ k_act_bn_bwd(const T* __restrict__ D, const T* __restrict__ y, const float* __re
                 load_f32<V>(dpool + n * C + c0, dp);
                 if constexpr (MODE == 1) load_f32<V>(gate + n * C + c0, gt);
             }
+            float agr[V];                                      // act'(scale * y + shift), evaluated in pairs
+#pragma unroll
+            for (int j = 0; j < V; j += 2) {
+                const dfd_f2 z2 = __builtin_elementwise_fma((dfd_f2){sc[j], sc[j + 1]}, (dfd_f2){yv[j], yv[j + 1]}, (dfd_f2){sh[j], sh[j + 1]});
+                const dfd_f2 g2 = act_grad2<ACT>(z2);
+                agr[j] = g2.x; agr[j + 1] = g2.y;
+            }
 #pragma unroll
             for (int j = 0; j < V; ++j) {
                 float da;
                 if constexpr (MODE == 0) da = dv[j];
                 else if constexpr (MODE == 1) da = fmaf(dv[j], gt[j], dp[j] * invHW);
                 else da = dp[j] * invHW;
-                const float z = fmaf(sc[j], yv[j], sh[j]);
-                const float d = round_to<T>(da * act_grad<ACT>(z));
+                const float d = round_to<T>(da * agr[j]);
                 dv[j] = d;
                 acc[j] += d;
                 acc[V + j] += d * (yv[j] - mean[j]) * rstd[j];

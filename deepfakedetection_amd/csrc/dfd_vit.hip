@@ -1073,8 +1073,7 @@ k_im2col(const T* __restrict__ x, const float* __restrict__ bnstate, T* __restri
                 float sc[V], sh[V];
                 load_f32<V>(bnstate + cv * V, sc);
                 load_f32<V>(bnstate + s.C + cv * V, sh);
-#pragma unroll
-                for (int j = 0; j < V; ++j) v[j] = act_fwd<ACT>(fmaf(sc[j], v[j], sh[j]));
+                bn_act_array<ACT, V>(v, sc, sh);
             }
         }
         Vec<T>::store(col + i * V, v);

@@ -633,3 +633,24 @@ def test_fused_window_attention_forward_and_backward(n, T, H, with_bias):
     # bitwise reproducible (fixed-order bias-gradient sum)
     dqkv2, dbias2 = K.wattn_bwd(qd, dO.cuda().view(n, T, 1, C), L, bd, H, scale, with_bias)
     assert torch.equal(dqkv, dqkv2) and (not with_bias or torch.equal(dbias, dbias2))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("rd", DT)
+def test_packed_pair_gelu_is_the_scalar_gelu_bit_for_bit(rd):
+    """The hot kernels evaluate GELU / GELU' on float2 pairs (v_pk_*_f32: dfd_common.h act_fwd2 / act_grad2); the row kernels
+    dfd_bn_add_act / dfd_bn_add_act_bwd still use the scalar forms.  Same operations in the same order -> identical bits, over
+    the whole range where the erfc polynomial, the exp underflow and the sign select matter."""
+    K = _k()
+    N, H, W, C = 4, 9, 7, 64
+    y = (gen((N, H, W, C), 71, rd) * 3.0)
+    y.view(-1)[:8] = torch.tensor([0.0, -0.0, 1e-8, -1e-8, 12.0, -12.0, 40.0, -40.0]).to(rd)
+    g = gen((N, H, W, C), 72, rd)
+    st = rand_state(C, 73)
+    y, g, st = y.cuda(), g.cuda(), st.cuda()
+    packed = K.bn_act_apply(y, st, R.ACT_GELU)
+    scalar = K.bn_add_act(y, st, None, R.ACT_GELU)
+    assert torch.equal(packed, scalar), float((packed.float() - scalar.float()).abs().max())
+    d_packed, _, _ = K.act_bn_bwd(g, y, None, None, st, R.ACT_GELU)
+    d_scalar, _, _ = K.bn_add_act_bwd(g, y, st, None, R.ACT_GELU, stats=False)
+    assert torch.equal(d_packed, d_scalar), float((d_packed.float() - d_scalar.float()).abs().max())
