@@ -25,19 +25,17 @@
 #include "dfd_common.h"
 #include "dfd_pw.h"
 
-#define C3_TH 8
 #define C3_TW 16
-#define C3_IH (C3_TH + 2)
 #define C3_IW (C3_TW + 2)
 #define C3_OP 72                 // elements per pixel of the staged output tile (64 channels + 8)
 
-template <int CK, int ACT, bool PRO, bool STATS>        // CK = C / 32
+template <int CK, int ACT, bool PRO, bool STATS, int TH>        // CK = C / 32; TH = tile rows (8, or 7 where 7 divides H and 8 does not)
 __global__ void __launch_bounds__(DFD_THREADS, 2)
 k_conv3_direct(const unsigned short* __restrict__ x, const float* __restrict__ in_bn, const unsigned short* __restrict__ w,
                unsigned short* __restrict__ y, float* __restrict__ partials, int N, int H, int W, int Cout, int tiles_y, int tiles_x) {
     constexpr int C = 32 * CK, CP = C + 16;             // pixel pitch in elements: C / 8 + 2 sixteen-byte units, = 2 mod 4 (see below)
-    extern __shared__ __attribute__((aligned(16))) unsigned short tile[];         // [C3_IH][C3_IW][CP], then the output tile
-    unsigned short* otile = tile + C3_IH * C3_IW * CP;                            // [C3_TH * C3_TW][C3_OP]
+    extern __shared__ __attribute__((aligned(16))) unsigned short tile[];         // [(TH + 2)][C3_IW][CP], then the output tile
+    unsigned short* otile = tile + (TH + 2) * C3_IW * CP;                            // [TH * C3_TW][C3_OP]
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, c16 = lane & 15, g = lane >> 4;
     const int co0 = blockIdx.y * 64 + wave * 16;        // this wave's 16 output channels
     // resident weights: A operand fragment (row = output channel co0 + c16, k = input channels 32 ks + 8 g ..) per tap
@@ -54,13 +52,13 @@ k_conv3_direct(const unsigned short* __restrict__ x, const float* __restrict__ i
     for (long work = blockIdx.x; work < nwork; work += gridDim.x) {
         const int n = (int)(work / tiles), tr = (int)(work - (long)n * tiles);
         const int ty = tr / tiles_x, tx = tr - ty * tiles_x;
-        const int h0 = ty * C3_TH, w0 = tx * C3_TW;
+        const int h0 = ty * TH, w0 = tx * C3_TW;
         __syncthreads();                                 // previous tile's fragment reads are done
         // ---- stage the input tile with halo; the producer's BN + activation once per element; zeros outside the image
         // the tile's loads are issued in one batch (64 channels: 6 vectors per lane) before their first use, or in three of 3-4
         // (96 / 128 channels: beside 108-144 registers of resident weights a batch of 6 spilled and measured 14-27 % slower)
         {
-            constexpr int NV = (C3_IH * C3_IW * VPP + DFD_THREADS - 1) / DFD_THREADS;
+            constexpr int NV = ((TH + 2) * C3_IW * VPP + DFD_THREADS - 1) / DFD_THREADS;
             constexpr int NBATCH = CK >= 3 ? 3 : 1, NVB = (NV + NBATCH - 1) / NBATCH;
 #pragma unroll 1
             for (int bt = 0; bt < NBATCH; ++bt) {       // a real loop: unrolled, the compiler hoists every batch's loads to the top
@@ -72,14 +70,14 @@ k_conv3_direct(const unsigned short* __restrict__ x, const float* __restrict__ i
                     const int pix = i / VPP, v = i - pix * VPP;
                     const int iy = pix / C3_IW, ix = pix - iy * C3_IW;
                     const int gy = h0 - 1 + iy, gx = w0 - 1 + ix;
-                    ok[u] = i < C3_IH * C3_IW * VPP && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+                    ok[u] = i < (TH + 2) * C3_IW * VPP && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
                     r[u] = make_uint4(0, 0, 0, 0);
                     if (ok[u]) r[u] = *reinterpret_cast<const uint4*>(x + (((long)n * H + gy) * W + gx) * C + v * 8);
                 }
 #pragma unroll
                 for (int u = 0; u < NVB; ++u) {
                     const int i = threadIdx.x + (bt * NVB + u) * DFD_THREADS;
-                    if (i >= C3_IH * C3_IW * VPP) continue;
+                    if (i >= (TH + 2) * C3_IW * VPP) continue;
                     const int pix = i / VPP, v = i - pix * VPP;
                     uint4 q = r[u];
                     if constexpr (PRO) {
@@ -98,28 +96,28 @@ k_conv3_direct(const unsigned short* __restrict__ x, const float* __restrict__ i
         }
         __syncthreads();
         // ---- 8 rows of 16 pixels x this wave's 16 channels
-        f32x4_t acc[C3_TH];
+        f32x4_t acc[TH];
 #pragma unroll
-        for (int r = 0; r < C3_TH; ++r) acc[r] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        for (int r = 0; r < TH; ++r) acc[r] = f32x4_t{0.f, 0.f, 0.f, 0.f};
         // blocks of (tap, k-step): the next block's eight pixel fragments (B operand: column = pixel c16 of a tile row, k =
         // channels 32 ks + 8 g ..) are read while the current block's MFMAs issue; the scheduling barrier keeps the compiler from
         // hoisting every read of the tile to the top (that spills the resident weights)
         constexpr int NB = 9 * CK;
-        bf16x8_t pf[2][C3_TH];
+        bf16x8_t pf[2][TH];
         const unsigned short* lane_base = tile + c16 * CP + 8 * g;
 #pragma unroll
-        for (int r = 0; r < C3_TH; ++r) pf[0][r] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(lane_base + r * C3_IW * CP));
+        for (int r = 0; r < TH; ++r) pf[0][r] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(lane_base + r * C3_IW * CP));
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
             if (b + 1 < NB) {
                 const int t = (b + 1) / CK, ks = (b + 1) - t * CK, kh = t / 3, kw = t - 3 * kh;
                 const unsigned short* base = lane_base + (kh * C3_IW + kw) * CP + 32 * ks;
 #pragma unroll
-                for (int r = 0; r < C3_TH; ++r) pf[(b + 1) & 1][r] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(base + r * C3_IW * CP));
+                for (int r = 0; r < TH; ++r) pf[(b + 1) & 1][r] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(base + r * C3_IW * CP));
             }
             const int t = b / CK, ks = b - t * CK;
 #pragma unroll
-            for (int r = 0; r < C3_TH; ++r) acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[t][ks], pf[b & 1][r], acc[r], 0, 0, 0);
+            for (int r = 0; r < TH; ++r) acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[t][ks], pf[b & 1][r], acc[r], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
         // ---- store: lane holds output channels co0 + 4 g .. + 3 of pixel (h0 + r, w0 + c16).  The four waves' 32-byte quarters
@@ -127,7 +125,7 @@ k_conv3_direct(const unsigned short* __restrict__ x, const float* __restrict__ i
         // accumulators wrote quarter lines at four different times: measured slower, here and in the GEMM kernel)
         const int ox = w0 + c16;
 #pragma unroll
-        for (int r = 0; r < C3_TH; ++r) {
+        for (int r = 0; r < TH; ++r) {
             const unsigned lo = pack_bf2(acc[r][0], acc[r][1]), hi = pack_bf2(acc[r][2], acc[r][3]);
             *reinterpret_cast<uint2*>(otile + (r * C3_TW + c16) * C3_OP + wave * 16 + 4 * g) = make_uint2(lo, hi);
             if constexpr (STATS) {
@@ -141,10 +139,10 @@ k_conv3_direct(const unsigned short* __restrict__ x, const float* __restrict__ i
         }
         __syncthreads();
 #pragma unroll
-        for (int u = 0; u < C3_TH * C3_TW * 8 / DFD_THREADS; ++u) {
+        for (int u = 0; u < (TH * C3_TW * 8 + DFD_THREADS - 1) / DFD_THREADS; ++u) {
             const int idx = threadIdx.x + u * DFD_THREADS, pix = idx >> 3, ch = idx & 7;
             const int oy = h0 + (pix >> 4), oxx = w0 + (pix & 15);
-            if (oy < H && oxx < W)
+            if (pix < TH * C3_TW && oy < H && oxx < W)
                 *reinterpret_cast<uint4*>(y + (((long)n * H + oy) * W + oxx) * Cout + blockIdx.y * 64 + ch * 8) =
                     *reinterpret_cast<const uint4*>(otile + pix * C3_OP + ch * 8);
         }
@@ -168,7 +166,8 @@ int dfd_conv3_direct(const void* x, const dfd_dwconv_shape* s, const float* in_b
                      void* y, float* partials, int pcap, int* nparts, hipStream_t st) {
     if (s->k != 3 || s->stride != 1 || s->pad_top != 1 || s->pad_left != 1 || s->Ho != s->H || s->Wo != s->W) return DFD_EUNSUPPORTED;
     if (Cout % 64 || !(s->C == 64 || s->C == 96 || s->C == 128)) return DFD_EUNSUPPORTED;
-    const int tiles_y = (s->H + C3_TH - 1) / C3_TH, tiles_x = (s->W + C3_TW - 1) / C3_TW;
+    const int th = (s->H % 8 != 0 && s->H % 7 == 0) ? 7 : 8;      // 28 x 28 (and 14, 7): 7-row tiles cover the image exactly
+    const int tiles_y = (s->H + th - 1) / th, tiles_x = (s->W + C3_TW - 1) / C3_TW;
     const long nwork = (long)s->N * tiles_y * tiles_x;
     const bool stats = partials != nullptr;
     long gx = 512;                                       // two workgroups per CU, persistent
@@ -176,10 +175,14 @@ int dfd_conv3_direct(const void* x, const dfd_dwconv_shape* s, const float* in_b
     if (gx > nwork) gx = nwork;
     if (stats) *nparts = (int)gx;
     const dim3 grid((unsigned)gx, Cout / 64);
-    const size_t lds = (size_t)C3_IH * C3_IW * (s->C + 16) * 2 + (size_t)C3_TH * C3_TW * C3_OP * 2;
+    const size_t lds = (size_t)(th + 2) * C3_IW * (s->C + 16) * 2 + (size_t)th * C3_TW * C3_OP * 2;
 #define C3_LAUNCH(CK, PRO, STATS)                                                                                          \
-    hipLaunchKernelGGL((k_conv3_direct<CK, ACT, PRO, STATS>), grid, dim3(DFD_THREADS), lds, st, (const unsigned short*)x,  \
-                       in_bnstate, (const unsigned short*)w_nk, (unsigned short*)y, partials, s->N, s->H, s->W, Cout, tiles_y, tiles_x)
+    do {                                                                                                                   \
+        if (th == 7) hipLaunchKernelGGL((k_conv3_direct<CK, ACT, PRO, STATS, 7>), grid, dim3(DFD_THREADS), lds, st, (const unsigned short*)x, \
+                       in_bnstate, (const unsigned short*)w_nk, (unsigned short*)y, partials, s->N, s->H, s->W, Cout, tiles_y, tiles_x); \
+        else hipLaunchKernelGGL((k_conv3_direct<CK, ACT, PRO, STATS, 8>), grid, dim3(DFD_THREADS), lds, st, (const unsigned short*)x, \
+                       in_bnstate, (const unsigned short*)w_nk, (unsigned short*)y, partials, s->N, s->H, s->W, Cout, tiles_y, tiles_x); \
+    } while (0)
 #define C3_CK(CK)                                                                                                          \
     do {                                                                                                                   \
         if (!in_bnstate) {                                                                                                 \
