@@ -46,10 +46,13 @@ for C, H, k, s, count in shapes:
     tf = timeit(lambda: K.dwconv_fwd(x, st, act, w, k, s, p, p, Ho, Ho, stats=True))
     td = timeit(lambda: K.dwconv_bwd_data(dz, y, cf, w, x, st, act, tuple(x.shape), k, s, p, p))
     tw = timeit(lambda: K.dwconv_bwd_weight(dz, y, cf, x, st, act, k, s, p, p))
+    tf0 = timeit(lambda: K.dwconv_fwd(x, None, 0, w, k, s, p, p, Ho, Ho, stats=True))
+    tw0 = timeit(lambda: K.dwconv_bwd_weight(dz, y, cf, x, None, 0, k, s, p, p))
+    ta = timeit(lambda: K.bn_act_apply(x, st, act))
     bi, bo = x.numel() * 2, dz.numel() * 2
     bf, bd, bw = bi + bo, 2 * bo + 2 * bi, 2 * bo + bi
     print(f"C{C:5d} {H:3d}x{H:<3d} k{k}s{s} x{count}  fwd {tf:6.1f} us {bf / tf / 1e6:5.2f} TB/s | data {td:6.1f} us {bd / td / 1e6:5.2f} TB/s | "
-          f"weight {tw:6.1f} us {bw / tw / 1e6:5.2f} TB/s", flush=True)
+          f"weight {tw:6.1f} us {bw / tw / 1e6:5.2f} TB/s || no prologue: fwd {tf0:6.1f} weight {tw0:6.1f}  apply pass {ta:6.1f}", flush=True)
     for i, t in enumerate((tf, td, tw)):
         tot[i] += t * count
     del x, dz, y
