@@ -382,12 +382,13 @@ class ConvMlpFunction(torch.autograd.Function):
         y2, parts, n = K.dwconv_fwd(a1, None, ACT_NONE, wd, 3, 1, 1, 1, H, W, stats=tr)
         st2 = _bn_state(parts, n, N * H * W, cfg.bnd, gd, bed, tr, cfg.counters, conv_bias=bd)
         w2_nk, w2_kn = _prep(w2, x.dtype, cfg.derived, need_bwd)
-        y3, parts, n = K.pwconv(y2, K.pro_bn_act(st2, ACT_GELU), w2_nk, None, stats=tr)
+        a2 = K.bn_act_apply(y2, st2, ACT_GELU)               # likewise for fc2 and its weight gradient (S1: 18.6 -> 18.35 ms)
+        y3, parts, n = K.pwconv(a2, None, w2_nk, None, stats=tr)
         st3 = _bn_state(parts, n, N * H * W, cfg.bn2, g2, be2, tr, cfg.counters, conv_bias=b2, ls=ls)
         out = K.bn_act_apply(y3, st3, ACT_NONE, x, row_scale)
         ctx.cfg = cfg
         ctx.has_rs = row_scale is not None
-        ctx.save_for_backward(x, y1, a1, y2, y3, st1, st2, st3, w1_kn, w2_kn, w1, b1, g1, be1, wd, bd, gd, bed, w2, b2, g2, be2, ls,
+        ctx.save_for_backward(x, y1, a1, y2, a2, y3, st1, st2, st3, w1_kn, w2_kn, w1, b1, g1, be1, wd, bd, gd, bed, w2, b2, g2, be2, ls,
                               row_scale)
         return out
 
@@ -399,7 +400,7 @@ class ConvMlpFunction(torch.autograd.Function):
     @staticmethod
     def _backward(ctx, g):
         cfg: ConvMlpCtx = ctx.cfg
-        (x, y1, a1, y2, y3, st1, st2, st3, w1_kn, w2_kn, w1, b1, g1, be1, wd, bd, gd, bed, w2, b2, g2, be2, ls,
+        (x, y1, a1, y2, a2, y3, st1, st2, st3, w1_kn, w2_kn, w1, b1, g1, be1, wd, bd, gd, bed, w2, b2, g2, be2, ls,
          row_scale) = ctx.saved_tensors
         need = ctx.needs_input_grad
         tr = cfg.training
@@ -416,7 +417,7 @@ class ConvMlpFunction(torch.autograd.Function):
         D, _, _ = K.pwconv(gb, pro3, w2_kn, None, stats=False)
         dw2 = None
         if need[9]:
-            dw2 = K.pwconv_wgrad(gb, pro3, y2, K.pro_bn_act(st2, ACT_GELU), _slot(w2, True, (C, Cm))).view(C, Cm, 1, 1)
+            dw2 = K.pwconv_wgrad(gb, pro3, a2, None, _slot(w2, True, (C, Cm))).view(C, Cm, 1, 1)
         # ---- GELU' and the depthwise BN backward
         dz2, parts, n = K.act_bn_bwd(D, y2, None, None, st2, ACT_GELU)
         nbd = need[7] or need[8]
