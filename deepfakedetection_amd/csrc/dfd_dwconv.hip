@@ -100,11 +100,11 @@ extern "C" int dfd_sum_batch_end(void) {
 }
 
 // `partials` must have room for P + ceil(P / SUM_GROUP) rows of L floats.
-// Inside a batch only SMALL slabs wait for the batch's end (they are launch-bound: one pair of launches for all of them); a slab
+// Inside a batch only slabs up to 24 MB wait for the batch's end (they are launch-bound: one pair of launches for all of them); a slab
 // of tens of megabytes (FasterViT's level-2/3 linears: ~30 MB each) is summed at once, while it still sits in the last-level
 // cache — deferred, four of them were read back from HBM (1.15 ms per FasterViT-0 step, 0.6 ms of it saved here).
 #ifndef SUM_DEFER_MAX_BYTES
-#define SUM_DEFER_MAX_BYTES (8l << 20)
+#define SUM_DEFER_MAX_BYTES (24l << 20)
 #endif
 int dfd_launch_sum_partials(float* partials, int P, long L, float* out, int accumulate, hipStream_t st, bool deferrable) {
     if (tl_batch.on && deferrable && (long)P * L * 4 <= SUM_DEFER_MAX_BYTES) {
