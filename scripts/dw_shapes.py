@@ -49,10 +49,13 @@ for C, H, k, s, count in shapes:
     tf0 = timeit(lambda: K.dwconv_fwd(x, None, 0, w, k, s, p, p, Ho, Ho, stats=True))
     tw0 = timeit(lambda: K.dwconv_bwd_weight(dz, y, cf, x, None, 0, k, s, p, p))
     ta = timeit(lambda: K.bn_act_apply(x, st, act))
+    td0 = timeit(lambda: K.dwconv_bwd_data(dz, None, None, w, x, st, act, tuple(x.shape), k, s, p, p))
+    tw1 = timeit(lambda: K.dwconv_bwd_weight(dz, None, None, x, None, 0, k, s, p, p))
+    tm = timeit(lambda: K.affine2_apply(dz, y, cf))
     bi, bo = x.numel() * 2, dz.numel() * 2
     bf, bd, bw = bi + bo, 2 * bo + 2 * bi, 2 * bo + bi
     print(f"C{C:5d} {H:3d}x{H:<3d} k{k}s{s} x{count}  fwd {tf:6.1f} us {bf / tf / 1e6:5.2f} TB/s | data {td:6.1f} us {bd / td / 1e6:5.2f} TB/s | "
-          f"weight {tw:6.1f} us {bw / tw / 1e6:5.2f} TB/s || no prologue: fwd {tf0:6.1f} weight {tw0:6.1f}  apply pass {ta:6.1f}", flush=True)
+          f"weight {tw:6.1f} us {bw / tw / 1e6:5.2f} TB/s || no prologue: fwd {tf0:6.1f} weight {tw0:6.1f}  apply pass {ta:6.1f} || no BN map: data {td0:6.1f} weight(no pro, no map) {tw1:6.1f} map pass {tm:6.1f}", flush=True)
     for i, t in enumerate((tf, td, tw)):
         tot[i] += t * count
     del x, dz, y
