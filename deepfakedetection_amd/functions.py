@@ -279,13 +279,15 @@ class MBConvFunction(torch.autograd.Function):
         Cout, R = y3.shape[3], w1.shape[0]
         coef3, dg_proj, db_proj = K.bn_bwd_finalize(parts, n, N * Ho * Wo, g_proj, st3, tr, need[12] or need[13],
                                                     _dest(ctx, 12, (Cout,)), _dest(ctx, 13, (Cout,)))
-        pro_dy3 = K.pro_affine2(y3, coef3)
-        D, _, _ = K.pwconv(gb, pro_dy3, wproj_kn, None, stats=False)               # d(act*gate) [.., Cmid]
+        # the BN-backward-mapped gradient [rows][Cout] is materialised once for its two GEMMs: as a prologue it is re-evaluated
+        # (and y3 re-read) per 128-column tile of the Cmid-wide data gradient (B0: 13.99 -> 13.90 ms per step; same bits)
+        gm3 = K.affine2_apply(gb, y3, coef3)
+        D, _, _ = K.pwconv(gm3, None, wproj_kn, None, stats=False)                   # d(act*gate) [.., Cmid]
         dw_proj = None
         if need[11]:
             pro_q = K.pro_bn_act_gate(st2, ACT_SILU, gate, Ho * Wo)
             with K.side_stream(N * Ho * Wo):
-                dw_proj = K.pwconv_wgrad(gb, pro_dy3, y2, pro_q, _dest(ctx, 11, (Cout, Cmid))).view(Cout, Cmid, 1, 1)
+                dw_proj = K.pwconv_wgrad(gm3, None, y2, pro_q, _dest(ctx, 11, (Cout, Cmid))).view(Cout, Cmid, 1, 1)
         # ---- squeeze-excite backward
         want_se = need[7] or need[8] or need[9] or need[10]
         se_outs = (_dest(ctx, 7, (R, Cmid)), _dest(ctx, 8, (R,)), _dest(ctx, 9, (Cmid, R)), _dest(ctx, 10, (Cmid,)))
