@@ -17,12 +17,19 @@
 #include "dfd_dwq.h"
 #include <climits>
 
+#ifndef DW_FWD_PAIRS
+#define DW_FWD_PAIRS 0      // 1: 3x3 stride-1 bf16 forward with two outputs per lane, five workgroups per CU — measured 3-12 % SLOWER
+#endif                      //    on every EfficientNet-B0 / EfficientFormerV2 layer, so off; -DDW_FWD_PAIRS=1 builds it
+
 // EACT >= 0 (eval / inference, where this layer's own BatchNorm is an affine map known up front): the epilogue stores
 // act(BN(y)) instead of the raw output and leaves per-(tile, image) channel sums of it for the squeeze-excite pooling
 // (pool_parts [tiles][N][C], the layout dfd_se_fwd's per-image kernel adds up) — the consumer needs no prologue and
 // the pooling pass disappears.
-template <typename T, int K, int S, int ACT, bool PRO, bool STATS, int EACT = -1>
-__global__ void __launch_bounds__(DFD_THREADS, 4)
+// OPL = outputs per lane: 4 (a quad) or 2 (half a quad: the same tiles and staging, each lane item is a PAIR of adjacent
+// outputs — 16 accumulator registers instead of 32 and K + S instead of K + 3 S staged columns per kernel row, so that five
+// workgroups fit a CU (first option; per-layer A/B in DESIGN 9).
+template <typename T, int K, int S, int ACT, bool PRO, bool STATS, int EACT = -1, int OPL = 4>
+__global__ void __launch_bounds__(DFD_THREADS, OPL == 2 ? 5 : 4)
 k_dw_fwd_q(const T* __restrict__ x, const float* __restrict__ bnstate, const float* __restrict__ w, T* __restrict__ y,
            DwQGeom g, float* __restrict__ partials, int tile_bytes, const float* __restrict__ ebn = nullptr,
            float* __restrict__ pool_parts = nullptr) {
@@ -92,31 +99,33 @@ k_dw_fwd_q(const T* __restrict__ x, const float* __restrict__ bnstate, const flo
         }
         __syncthreads();
         if (EACT < 0 && !cvalid) continue;
+        constexpr int HPQ = 4 / OPL;                     // lane items per quad
 #pragma unroll 1
-        for (int q = cvalid ? lane : g.NQ; q < g.NQ; q += PL) {
+        for (int it = cvalid ? lane : HPQ * g.NQ; it < HPQ * g.NQ; it += PL) {
+            const int q = OPL == 4 ? it : (it >> 1), sub = OPL == 4 ? 0 : (it & 1) * OPL;
             const int qy = (int)(((unsigned)q * g.qw_magic) >> 20), qx = q - qy * g.QW;
-            const int oy = oy0 + qy, ox = ox0 + 4 * qx;
+            const int oy = oy0 + qy, ox = ox0 + 4 * qx + sub;
             if (oy >= g.Ho || ox >= g.Wo) continue;
-            f2 acc[4][N2];
+            f2 acc[OPL][N2];
 #pragma unroll
-            for (int o = 0; o < 4; ++o)
+            for (int o = 0; o < OPL; ++o)
 #pragma unroll
                 for (int j = 0; j < N2; ++j) acc[o][j] = (f2){0.f, 0.f};
 #pragma unroll 1
             for (int kh = 0; kh < K; ++kh) {
-                const uint4* row = tile + ((((qy * S + kh) * g.IW) + qx * 4 * S) << g.cvb_log2) + vl;
+                const uint4* row = tile + ((((qy * S + kh) * g.IW) + (qx * 4 + sub) * S) << g.cvb_log2) + vl;
                 f2 wv[K][N2];
 #pragma unroll
                 for (int kw = 0; kw < K; ++kw) lds_row<N2>(wl + ((kh * K + kw) * cvb + vl) * V, wv[kw]);
                 // walk the INPUT columns of the quad's window: one vector is unpacked at a time and
                 // feeds every (output, tap) pair it belongs to (keeps the live set at acc + weights)
-                constexpr int NCOL = 3 * S + K;
+                constexpr int NCOL = (OPL - 1) * S + K;
 #pragma unroll
                 for (int c = 0; c < NCOL; ++c) {
                     f2 xc[N2];
                     unpack2(row[c << g.cvb_log2], xc);
 #pragma unroll
-                    for (int o = 0; o < 4; ++o) {
+                    for (int o = 0; o < OPL; ++o) {
                         const int kw = c - S * o;
                         if (kw >= 0 && kw < K) {
 #pragma unroll
@@ -127,7 +136,7 @@ k_dw_fwd_q(const T* __restrict__ x, const float* __restrict__ bnstate, const flo
             }
             T* dst = y + (((long)n * g.Ho + oy) * g.Wo + ox) * g.C + c0;
 #pragma unroll
-            for (int o = 0; o < 4; ++o) {
+            for (int o = 0; o < OPL; ++o) {
                 if (ox + o < g.Wo) {
 #pragma unroll
                     for (int j = 0; j < N2; ++j) {
@@ -260,7 +269,10 @@ static int dw_fwd_q_t(const void* x, const float* in_bnstate, int in_act, const 
                       const dfd_dwconv_shape* s, float* partials, int pcap, int* nparts, hipStream_t st) {
     constexpr int V = Vec<T>::N;
     DwQGeom g; int tile_bytes;
-    if (!dfd_dwq_geom(s, V, 16, false, (size_t)(s ? s->k * s->k + 2 : 0) * 16 * V * 4, 0, 1, &g, &tile_bytes)) return DFD_EINVAL;
+    // two outputs per lane (five workgroups per CU: tile + tables within 31 KB): bf16 3x3 stride-1 layers (DW_FWD_PAIRS)
+    const bool pairs = DW_FWD_PAIRS && sizeof(T) == 2 && s && s->k == 3 && s->stride == 1;
+    const size_t tables = (size_t)(s ? s->k * s->k + 2 : 0) * 16 * V * 4;
+    if (!dfd_dwq_geom(s, V, 16, false, tables, 0, 1, &g, &tile_bytes, 1, pairs ? 31 * 1024 : 36 * 1024)) return DFD_EINVAL;
     const int cvb = 1 << g.cvb_log2, nchunks = (g.CV + cvb - 1) / cvb;
     // XCD-aware order (dwq_block): measured per layer — helps the forward kernel when an image spans
     // several tiles and the channel chunks share cache lines (block 2: 219 -> 201 us), hurts when one
@@ -279,9 +291,18 @@ static int dw_fwd_q_t(const void* x, const float* in_bnstate, int in_act, const 
     if (lds < red) lds = red;
     dim3 grid(nchunks, gy);
     const bool pro = in_bnstate != nullptr;
-#define LAUNCH_FWD(PRO, STATS) \
-    hipLaunchKernelGGL((k_dw_fwd_q<T, K, S, ACT, PRO, STATS>), grid, dim3(DFD_THREADS), lds, st, (const T*)x, in_bnstate, w, \
-                       (T*)y, g, partials, tile_bytes)
+#define LAUNCH_FWD(PRO, STATS)                                                                                               \
+    do {                                                                                                                     \
+        if constexpr (DW_FWD_PAIRS && sizeof(T) == 2 && K == 3 && S == 1) {                                                  \
+            if (pairs) {                                                                                                     \
+                hipLaunchKernelGGL((k_dw_fwd_q<T, K, S, ACT, PRO, STATS, -1, 2>), grid, dim3(DFD_THREADS), lds, st, (const T*)x, \
+                                   in_bnstate, w, (T*)y, g, partials, tile_bytes);                                           \
+                break;                                                                                                       \
+            }                                                                                                                \
+        }                                                                                                                    \
+        hipLaunchKernelGGL((k_dw_fwd_q<T, K, S, ACT, PRO, STATS>), grid, dim3(DFD_THREADS), lds, st, (const T*)x, in_bnstate, w, \
+                           (T*)y, g, partials, tile_bytes);                                                                  \
+    } while (0)
     DISPATCH_KS(s->k, s->stride, {
         if (pro) {
             DISPATCH_ACT_DW(in_act, { if (stats) LAUNCH_FWD(true, true); else LAUNCH_FWD(true, false); });
