@@ -66,8 +66,10 @@ k_bn_bwd_reduce(const T* __restrict__ g, const T* __restrict__ y, const float* _
     const bool active = rl < cm.rpb;
     const int c0 = (blockIdx.y * cm.cvb + vl) * V;
     float mean[V], rstd[V];
-    load_f32<V>(bnstate + 2 * C + c0, mean);
-    load_f32<V>(bnstate + 3 * C + c0, rstd);
+    if constexpr (HAS_Y) {
+        load_f32<V>(bnstate + 2 * C + c0, mean);
+        load_f32<V>(bnstate + 3 * C + c0, rstd);
+    }
     float acc[2 * V];
 #pragma unroll
     for (int j = 0; j < 2 * V; ++j) acc[j] = 0.f;
@@ -111,12 +113,12 @@ k_bn_bwd_reduce(const T* __restrict__ g, const T* __restrict__ y, const float* _
     }
     reduce_rowlanes<2 * V>(acc, red, cm.cvb, cm.rpb, vl, rl, active);
     if (rl == 0) {
-        float* p = partials + (long)blockIdx.x * 2 * C;
+        float* p = partials + (long)blockIdx.x * (HAS_Y ? 2 : 1) * C;      // HAS_Y false: rows of C sums (dfd_bias_grad)
         float a0[V], a1[V];
 #pragma unroll
         for (int j = 0; j < V; ++j) { a0[j] = acc[j]; a1[j] = acc[V + j]; }
         store_f32<V>(p + c0, a0);
-        store_f32<V>(p + C + c0, a1);
+        if constexpr (HAS_Y) store_f32<V>(p + C + c0, a1);
     }
 }
 
@@ -488,10 +490,30 @@ static int bn_bwd_reduce_t(const void* g, const void* y, const float* bnstate, c
 }
 extern "C" int dfd_bn_bwd_reduce(int dtype, const void* g, const void* y, const float* bnstate, const float* row_scale,
                                  int N, int HW, int C, float* partials, int pcap, int* nparts, dfd_stream stream) {
-    if (!shape_ok(dtype, N, HW, C) || !g || !bnstate || !partials || !nparts || pcap < 1) return DFD_EINVAL;
+    if (!shape_ok(dtype, N, HW, C) || !g || !y || !bnstate || !partials || !nparts || pcap < 1) return DFD_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     return dtype == DFD_BF16 ? bn_bwd_reduce_t<bf16>(g, y, bnstate, row_scale, N, HW, C, partials, pcap, nparts, st)
                              : bn_bwd_reduce_t<float>(g, y, bnstate, row_scale, N, HW, C, partials, pcap, nparts, st);
+}
+// Bias gradient of a layer without statistics (Linear + bias): dbias[c] (+)= sum over rows of g[row][c] (* row_scale[n]).
+// One reduction launch into partial rows [P][C] in `ws`, summed in row order by the weight gradients' summation (inside
+// dfd_sum_batch_begin/_end: with the block's other sums) — the BatchNorm-shaped pair it replaces (dfd_bn_bwd_reduce reading
+// y to multiply it by zero + a finalize launch per layer) cost two dependent launches where the second one was ~7 us of
+// pure latency (68 of them per FasterViT-0 step).
+extern "C" size_t dfd_bias_grad_ws(int N, int HW, int C) {
+    if (N < 1 || HW < 1 || C < 1) return 0;
+    return (size_t)(DFD_MAX_PARTIALS + DFD_MAX_PARTIALS / 32 + 2) * C * 4;
+}
+extern "C" int dfd_bias_grad(int dtype, const void* g, const float* row_scale, int N, int HW, int C, float* dbias, int accumulate,
+                             float* ws, size_t ws_bytes, dfd_stream stream) {
+    if (!shape_ok(dtype, N, HW, C) || !g || !dbias || !ws) return DFD_EINVAL;
+    if (ws_bytes < dfd_bias_grad_ws(N, HW, C)) return DFD_EWORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    int P = 0;
+    const int rc = dtype == DFD_BF16 ? bn_bwd_reduce_t<bf16>(g, nullptr, nullptr, row_scale, N, HW, C, ws, DFD_MAX_PARTIALS, &P, st)
+                                     : bn_bwd_reduce_t<float>(g, nullptr, nullptr, row_scale, N, HW, C, ws, DFD_MAX_PARTIALS, &P, st);
+    if (rc != DFD_OK) return rc;
+    return dfd_launch_sum_partials(ws, P, (long)C, dbias, accumulate, st);
 }
 
 template <typename T>
@@ -683,4 +705,4 @@ extern "C" int dfd_bn_bwd_finalize(const float* partials, int nparts, int C, dou
                                   nullptr, accumulate, coef, stream);
 }
 
-extern "C" int dfd_version(void) { return 120; }   // see include/dfd_hip.h
+extern "C" int dfd_version(void) { return 121; }   // see include/dfd_hip.h

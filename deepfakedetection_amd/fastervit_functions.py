@@ -340,16 +340,22 @@ def mlp_sub_bwd(g, saved, P, ls, row_scale, need: dict, need_dx: bool):
     C, hid = P["fc2_w"].shape[0], P["fc1_w"].shape[0]
     dev = x.device
     gb = K.scale_rows(g, row_scale) if row_scale is not None else g
-    parts, n = K.bn_bwd_reduce(gb, None if (ls is None and not need["ls"]) else y2, st2, None)
-    ones2, _ = ident(dev, C)
-    outs = (None, _slot(P["fc2_b"], need["fc2_b"], (C,)), _slot(ls, need["ls"], (C,)), None)
-    coef2, _, db2, dls, _ = K.bn_bwd_finalize_ex(parts, n, _rows(y2), ones2, P["fc2_b"], ls, st2, False, need["fc2_b"] or True, need["ls"],
-                                                 False, outs)
-    grads["fc2_b"], grads["ls"] = (db2 if need["fc2_b"] else None), dls
-    # fc2 has no BatchNorm: the backward map of its identity statistic is dz = ls * g.  Without layer scale that is g itself;
-    # with it the scaled gradient is materialised once (as a GEMM prologue it was evaluated once per 128-column tile of the
-    # data gradient — 8 times per element at hidden 1024 — and read y2 only to multiply it by zero)
-    dz2 = gb if ls is None else K.affine2_apply(gb, y2, coef2)
+    # fc2 has no BatchNorm: the backward map of its identity statistic is dz = ls * g.  Without layer scale that is g itself and
+    # the bias gradient is the column sums of g (one reduction launch, its final summation in the block's batch); with it the
+    # BatchNorm-shaped pair runs and the scaled gradient is materialised once (as a GEMM prologue it was evaluated once per
+    # 128-column tile of the data gradient — 8 times per element at hidden 1024 — and read y2 only to multiply it by zero)
+    if ls is None:
+        grads["fc2_b"] = K.bias_grad(gb, None, _slot(P["fc2_b"], True, (C,))) if need["fc2_b"] else None
+        grads["ls"] = None
+        dz2 = gb
+    else:
+        parts, n = K.bn_bwd_reduce(gb, y2, st2, None)
+        ones2, _ = ident(dev, C)
+        outs = (None, _slot(P["fc2_b"], need["fc2_b"], (C,)), _slot(ls, need["ls"], (C,)), None)
+        coef2, _, db2, dls, _ = K.bn_bwd_finalize_ex(parts, n, _rows(y2), ones2, P["fc2_b"], ls, st2, False, need["fc2_b"] or True,
+                                                     need["ls"], False, outs)
+        grads["fc2_b"], grads["ls"] = (db2 if need["fc2_b"] else None), dls
+        dz2 = K.affine2_apply(gb, y2, coef2)
     upstream = need_dx or any(need[k] for k in ("ln_w", "ln_b", "fc1_w", "fc1_b"))
     if need["fc2_w"]:
         grads["fc2_w"] = K.pwconv_wgrad(dz2, None, a, None, _slot(P["fc2_w"], True, (C, hid))).view(P["fc2_w"].shape)

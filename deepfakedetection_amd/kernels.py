@@ -343,15 +343,27 @@ def bn_act_apply(y: torch.Tensor, state: torch.Tensor, act: int, residual: torch
     return out
 
 
-def bn_bwd_reduce(g: torch.Tensor, y: torch.Tensor | None, state: torch.Tensor, row_scale: torch.Tensor | None = None):
-    """y None: only the sums of g (the second partial sum is written as zero)."""
-    _chk_nhwc(g if y is None else y)
-    N, H, W, C = g.shape if y is None else y.shape
-    parts = partials_buf(g.device, C)
+def bn_bwd_reduce(g: torch.Tensor, y: torch.Tensor, state: torch.Tensor, row_scale: torch.Tensor | None = None):
+    _chk_nhwc(y)
+    N, H, W, C = y.shape
+    parts = partials_buf(y.device, C)
     n = ctypes.c_int(0)
-    check(_L().dfd_bn_bwd_reduce(_dt(g), _p(g), _p(y), _p(state), _p(row_scale), N, H * W, C, _p(parts), MAX_PARTIALS,
-                                 ctypes.byref(n), _stream()), "dfd_bn_bwd_reduce", str(tuple(g.shape)))
+    check(_L().dfd_bn_bwd_reduce(_dt(y), _p(g), _p(y), _p(state), _p(row_scale), N, H * W, C, _p(parts), MAX_PARTIALS,
+                                 ctypes.byref(n), _stream()), "dfd_bn_bwd_reduce", str(tuple(y.shape)))
     return parts, n.value
+
+
+def bias_grad(g: torch.Tensor, row_scale: torch.Tensor | None = None, out: torch.Tensor | None = None) -> torch.Tensor:
+    """Sum of g [N,H,W,C] over its rows (times row_scale[n]) -> f32 [C]: the bias gradient of a Linear layer.  Inside
+    sum_batch() the final summation is deferred to the block's batch like a weight gradient's (valid after the block)."""
+    _chk_nhwc(g)
+    N, H, W, C = g.shape
+    nbytes = _L().dfd_bias_grad_ws(N, H * W, C)
+    ws = scratch(g.device, "bias_ws", nbytes)
+    db = _dst(out, (C,), g.device)
+    check(_L().dfd_bias_grad(_dt(g), _p(g), _p(row_scale), N, H * W, C, _p(db), 0, _p(ws), ws.numel() * 4, _stream()),
+          "dfd_bias_grad", str(tuple(g.shape)))
+    return db
 
 
 def act_bn_bwd(D: torch.Tensor | None, y: torch.Tensor, gate: torch.Tensor | None, dpool: torch.Tensor | None,

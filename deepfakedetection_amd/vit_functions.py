@@ -71,10 +71,20 @@ def pwbn_bwd(g, x, y, st, w_kn, w_shape, w, b, gamma, beta, ls, act, training, n
     prologue, which would read y only to multiply it by zero."""
     if row_scale is not None:
         g = K.scale_rows(g, row_scale)
+    # a Linear layer without layer scale: the BatchNorm-shaped backward degenerates to dz = g and dbias = column sums of g
+    plain = act == ACT_NONE and identity and not training and ls is None and not need_ls and b is None
+    if plain:
+        dbeta = K.bias_grad(g, None, _slot(beta, need_bn, (gamma.numel(),))) if (need_bn and beta is not None) else None
+        dx = dx_residual
+        if need_dx:
+            dx, _, _ = K.pwconv(g, None, w_kn, dx_residual, stats=False)
+        dw = None
+        if need_w:
+            O, I = w_shape[0], w_shape[1]
+            dw = K.pwconv_wgrad(g, None, x, None, _slot(w, True, (O, I))).view(w_shape)
+        return dx, dw, None, None, dbeta, None
     if act == ACT_NONE:
-        # a Linear layer without layer scale needs only the bias gradient (sum of g): y is not read
-        plain = identity and not training and ls is None and not need_ls
-        parts, n = K.bn_bwd_reduce(g, None if plain else y, st, None)
+        parts, n = K.bn_bwd_reduce(g, y, st, None)
         dz = g
     else:
         dz, parts, n = K.act_bn_bwd(g, y, None, None, st, act)

@@ -137,11 +137,15 @@ int dfd_bn_bwd_finalize_ex(const float* partials, int nparts, int C, double coun
 int dfd_bn_act_apply(int dtype, const void* y, const float* bnstate, int act,
                      const void* residual, const float* row_scale, void* out,
                      int N, int HW, int C, dfd_stream stream);
-/* partial sums of (g*rs, g*rs*xhat) per channel, xhat = (y-mean)*rstd; y == NULL: (g*rs, 0) — layers whose
- * "statistic" is the identity (Linear + bias) need only the bias gradient and skip the second operand            */
+/* partial sums of (g*rs, g*rs*xhat) per channel, xhat = (y-mean)*rstd            */
 int dfd_bn_bwd_reduce(int dtype, const void* g, const void* y, const float* bnstate,
                       const float* row_scale, int N, int HW, int C,
                       float* partials, int pcap, int* nparts, dfd_stream stream);
+/* dbias[c] (+)= sum over rows of g[row][c] (* row_scale[n]): the bias gradient of a Linear layer (no statistics).  ws:
+ * dfd_bias_grad_ws bytes; its final fixed-order summation joins an open dfd_sum_batch like a weight gradient's.  ABI 121 */
+size_t dfd_bias_grad_ws(int N, int HW, int C);
+int dfd_bias_grad(int dtype, const void* g, const float* row_scale, int N, int HW, int C, float* dbias, int accumulate,
+                  float* ws, size_t ws_bytes, dfd_stream stream);
 /* dz = (D*gate[n,c] + dpool[n,c]/HW) * act'(scale*y+shift); writes dz and the partial
  * sums (dz, dz*xhat).  D, gate, dpool are each optional (NULL): D==NULL means the
  * incoming gradient is dpool/HW only (global-average-pool backward).             */

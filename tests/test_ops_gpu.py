@@ -300,13 +300,13 @@ def test_rowpass(case, rd):
     coef2, _, _ = K.bn_bwd_finalize(parts, n, N * H * W, dev(gamma), dev(st), True)
     wc2, _, _ = R.bn_bwd_coef(g.float() * rs[:, None, None, None], y.float(), gamma, st)
     close(coef2, wc2, 2e-3, "bn bwd coef rs")
-    # without the second operand (layers whose statistic is the identity): the same sums of g, zeros for the second sum
-    for scale in (None, dev(rs)):
-        p_full, n_full = K.bn_bwd_reduce(dev(g), dev(y), dev(st), scale)
-        full = p_full[:n_full * 2 * C].view(n_full, 2, C).clone()
-        p_g, n_g = K.bn_bwd_reduce(dev(g), None, dev(st), scale)
-        only = p_g[:n_g * 2 * C].view(n_g, 2, C)
-        assert n_g == n_full and torch.equal(only[:, 0], full[:, 0]) and not only[:, 1].any()
+    # bias gradient of a layer without statistics: column sums of g (times the row scale), into a given destination too
+    for scale in (None, rs):
+        want_db = (g.float() * (1.0 if scale is None else scale[:, None, None, None])).sum((0, 1, 2))
+        got_db = K.bias_grad(dev(g), None if scale is None else dev(scale))
+        close(got_db, want_db, 2e-3, "bias grad")
+        slot = torch.full((C,), 7.0, device="cuda")
+        assert K.bias_grad(dev(g), None if scale is None else dev(scale), out=slot) is slot and torch.equal(slot, got_db)
     # act_bn_bwd, three modes
     gate = torch.rand((N, C), generator=torch.Generator().manual_seed(37))
     dpool = torch.randn((N, C), generator=torch.Generator().manual_seed(38))
