@@ -92,7 +92,50 @@ k_pw_nt(const T* __restrict__ a, ProArgs pa, const T* __restrict__ w, T* __restr
     // waits in the other set for its turn through the prologue into LDS
     struct Regs { uint4 a[AI], a2[AI], b[BN / 32]; unsigned ok; };
     Regs R0, R1;
+    // Full K stages (all 8 chunks): a lane's rows and chunk are the same for every such stage of a row
+    // tile, so its byte offsets inside the tile are computed ONCE per tile (weights: once per kernel) and a stage's addresses
+    // are a wave-uniform base + that offset — the per-stage clamps and 64-bit multiply-adds (~90 VALU instructions per lane
+    // and stage, as many issue cycles as the stage's 32 MFMAs) are gone from the K loop.
+    // (a K that is not a multiple of the tile: every stage but the last is full, the last one takes the general path)
+    const bool kany = !CONV && K >= BK;
+    auto stage_full = [&](int kt) { return kany && (kt + 1) * BK <= K; };
+    unsigned voffA[AI], voffB[BN / 32];
+    if (kany) {
+        const int c = t & 7, rb0 = t >> 3;
+#pragma unroll
+        for (int i = 0; i < BN / 32; ++i) {
+            const int r = rb0 + i * 32;
+            const int dn = n0 + r < Nout ? r : Nout - 1 - n0;
+            voffB[i] = (unsigned)(dn * K + c * E) * (unsigned)sizeof(T);
+        }
+    }
     auto g_load = [&](Regs& R, int mt, int kt, bool with_b) {
+        if (stage_full(kt)) {
+            const int m0 = mt * BM, k0 = kt * BK;
+            if (kt == 0) {                               // wave-uniform: first stage of a row tile
+                const int c = t & 7, rb0 = t >> 3;
+#pragma unroll
+                for (int i = 0; i < AI; ++i) {
+                    const int r = rb0 + i * 32;
+                    const int dm = m0 + r < M ? r : M - 1 - m0;
+                    voffA[i] = (unsigned)(dm * K + c * E) * (unsigned)sizeof(T);
+                }
+            }
+            const char* baseA = reinterpret_cast<const char*>(a) + ((long)m0 * K + k0) * (long)sizeof(T);
+#pragma unroll
+            for (int i = 0; i < AI; ++i) R.a[i] = *reinterpret_cast<const uint4*>(baseA + voffA[i]);
+            if constexpr (PRO == DFD_PRO_AFFINE2) {
+                const char* baseA2 = reinterpret_cast<const char*>(a2) + ((long)m0 * K + k0) * (long)sizeof(T);
+#pragma unroll
+                for (int i = 0; i < AI; ++i) R.a2[i] = *reinterpret_cast<const uint4*>(baseA2 + voffA[i]);
+            }
+            if (with_b) {
+                const char* baseB = reinterpret_cast<const char*>(w) + ((long)n0 * K + k0) * (long)sizeof(T);
+#pragma unroll
+                for (int i = 0; i < BN / 32; ++i) R.b[i] = *reinterpret_cast<const uint4*>(baseB + voffB[i]);
+            }
+            return;
+        }
         int kc, sh;
         tile_kc(kt, kc, sh);
         const int c = t & ((1 << sh) - 1), rb0 = t >> sh, rstep = DFD_THREADS >> sh;
@@ -156,6 +199,34 @@ k_pw_nt(const T* __restrict__ a, ProArgs pa, const T* __restrict__ w, T* __restr
         }
     };
     auto s_store = [&](const Regs& R, int mt, int kt, int buf, bool with_b) {
+        if (stage_full(kt)) {                            // all 8 chunks, 32 rows per pass: no per-item range checks, no branches
+            const int c = t & 7, rb0 = t >> 3;
+            unsigned char* ab = smem + buf * L::A_BYTES;
+            unsigned char* bb = smem + L::BOFF + buf * L::B_BYTES;
+            const int m0 = mt * BM, k0 = kt * BK;
+            const bool full_m = m0 + BM <= M, full_n = n0 + BN <= Nout;      // wave-uniform: only edge tiles select zeros
+#pragma unroll
+            for (int i = 0; i < AI; ++i) {
+                const int r = rb0 + i * 32;
+                const bool valid = full_m || m0 + r < M;
+                uint4 q = R.a[i];
+                if constexpr (PRO != DFD_PRO_NONE) {
+                    const float* gk = nullptr;
+                    if constexpr (PRO == DFD_PRO_BN_ACT_GATE) gk = pa.gate + (long)pro_image(pa, valid ? m0 + r : M - 1) * K + k0 + c * E;
+                    q = apply_pro_c<T, PRO, ACT, E>(R.a[i], R.a2[i], c0, c1, c2, gk);
+                }
+                if (!valid) q = make_uint4(0, 0, 0, 0);
+                *reinterpret_cast<uint4*>(ab + r * 128 + ((c ^ (r & 7)) << 4)) = q;
+            }
+            if (with_b) {
+#pragma unroll
+                for (int i = 0; i < BN / 32; ++i) {
+                    const int r = rb0 + i * 32;
+                    *reinterpret_cast<uint4*>(bb + r * 128 + ((c ^ (r & 7)) << 4)) = (full_n || n0 + r < Nout) ? R.b[i] : make_uint4(0, 0, 0, 0);
+                }
+            }
+            return;
+        }
         int kc, sh;
         tile_kc(kt, kc, sh);
         const int c = t & ((1 << sh) - 1), rb0 = t >> sh, rstep = DFD_THREADS >> sh;
