@@ -108,14 +108,15 @@ k_pw_ntw(const T* __restrict__ a, ProArgs pa, const T* __restrict__ w, T* __rest
         for (int j = 0; j < JN; ++j)
 #pragma unroll
             for (int ks = 0; ks < KSN; ++ks) {
+                // Unconditional loads from a row / chunk clamped into the operand (as in k_pw_nt): inside divergent branches the
+                // compiler cannot count the loads in flight and waited vmcnt(0) right behind the request — the two register sets
+                // pipelined nothing.  Rows past M are never stored; chunks past K become zeros where the fragment is formed
+                // (`prologue`), a stage later — a select on the load's own destination would wait for the load again.
                 const int row = rbase + j * 16, kk = kt * BK + (ks * 4 + fk) * E;
-                R.a[j][ks] = make_uint4(0, 0, 0, 0);
-                if (PRO == DFD_PRO_AFFINE2) R.a2[j][ks] = make_uint4(0, 0, 0, 0);
-                if (row < M && kk < K) {
-                    const long off = (long)row * K + kk;
-                    R.a[j][ks] = *reinterpret_cast<const uint4*>(a + off);
-                    if constexpr (PRO == DFD_PRO_AFFINE2) R.a2[j][ks] = *reinterpret_cast<const uint4*>(a2 + off);
-                }
+                const long off = (long)(row < M ? row : M - 1) * K + (kk < K ? kk : 0);
+                R.a[j][ks] = *reinterpret_cast<const uint4*>(a + off);
+                if constexpr (PRO == DFD_PRO_AFFINE2) R.a2[j][ks] = *reinterpret_cast<const uint4*>(a2 + off);
+
             }
     };
     auto gate_load = [&](int mt, int kt) {
@@ -143,7 +144,7 @@ k_pw_ntw(const T* __restrict__ a, ProArgs pa, const T* __restrict__ w, T* __rest
 #pragma unroll
             for (int j = 0; j < JN; ++j) {
                 if constexpr (PRO == DFD_PRO_NONE) {
-                    fa[j][ks] = R.a[j][ks];
+                    fa[j][ks] = (kt * BK + (ks * 4 + fk) * E < K) ? R.a[j][ks] : make_uint4(0, 0, 0, 0);
                 } else {
                     const int kk = kt * BK + (ks * 4 + fk) * E;
                     float v[E], c0[E], c1[E];
@@ -165,7 +166,7 @@ k_pw_ntw(const T* __restrict__ a, ProArgs pa, const T* __restrict__ w, T* __rest
                             for (int x = 0; x < E; ++x) v[x] = round_to<T>(v[x]) * gt[j][ks][x];
                         }
                     }
-                    fa[j][ks] = f_to_q(v);
+                    fa[j][ks] = kk < K ? f_to_q(v) : make_uint4(0, 0, 0, 0);
                 }
             }
     };
