@@ -72,7 +72,8 @@ typedef void* dfd_stream;          /* a hipStream_t */
  * 112 = the eval / inference form of the MBConv block: dfd_pwconv_fwd_eval, dfd_dwconv_fwd_eval(_tiles),
  * dfd_se_fwd_parts;
  * 120 = MX fp8 weights (dfd_mx_*), fused window attention on bf16 MFMA (dfd_wattn_*),
- * batched coordinate MLPs (dfd_coord_mlp_*_multi, dfd_relpos_bias_*_multi), dfd_dwconv_bwd_fused, dfd_resize_crop_u8. */
+ * batched coordinate MLPs (dfd_coord_mlp_*_multi, dfd_relpos_bias_*_multi), dfd_dwconv_bwd_fused, dfd_resize_crop_u8;
+ * 121 = dfd_bias_grad / dfd_bias_grad_ws. */
 int dfd_version(void);
 
 /* Batched final summation of weight gradients.  The weight-gradient entry points whose result goes straight to the
