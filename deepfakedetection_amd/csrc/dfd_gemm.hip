@@ -1,0 +1,139 @@
+// dfd_gemm.hip — plain bf16 NT product out[M][N] = a[M][K] * w[N][K]^T for MANY rows and a deep K (FasterViT's Linear layers:
+// 54 k x 256..1024 x 256..1024, forward and data gradient), the shape class where the 128 x 128 four-wave kernel of
+// dfd_pwconv.hip stops at half of hipBLASLt's rate: its barrier-per-stage loop of 64 x 64-per-wave tiles costs 45 us on
+// 54 k x 1024 x 256 with every global load removed, against 11 us of MFMA time.
+//
+// Structure (cdna_hip_programming.md 5, "glds vs register staging": 256^2 tile, one workgroup per CU, two LDS buffers, BK = 64):
+//   * 256 x 256 output tile, 512 threads = 8 waves as 4 (rows) x 2 (columns): 64 x 128 outputs per wave = 32 accumulator
+//     tiles; per 32-deep k sub-step 4 + 8 fragment reads feed 32 MFMAs (0.375 reads per MFMA against 0.5);
+//   * operands go global -> LDS by LDS-DMA (`global_load_lds_dwordx4`): no staging registers, no ds_write pass.  The LDS
+//     image of a stage is [rows][64 k] in 128-byte rows with the 16-byte chunks XOR-swizzled by the row (conflict-free
+//     fragment reads); a DMA instruction's destination is lane-linear (1 KB = 8 rows), so the swizzle is applied to the
+//     per-lane SOURCE address;
+//   * per stage: wait for the stage's DMA, barrier, request the next stage into the other buffer, MFMAs;
+//   * epilogue through an LDS overlay in whole 16-byte row pieces (8-byte stores from the accumulators measured slower).
+// Rows / columns past the operands are clamped at the source and masked at the store.  Anything else (prologues, statistics,
+// residuals, f32, K % 64, narrow N, too few tiles to fill the chip) stays with k_pw_nt.
+#include "dfd_common.h"
+#include "dfd_pw.h"
+
+#define GD_THREADS 512
+#define GD_BM 256
+#define GD_BN 256
+#define GD_BK 64
+#define GD_A_BYTES (GD_BM * 128)
+#define GD_B_BYTES (GD_BN * 128)
+#define GD_STAGE (GD_A_BYTES + GD_B_BYTES)
+#define GD_OROW (GD_BN * 2 + 16)
+#define GD_LDS ((2 * GD_STAGE) > (GD_BM * GD_OROW) ? (2 * GD_STAGE) : (GD_BM * GD_OROW))
+
+typedef __attribute__((address_space(3))) void gd_lds_void;
+typedef __attribute__((address_space(1))) const void gd_glb_void;
+
+__global__ void __launch_bounds__(GD_THREADS, 1)
+k_gemm_nt_dma(const unsigned short* __restrict__ a, const unsigned short* __restrict__ w, unsigned short* __restrict__ out, int M, int K,
+              int N, int m_tiles, int n_tiles) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // XCD-aware order: the column tiles of one row tile run back to back on one XCD (they share the A rows in its L2)
+    const int total = m_tiles * n_tiles;
+    int lin = blockIdx.x;
+    {
+        const int q = total >> 3, r = total & 7, xcd = lin & 7, slot = lin >> 3;
+        lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+    }
+    const int mt = lin / n_tiles, nt = lin - mt * n_tiles;
+    const int m0 = mt * GD_BM, n0 = nt * GD_BN;
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int frow = lane & 15, fk = lane >> 4;
+    const int nk = K / GD_BK;
+
+    // DMA sources: instruction j of this wave fills LDS units [(j * 8 + wave) * 64, +64) of the A (B) image; unit u is row
+    // u >> 3, slot u & 7, and holds source chunk (u & 7) ^ (row & 7) of that row
+    const unsigned short* srcA[4];
+    const unsigned short* srcB[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int u = (j * 8 + wave) * 64 + lane, r = u >> 3, c = (u & 7) ^ (r & 7);
+        const int ma = m0 + r < M ? m0 + r : M - 1, nb = n0 + r < N ? n0 + r : N - 1;
+        srcA[j] = a + (long)ma * K + c * 8;
+        srcB[j] = w + (long)nb * K + c * 8;
+    }
+    auto request = [&](int kt, int buf) {
+        unsigned char* sa = smem + buf * GD_STAGE;
+        unsigned char* sb = sa + GD_A_BYTES;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            __builtin_amdgcn_global_load_lds((gd_glb_void*)(srcA[j] + kt * GD_BK), (gd_lds_void*)(sa + (j * 8 + wave) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gd_glb_void*)(srcB[j] + kt * GD_BK), (gd_lds_void*)(sb + (j * 8 + wave) * 1024), 16, 0, 0);
+        }
+    };
+
+    f32x4_t acc[8][4];                                   // [n fragment][m fragment]
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    request(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+        __builtin_amdgcn_s_waitcnt(0x0F70);              // vmcnt(0): this wave's DMA of stage kt has landed
+        __syncthreads();                                 // ... everybody's has, and the other buffer is no longer read
+        if (kt + 1 < nk) request(kt + 1, (kt + 1) & 1);
+        const unsigned char* ab = smem + (kt & 1) * GD_STAGE;
+        const unsigned char* bb = ab + GD_A_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int c = ks * 4 + fk;
+            uint4 fa[4], fw[8];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int r = wm * 64 + j * 16 + frow;
+                fa[j] = *reinterpret_cast<const uint4*>(ab + r * 128 + ((c ^ (r & 7)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int r = wn * 128 + i * 16 + frow;
+                fw[i] = *reinterpret_cast<const uint4*>(bb + r * 128 + ((c ^ (r & 7)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, fw[i]), __builtin_bit_cast(bf16x8_t, fa[j]),
+                                                                        acc[i][j], 0, 0, 0);
+        }
+    }
+    // ---- accumulators -> LDS overlay [m][n] -> 16-byte row-major stores
+    __syncthreads();                                     // every wave is done with the last stage's buffers
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int m = wm * 64 + j * 16 + frow, n = wn * 128 + i * 16 + fk * 4;
+            *reinterpret_cast<uint2*>(smem + m * GD_OROW + n * 2) = make_uint2(pack_bf2(acc[i][j][0], acc[i][j][1]), pack_bf2(acc[i][j][2], acc[i][j][3]));
+        }
+    __syncthreads();
+#pragma unroll 4
+    for (int idx = t; idx < GD_BM * (GD_BN / 8); idx += GD_THREADS) {
+        const int r = idx >> 5, ch = idx & 31;           // 32 sixteen-byte pieces per row
+        const int m = m0 + r, n = n0 + ch * 8;
+        if (m < M && n < N) *reinterpret_cast<uint4*>(out + (long)m * N + n) = *reinterpret_cast<const uint4*>(smem + r * GD_OROW + ch * 16);
+    }
+}
+
+// DFD_EUNSUPPORTED: not this kernel's shape (the caller runs k_pw_nt)
+int dfd_gemm_nt_dma(const void* a, const void* w, void* out, int M, int K, int N, hipStream_t st) {
+    if (K % GD_BK || K < 2 * GD_BK || N % 8 || N < GD_BN || M < GD_BM) return DFD_EUNSUPPORTED;
+    const int m_tiles = (M + GD_BM - 1) / GD_BM, n_tiles = (N + GD_BN - 1) / GD_BN;
+    if ((long)m_tiles * n_tiles < 160) return DFD_EUNSUPPORTED;          // fewer tiles than CUs: the smaller tiles fill the chip better
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_nt_dma), hipFuncAttributeMaxDynamicSharedMemorySize, GD_LDS);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_gemm_nt_dma, dim3((unsigned)(m_tiles * n_tiles)), dim3(GD_THREADS), GD_LDS, st, (const unsigned short*)a,
+                       (const unsigned short*)w, (unsigned short*)out, M, K, N, m_tiles, n_tiles);
+    return DFD_CHECK_LAUNCH();
+}

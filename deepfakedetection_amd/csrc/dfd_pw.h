@@ -193,6 +193,9 @@ size_t dfd_conv3_wgrad_ws(const dfd_dwconv_shape* s, int Cout);
 int dfd_conv3_wgrad(const void* p, const dfd_prologue* pro_p, int Cout, const void* x, const dfd_dwconv_shape* s,
                     const float* in_bnstate, int in_act, float* dw, int accumulate, float* ws, size_t ws_bytes, hipStream_t st);
 
+// plain bf16 NT product on 256 x 256 tiles with LDS-DMA staging (dfd_gemm.hip); DFD_EUNSUPPORTED: shape not served
+int dfd_gemm_nt_dma(const void* a, const void* w, void* out, int M, int K, int N, hipStream_t st);
+
 // wave-autonomous TN (weight-gradient) kernel for large-M layers with a narrow and a wide operand
 // (dfd_pwtnw.hip, bf16 only); DFD_EUNSUPPORTED when the shape does not qualify
 int dfd_pw_tnw(const void* p, const dfd_prologue* pro_p, int Ni, const void* q, const dfd_prologue* pro_q, int Nj, int M,

@@ -825,6 +825,12 @@ template <typename T>
 static int pw_nt_t(const void* a, const dfd_prologue* pro, const void* w, void* out, const void* residual, int M, int K,
                    int Nout, float* partials, int pcap, int* nparts, hipStream_t st, const float* ebn = nullptr,
                    int eact = DFD_ACT_NONE) {
+    if constexpr (sizeof(T) == 2) {                      // plain product, many rows, deep K: 256 x 256 tiles with LDS-DMA staging
+        if (!pro && !residual && !partials && !ebn) {
+            const int rc = dfd_gemm_nt_dma(a, w, out, M, K, Nout, st);
+            if (rc != DFD_EUNSUPPORTED) return rc;
+        }
+    }
     // 128-row tiles unless they would leave most CUs without a workgroup (the 7x7 / 14x14 layers)
     const long tiles128 = (long)((M + 127) / 128) * ((Nout + 127) / 128);
     const bool small = tiles128 < 256;      // measured: a win below one tile per CU, a loss above

@@ -654,3 +654,25 @@ def test_packed_pair_gelu_is_the_scalar_gelu_bit_for_bit(rd):
     d_packed, _, _ = K.act_bn_bwd(g, y, None, None, st, R.ACT_GELU)
     d_scalar, _, _ = K.bn_add_act_bwd(g, y, st, None, R.ACT_GELU, stats=False)
     assert torch.equal(d_packed, d_scalar), float((d_packed.float() - d_scalar.float()).abs().max())
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("shape", [(256 * 80 + 17, 192, 520), (256 * 170, 128, 256), (256 * 41 + 255, 1024, 1032)])
+def test_plain_bf16_product_on_256_tiles_with_lds_dma(shape):
+    """Plain bf16 products with >= 160 tiles of 256 x 256 and K % 64 == 0 run `k_gemm_nt_dma` (csrc/dfd_gemm.hip: LDS-DMA staging,
+    swizzle on the source address, eight waves): ragged last row / column tiles (clamped sources, masked stores), K from two
+    stages up.  Against the f32 product of the same bf16 operands: one bf16 rounding of the result."""
+    K = _k()
+    M, Kd, N = shape
+    g = torch.Generator().manual_seed(M + N)
+    a = (torch.randn((M, 1, 1, Kd), generator=g)).to(torch.bfloat16).cuda()
+    w = (torch.randn((N, Kd), generator=g) * Kd ** -0.5).cuda()
+    w_nk, _ = K.prep_weights(w, torch.bfloat16, True, False)
+    out, _, _ = K.pwconv(a, None, w_nk, None, stats=False)
+    want = a.view(M, Kd).float() @ w.to(torch.bfloat16).float().t()
+    err = (out.view(M, N).float() - want).abs().max()
+    assert float(err) <= 2.0 ** -8 * float(want.abs().max()) + 1e-6, (float(err), float(want.abs().max()))
+    # rows far apart and the ragged edges, exactly as stored
+    rows = torch.tensor([0, 1, 255, 256, M // 2, M - 2, M - 1], device="cuda")
+    assert torch.equal(out.view(M, N)[rows], want[rows].to(torch.bfloat16)) or float(
+        (out.view(M, N)[rows].float() - want[rows]).abs().max()) <= 2.0 ** -8 * float(want.abs().max())
