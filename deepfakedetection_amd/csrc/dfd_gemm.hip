@@ -10,29 +10,37 @@
 //     image of a stage is [rows][64 k] in 128-byte rows with the 16-byte chunks XOR-swizzled by the row (conflict-free
 //     fragment reads); a DMA instruction's destination is lane-linear (1 KB = 8 rows), so the swizzle is applied to the
 //     per-lane SOURCE address;
-//   * per stage: wait for the stage's DMA, barrier, request the next stage into the other buffer, MFMAs;
+//   * per stage: wait for the stage's DMA, barrier, all fragment reads, request the next stage into the other buffer, MFMAs;
 //   * epilogue through an LDS overlay in whole 16-byte row pieces (8-byte stores from the accumulators measured slower).
 // Rows / columns past the operands are clamped at the source and masked at the store.  Anything else (prologues, statistics,
 // residuals, f32, K % 64, narrow N, too few tiles to fill the chip) stays with k_pw_nt.
 #include "dfd_common.h"
 #include "dfd_pw.h"
 
-#define GD_THREADS 512
-#define GD_BM 256
+#ifndef GD_ROWS128
+#define GD_ROWS128 1            // 128-row tiles where 256-row tiles would leave CUs idle (A/B switch)
+#endif
 #define GD_BN 256
 #define GD_BK 64
-#define GD_A_BYTES (GD_BM * 128)
 #define GD_B_BYTES (GD_BN * 128)
-#define GD_STAGE (GD_A_BYTES + GD_B_BYTES)
 #define GD_OROW (GD_BN * 2 + 16)
-#define GD_LDS ((2 * GD_STAGE) > (GD_BM * GD_OROW) ? (2 * GD_STAGE) : (GD_BM * GD_OROW))
+// WM = waves along the rows (4: 256-row tiles, 512 threads; 2: 128-row tiles, 256 threads — when 256-row tiles would not fill the chip)
+template <int WM> struct GdGeom {
+    static constexpr int BM = 64 * WM, NW = 2 * WM, THREADS = 64 * NW;
+    static constexpr int A_BYTES = BM * 128, STAGE = A_BYTES + GD_B_BYTES;
+    static constexpr int LDS = (2 * STAGE) > (BM * GD_OROW) ? (2 * STAGE) : (BM * GD_OROW);
+    static constexpr int JA = BM * 8 / 64 / NW, JB = GD_BN * 8 / 64 / NW;        // DMA instructions per wave and stage
+};
 
 typedef __attribute__((address_space(3))) void gd_lds_void;
 typedef __attribute__((address_space(1))) const void gd_glb_void;
 
-__global__ void __launch_bounds__(GD_THREADS, 1)
+template <int WM>
+__global__ void __launch_bounds__(GdGeom<WM>::THREADS, 1)
 k_gemm_nt_dma(const unsigned short* __restrict__ a, const unsigned short* __restrict__ w, unsigned short* __restrict__ out, int M, int K,
               int N, int m_tiles, int n_tiles) {
+    using G = GdGeom<WM>;
+    constexpr int GD_BM = G::BM, GD_A_BYTES = G::A_BYTES, GD_STAGE = G::STAGE, GD_THREADS = G::THREADS, NW = G::NW;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // XCD-aware order: the column tiles of one row tile run back to back on one XCD (they share the A rows in its L2)
     const int total = m_tiles * n_tiles;
@@ -51,23 +59,27 @@ k_gemm_nt_dma(const unsigned short* __restrict__ a, const unsigned short* __rest
 
     // DMA sources: instruction j of this wave fills LDS units [(j * 8 + wave) * 64, +64) of the A (B) image; unit u is row
     // u >> 3, slot u & 7, and holds source chunk (u & 7) ^ (row & 7) of that row
-    const unsigned short* srcA[4];
-    const unsigned short* srcB[4];
+    const unsigned short* srcA[G::JA];
+    const unsigned short* srcB[G::JB];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int u = (j * 8 + wave) * 64 + lane, r = u >> 3, c = (u & 7) ^ (r & 7);
-        const int ma = m0 + r < M ? m0 + r : M - 1, nb = n0 + r < N ? n0 + r : N - 1;
-        srcA[j] = a + (long)ma * K + c * 8;
-        srcB[j] = w + (long)nb * K + c * 8;
+    for (int j = 0; j < G::JA; ++j) {
+        const int u = (j * NW + wave) * 64 + lane, r = u >> 3, c = (u & 7) ^ (r & 7);
+        srcA[j] = a + (long)(m0 + r < M ? m0 + r : M - 1) * K + c * 8;
+    }
+#pragma unroll
+    for (int j = 0; j < G::JB; ++j) {
+        const int u = (j * NW + wave) * 64 + lane, r = u >> 3, c = (u & 7) ^ (r & 7);
+        srcB[j] = w + (long)(n0 + r < N ? n0 + r : N - 1) * K + c * 8;
     }
     auto request = [&](int kt, int buf) {
         unsigned char* sa = smem + buf * GD_STAGE;
         unsigned char* sb = sa + GD_A_BYTES;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            __builtin_amdgcn_global_load_lds((gd_glb_void*)(srcA[j] + kt * GD_BK), (gd_lds_void*)(sa + (j * 8 + wave) * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((gd_glb_void*)(srcB[j] + kt * GD_BK), (gd_lds_void*)(sb + (j * 8 + wave) * 1024), 16, 0, 0);
-        }
+        for (int j = 0; j < G::JA; ++j)
+            __builtin_amdgcn_global_load_lds((gd_glb_void*)(srcA[j] + kt * GD_BK), (gd_lds_void*)(sa + (j * NW + wave) * 1024), 16, 0, 0);
+#pragma unroll
+        for (int j = 0; j < G::JB; ++j)
+            __builtin_amdgcn_global_load_lds((gd_glb_void*)(srcB[j] + kt * GD_BK), (gd_lds_void*)(sb + (j * NW + wave) * 1024), 16, 0, 0);
     };
 
     f32x4_t acc[8][4];                                   // [n fragment][m fragment]
@@ -76,34 +88,43 @@ k_gemm_nt_dma(const unsigned short* __restrict__ a, const unsigned short* __rest
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
+    // Per stage: wait for its DMA, barrier, read ALL of the stage's fragments (24 x 16 bytes per lane), THEN request the next
+    // stage, then the 64 MFMAs.  The compiler orders every ds_read behind a pending LDS-DMA with s_waitcnt vmcnt(0) (it cannot
+    // tell the buffers apart): requested before the fragment reads, the next stage's DMA was waited for on the spot and
+    // overlapped nothing inside the wave; requested after them it drains underneath the MFMAs.
     request(0, 0);
+    int buf = 0;
     for (int kt = 0; kt < nk; ++kt) {
         __builtin_amdgcn_s_waitcnt(0x0F70);              // vmcnt(0): this wave's DMA of stage kt has landed
         __syncthreads();                                 // ... everybody's has, and the other buffer is no longer read
-        if (kt + 1 < nk) request(kt + 1, (kt + 1) & 1);
-        const unsigned char* ab = smem + (kt & 1) * GD_STAGE;
+        const unsigned char* ab = smem + buf * GD_STAGE;
         const unsigned char* bb = ab + GD_A_BYTES;
+        uint4 fa[2][4], fw[2][8];
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const int c = ks * 4 + fk;
-            uint4 fa[4], fw[8];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int r = wm * 64 + j * 16 + frow;
-                fa[j] = *reinterpret_cast<const uint4*>(ab + r * 128 + ((c ^ (r & 7)) << 4));
+                fa[ks][j] = *reinterpret_cast<const uint4*>(ab + r * 128 + ((c ^ (r & 7)) << 4));
             }
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const int r = wn * 128 + i * 16 + frow;
-                fw[i] = *reinterpret_cast<const uint4*>(bb + r * 128 + ((c ^ (r & 7)) << 4));
+                fw[ks][i] = *reinterpret_cast<const uint4*>(bb + r * 128 + ((c ^ (r & 7)) << 4));
             }
+        }
+        __builtin_amdgcn_s_waitcnt(0xC07F);              // lgkmcnt(0): the fragments are in registers
+        if (kt + 1 < nk) request(kt + 1, buf ^ 1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
             for (int i = 0; i < 8; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, fw[i]), __builtin_bit_cast(bf16x8_t, fa[j]),
-                                                                        acc[i][j], 0, 0, 0);
-        }
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, fw[ks][i]),
+                                                                        __builtin_bit_cast(bf16x8_t, fa[ks][j]), acc[i][j], 0, 0, 0);
+        buf ^= 1;
     }
     // ---- accumulators -> LDS overlay [m][n] -> 16-byte row-major stores
     __syncthreads();                                     // every wave is done with the last stage's buffers
@@ -124,16 +145,23 @@ k_gemm_nt_dma(const unsigned short* __restrict__ a, const unsigned short* __rest
 }
 
 // DFD_EUNSUPPORTED: not this kernel's shape (the caller runs k_pw_nt)
-int dfd_gemm_nt_dma(const void* a, const void* w, void* out, int M, int K, int N, hipStream_t st) {
-    if (K % GD_BK || K < 2 * GD_BK || N % 8 || N < GD_BN || M < GD_BM) return DFD_EUNSUPPORTED;
-    const int m_tiles = (M + GD_BM - 1) / GD_BM, n_tiles = (N + GD_BN - 1) / GD_BN;
-    if ((long)m_tiles * n_tiles < 160) return DFD_EUNSUPPORTED;          // fewer tiles than CUs: the smaller tiles fill the chip better
+template <int WM>
+static int gemm_nt_dma_launch(const void* a, const void* w, void* out, int M, int K, int N, int m_tiles, int n_tiles, hipStream_t st) {
+    using G = GdGeom<WM>;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_nt_dma), hipFuncAttributeMaxDynamicSharedMemorySize, GD_LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_nt_dma<WM>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
         attr_set = true;
     }
-    hipLaunchKernelGGL(k_gemm_nt_dma, dim3((unsigned)(m_tiles * n_tiles)), dim3(GD_THREADS), GD_LDS, st, (const unsigned short*)a,
+    hipLaunchKernelGGL((k_gemm_nt_dma<WM>), dim3((unsigned)(m_tiles * n_tiles)), dim3(G::THREADS), G::LDS, st, (const unsigned short*)a,
                        (const unsigned short*)w, (unsigned short*)out, M, K, N, m_tiles, n_tiles);
     return DFD_CHECK_LAUNCH();
+}
+int dfd_gemm_nt_dma(const void* a, const void* w, void* out, int M, int K, int N, hipStream_t st) {
+    if (K % GD_BK || K < 2 * GD_BK || N % 8 || N < GD_BN || M < 256) return DFD_EUNSUPPORTED;
+    const int n_tiles = (N + GD_BN - 1) / GD_BN;
+    const int mt256 = (M + 255) / 256, mt128 = (M + 127) / 128;
+    if ((long)mt256 * n_tiles >= 160) return gemm_nt_dma_launch<4>(a, w, out, M, K, N, mt256, n_tiles, st);
+    if (GD_ROWS128 && (long)mt128 * n_tiles >= 160) return gemm_nt_dma_launch<2>(a, w, out, M, K, N, mt128, n_tiles, st);
+    return DFD_EUNSUPPORTED;                             // fewer tiles than CUs: the smaller tiles of k_pw_nt fill the chip better
 }
