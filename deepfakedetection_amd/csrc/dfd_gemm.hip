@@ -35,10 +35,21 @@ template <int WM> struct GdGeom {
 typedef __attribute__((address_space(3))) void gd_lds_void;
 typedef __attribute__((address_space(1))) const void gd_glb_void;
 
-template <int WM>
+// EACT < 0: out = the product.  EACT = DFD_ACT_NONE / DFD_ACT_GELU: the BN-apply pass of the engine fused into the store
+// loop — out = act(scale[n] * y + shift[n]) [* row_scale[row / HW]] [+ residual], with y the product ROUNDED to bf16 first (it
+// sits in the LDS overlay as bf16), i.e. the same arithmetic on the same values as dfd_bn_act_apply on a stored y: identical
+// bits; yraw (optional) also receives y itself (the layers whose backward needs the pre-activation).
+struct GdEpi {
+    const float* st;            // [2][N]: scale, shift
+    const unsigned short* res;  // [M][N] or null
+    const float* rs;            // per image or null
+    unsigned short* yraw;       // [M][N] or null
+    int HW;
+};
+template <int WM, int EACT>
 __global__ void __launch_bounds__(GdGeom<WM>::THREADS, 1)
 k_gemm_nt_dma(const unsigned short* __restrict__ a, const unsigned short* __restrict__ w, unsigned short* __restrict__ out, int M, int K,
-              int N, int m_tiles, int n_tiles) {
+              int N, int m_tiles, int n_tiles, GdEpi ep) {
     using G = GdGeom<WM>;
     constexpr int GD_BM = G::BM, GD_A_BYTES = G::A_BYTES, GD_STAGE = G::STAGE, GD_THREADS = G::THREADS, NW = G::NW;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -140,28 +151,73 @@ k_gemm_nt_dma(const unsigned short* __restrict__ a, const unsigned short* __rest
     for (int idx = t; idx < GD_BM * (GD_BN / 8); idx += GD_THREADS) {
         const int r = idx >> 5, ch = idx & 31;           // 32 sixteen-byte pieces per row
         const int m = m0 + r, n = n0 + ch * 8;
-        if (m < M && n < N) *reinterpret_cast<uint4*>(out + (long)m * N + n) = *reinterpret_cast<const uint4*>(smem + r * GD_OROW + ch * 16);
+        if (m < M && n < N) {
+            uint4 q = *reinterpret_cast<const uint4*>(smem + r * GD_OROW + ch * 16);
+            if constexpr (EACT >= 0) {
+                if (ep.yraw) *reinterpret_cast<uint4*>(ep.yraw + (long)m * N + n) = q;
+                float v[8], sc[8], sh[8];
+                Vec<bf16>::unpack(q, v);
+                load_f32<8>(ep.st + n, sc);
+                load_f32<8>(ep.st + N + n, sh);
+                bn_act_array<EACT, 8>(v, sc, sh);
+                if (ep.rs) {
+                    const float rr = ep.rs[m / ep.HW];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] *= rr;
+                }
+                if (ep.res) {
+                    float qq[8];
+                    Vec<bf16>::unpack(*reinterpret_cast<const uint4*>(ep.res + (long)m * N + n), qq);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] += qq[j];
+                }
+                q = Vec<bf16>::pack(v);
+            }
+            *reinterpret_cast<uint4*>(out + (long)m * N + n) = q;
+        }
     }
 }
 
 // DFD_EUNSUPPORTED: not this kernel's shape (the caller runs k_pw_nt)
-template <int WM>
-static int gemm_nt_dma_launch(const void* a, const void* w, void* out, int M, int K, int N, int m_tiles, int n_tiles, hipStream_t st) {
+template <int WM, int EACT>
+static int gemm_nt_dma_launch(const void* a, const void* w, void* out, int M, int K, int N, int m_tiles, int n_tiles, const GdEpi& ep,
+                              hipStream_t st) {
     using G = GdGeom<WM>;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_nt_dma<WM>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_nt_dma<WM, EACT>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
         attr_set = true;
     }
-    hipLaunchKernelGGL((k_gemm_nt_dma<WM>), dim3((unsigned)(m_tiles * n_tiles)), dim3(G::THREADS), G::LDS, st, (const unsigned short*)a,
-                       (const unsigned short*)w, (unsigned short*)out, M, K, N, m_tiles, n_tiles);
+    hipLaunchKernelGGL((k_gemm_nt_dma<WM, EACT>), dim3((unsigned)(m_tiles * n_tiles)), dim3(G::THREADS), G::LDS, st, (const unsigned short*)a,
+                       (const unsigned short*)w, (unsigned short*)out, M, K, N, m_tiles, n_tiles, ep);
     return DFD_CHECK_LAUNCH();
 }
-int dfd_gemm_nt_dma(const void* a, const void* w, void* out, int M, int K, int N, hipStream_t st) {
-    if (K % GD_BK || K < 2 * GD_BK || N % 8 || N < GD_BN || M < 256) return DFD_EUNSUPPORTED;
-    const int n_tiles = (N + GD_BN - 1) / GD_BN;
+static bool gemm_nt_dma_plan(int M, int K, int N, int* wm, int* m_tiles, int* n_tiles) {
+    if (K % GD_BK || K < 2 * GD_BK || N % 8 || N < GD_BN || M < 256) return false;
+    *n_tiles = (N + GD_BN - 1) / GD_BN;
     const int mt256 = (M + 255) / 256, mt128 = (M + 127) / 128;
-    if ((long)mt256 * n_tiles >= 160) return gemm_nt_dma_launch<4>(a, w, out, M, K, N, mt256, n_tiles, st);
-    if (GD_ROWS128 && (long)mt128 * n_tiles >= 160) return gemm_nt_dma_launch<2>(a, w, out, M, K, N, mt128, n_tiles, st);
-    return DFD_EUNSUPPORTED;                             // fewer tiles than CUs: the smaller tiles of k_pw_nt fill the chip better
+    if ((long)mt256 * *n_tiles >= 160) { *wm = 4; *m_tiles = mt256; return true; }
+    if (GD_ROWS128 && (long)mt128 * *n_tiles >= 160) { *wm = 2; *m_tiles = mt128; return true; }
+    return false;                                        // fewer tiles than CUs: the smaller tiles of k_pw_nt fill the chip better
+}
+int dfd_gemm_nt_dma(const void* a, const void* w, void* out, int M, int K, int N, hipStream_t st) {
+    int wm, mt, nt;
+    if (!gemm_nt_dma_plan(M, K, N, &wm, &mt, &nt)) return DFD_EUNSUPPORTED;
+    const GdEpi ep{nullptr, nullptr, nullptr, nullptr, 1};
+    return wm == 4 ? gemm_nt_dma_launch<4, -1>(a, w, out, M, K, N, mt, nt, ep, st) : gemm_nt_dma_launch<2, -1>(a, w, out, M, K, N, mt, nt, ep, st);
+}
+// out = act(scale * (a w^T) + shift) [* row_scale] [+ residual] (+ the raw product in yraw): include/dfd_hip.h, dfd_gemm_bias_act
+extern "C" int dfd_gemm_bias_act(int dtype, const void* a, const void* w_nk, int M, int K, int N, const float* state, int act,
+                              const void* residual, const float* row_scale, int HW, void* yraw, void* out, dfd_stream stream) {
+    if (!a || !w_nk || !out || !state || M < 1 || K < 1 || N < 1 || (row_scale && HW < 1)) return DFD_EINVAL;
+    if (dtype != DFD_BF16 || !(act == DFD_ACT_NONE || act == DFD_ACT_GELU)) return DFD_EUNSUPPORTED;
+    int wm, mt, nt;
+    if (!gemm_nt_dma_plan(M, K, N, &wm, &mt, &nt)) return DFD_EUNSUPPORTED;
+    const GdEpi ep{state, (const unsigned short*)residual, row_scale, (unsigned short*)yraw, row_scale ? HW : 1};
+    hipStream_t st = (hipStream_t)stream;
+    if (act == DFD_ACT_GELU)
+        return wm == 4 ? gemm_nt_dma_launch<4, DFD_ACT_GELU>(a, w_nk, out, M, K, N, mt, nt, ep, st)
+                       : gemm_nt_dma_launch<2, DFD_ACT_GELU>(a, w_nk, out, M, K, N, mt, nt, ep, st);
+    return wm == 4 ? gemm_nt_dma_launch<4, DFD_ACT_NONE>(a, w_nk, out, M, K, N, mt, nt, ep, st)
+                   : gemm_nt_dma_launch<2, DFD_ACT_NONE>(a, w_nk, out, M, K, N, mt, nt, ep, st);
 }

@@ -318,19 +318,30 @@ def mlp_sub_fwd(x, P, ls, row_scale):
     dt = x.dtype
     xn, lnst = K.layernorm_fwd(x, P["ln_w"], P["ln_b"], 1e-5)
     w1_nk, w1_kn = _prep(P["fc1_w"], dt)
-    h, _, _ = K.pwconv(xn, None, w1_nk, None, stats=False)
     hid = P["fc1_w"].shape[0]
     ones, ref = ident(x.device, hid)
-    st1 = _bn_state(None, 0, _rows(h), ref, ones, P["fc1_b"], False)
+    st1 = _bn_state(None, 0, _rows(xn), ref, ones, P["fc1_b"], False)
     w2_nk, w2_kn = _prep(P["fc2_w"], dt)
-    # the activated hidden tensor is materialised once: as a GEMM prologue the GELU is evaluated once per 128-column output
-    # tile by fc2's forward and again by its weight gradient (VALU-bound: 130 us against ~50 for the plain GEMM at level 2)
-    a = K.bn_act_apply(h, st1, ACT_GELU)
-    y2, _, _ = K.pwconv(a, None, w2_nk, None, stats=False)
     C = P["fc2_w"].shape[0]
     ones2, ref2 = ident(x.device, C)
-    st2 = _bn_state(None, 0, _rows(y2), ref2, ones2, P["fc2_b"], False, None, None, ls)
-    out = K.bn_act_apply(y2, st2, ACT_NONE, x, row_scale)
+    st2 = _bn_state(None, 0, _rows(xn), ref2, ones2, P["fc2_b"], False, None, None, ls)
+    # fc1 + bias + GELU and fc2 + bias (+ LayerScale, DropPath row scale, skip connection) are one kernel each where the shape
+    # is dfd_gemm's (the activated hidden tensor `a` and the pre-activation `h` both leave fc1's epilogue: `h` for GELU');
+    # otherwise the activated tensor is materialised by one pass — as a GEMM prologue the GELU was evaluated once per
+    # 128-column output tile by fc2's forward and again by its weight gradient
+    f1 = K.gemm_bias_act(xn, w1_nk, st1, ACT_GELU, None, None, want_raw=True)
+    if f1 is not None:
+        a, h = f1
+    else:
+        h, _, _ = K.pwconv(xn, None, w1_nk, None, stats=False)
+        a = K.bn_act_apply(h, st1, ACT_GELU)
+    f2 = K.gemm_bias_act(a, w2_nk, st2, ACT_NONE, x, row_scale, want_raw=ls is not None)
+    if f2 is not None:
+        out, y2 = f2                                        # y2 None without LayerScale: the backward never reads it (and `out`
+                                                            # must not stand in: a Function must not save its own output)
+    else:
+        y2, _, _ = K.pwconv(a, None, w2_nk, None, stats=False)
+        out = K.bn_act_apply(y2, st2, ACT_NONE, x, row_scale)
     return out, (x, xn, lnst, h, a, st1, y2, st2, w1_kn, w2_kn)
 
 

@@ -353,6 +353,31 @@ def bn_bwd_reduce(g: torch.Tensor, y: torch.Tensor, state: torch.Tensor, row_sca
     return parts, n.value
 
 
+_UNSUPPORTED = -2
+
+
+def gemm_bias_act(x: torch.Tensor, w_nk, state: torch.Tensor, act: int, residual: torch.Tensor | None = None,
+                  row_scale: torch.Tensor | None = None, want_raw: bool = False):
+    """Linear layer without statistics in one kernel: act(scale * (x w^T) + shift) [* row_scale] [+ residual] -> (out, raw y or
+    None), bit-identical to pwconv + bn_act_apply; None when the shape is not the fused kernel's (the caller runs the pair)."""
+    if x.dtype != torch.bfloat16 or isinstance(w_nk, MxWeight) or not _FUSE_LINEAR:
+        return None
+    _chk_nhwc(x)
+    N_, H, W, Kd = x.shape
+    M, Nout = N_ * H * W, w_nk.shape[0]
+    out = torch.empty((N_, H, W, Nout), dtype=x.dtype, device=x.device)
+    raw = torch.empty_like(out) if want_raw else None
+    rc = _L().dfd_gemm_bias_act(_dt(x), _p(x), _p(w_nk), M, Kd, Nout, _p(state), act, _p(residual), _p(row_scale), H * W,
+                                _p(raw), _p(out), _stream())
+    if rc == _UNSUPPORTED:
+        return None
+    check(rc, "dfd_gemm_bias_act", f"{tuple(x.shape)} -> {Nout}")
+    return out, raw
+
+
+_FUSE_LINEAR = os.environ.get("DFD_FUSE_LINEAR", "1") != "0"      # A/B switch
+
+
 def bias_grad(g: torch.Tensor, row_scale: torch.Tensor | None = None, out: torch.Tensor | None = None) -> torch.Tensor:
     """Sum of g [N,H,W,C] over its rows (times row_scale[n]) -> f32 [C]: the bias gradient of a Linear layer.  Inside
     sum_batch() the final summation is deferred to the block's batch like a weight gradient's (valid after the block)."""

@@ -73,7 +73,7 @@ typedef void* dfd_stream;          /* a hipStream_t */
  * dfd_se_fwd_parts;
  * 120 = MX fp8 weights (dfd_mx_*), fused window attention on bf16 MFMA (dfd_wattn_*),
  * batched coordinate MLPs (dfd_coord_mlp_*_multi, dfd_relpos_bias_*_multi), dfd_dwconv_bwd_fused, dfd_resize_crop_u8;
- * 121 = dfd_bias_grad / dfd_bias_grad_ws. */
+ * 121 = dfd_bias_grad / dfd_bias_grad_ws; 122 = dfd_gemm_bias_act. */
 int dfd_version(void);
 
 /* Batched final summation of weight gradients.  The weight-gradient entry points whose result goes straight to the
@@ -142,6 +142,13 @@ int dfd_bn_act_apply(int dtype, const void* y, const float* bnstate, int act,
 int dfd_bn_bwd_reduce(int dtype, const void* g, const void* y, const float* bnstate,
                       const float* row_scale, int N, int HW, int C,
                       float* partials, int pcap, int* nparts, dfd_stream stream);
+/* Linear layer without statistics in ONE kernel (bf16, many rows, K % 64 == 0: csrc/dfd_gemm.hip; else DFD_EUNSUPPORTED and the
+ * caller runs dfd_pwconv_fwd + dfd_bn_act_apply):  out = act(scale[n] * y + shift[n]) [* row_scale[row / HW]] [+ residual] with
+ * y = bf16(a w^T) — the same arithmetic on the same rounded y as the two-kernel form, identical bits.  state: float[>=2][N]
+ * (dfd_bn_eval_coeffs*: scale, shift = LayerScale and bias folded); act: DFD_ACT_NONE / DFD_ACT_GELU; yraw (optional, [M][N])
+ * also receives y itself.  ABI 122.                                                                                          */
+int dfd_gemm_bias_act(int dtype, const void* a, const void* w_nk, int M, int K, int N, const float* state, int act,
+                      const void* residual, const float* row_scale, int HW, void* yraw, void* out, dfd_stream stream);
 /* dbias[c] (+)= sum over rows of g[row][c] (* row_scale[n]): the bias gradient of a Linear layer (no statistics).  ws:
  * dfd_bias_grad_ws bytes; its final fixed-order summation joins an open dfd_sum_batch like a weight gradient's.  ABI 121 */
 size_t dfd_bias_grad_ws(int N, int HW, int C);

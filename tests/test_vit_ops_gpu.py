@@ -676,3 +676,30 @@ def test_plain_bf16_product_on_256_tiles_with_lds_dma(shape):
     rows = torch.tensor([0, 1, 255, 256, M // 2, M - 2, M - 1], device="cuda")
     assert torch.equal(out.view(M, N)[rows], want[rows].to(torch.bfloat16)) or float(
         (out.view(M, N)[rows].float() - want[rows]).abs().max()) <= 2.0 ** -8 * float(want.abs().max())
+
+
+@pytest.mark.parametrize("case", [(256 * 170, 256, 256, R.ACT_GELU, False, False, True), (256 * 80 + 17, 192, 520, R.ACT_NONE, True, True, False),
+                                  (49 * 256, 512, 512, R.ACT_NONE, True, True, True), (256 * 170, 128, 768, R.ACT_NONE, False, False, False)])
+def test_linear_with_fused_bias_activation_residual_epilogue_is_bitwise_the_two_kernel_form(case):
+    """dfd_gemm_bias_act: act(scale * y + shift) [* row_scale] [+ residual] in the product's store loop, on the bf16-rounded y —
+    identical bits to dfd_pwconv_fwd followed by dfd_bn_act_apply, and the optional raw y equals the plain product."""
+    K = _k()
+    M, Kd, N, act, with_res, with_rs, want_raw = case
+    T = 53 if M % 53 == 0 else (49 if M % 49 == 0 else 1)
+    n = M // T
+    g = torch.Generator().manual_seed(M + N + act)
+    x = torch.randn((n, T, 1, Kd), generator=g).to(torch.bfloat16).cuda()
+    w = (torch.randn((N, Kd), generator=g) * Kd ** -0.5).cuda()
+    w_nk, _ = K.prep_weights(w, torch.bfloat16, True, False)
+    st = rand_state(N, 91).cuda()
+    res = torch.randn((n, T, 1, N), generator=g).to(torch.bfloat16).cuda() if with_res else None
+    rs = (0.5 + torch.rand(n, generator=g)).cuda() if with_rs else None
+    fused = K.gemm_bias_act(x, w_nk, st, act, res, rs, want_raw=want_raw)
+    assert fused is not None, "shape expected to be served by the fused kernel"
+    out, raw = fused
+    y, _, _ = K.pwconv(x, None, w_nk, None, stats=False)
+    want = K.bn_act_apply(y, st, act, res, rs)
+    assert torch.equal(out, want), float((out.float() - want.float()).abs().max())
+    assert (raw is None) == (not want_raw)
+    if raw is not None:
+        assert torch.equal(raw, y)
