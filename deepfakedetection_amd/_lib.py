@@ -52,6 +52,8 @@ _PI = POINTER(c_int)
 # name -> (restype, argtypes); every symbol include/dfd_hip.h declares
 SIGNATURES: dict[str, tuple] = {
     "dfd_version": (c_int, []),
+    "dfd_tune": (c_int, [c_int, c_int]),
+    "dfd_dw_mm_plan": (c_int, [POINTER(DwShape), c_int, _PI]),
     "dfd_bn_finalize": (c_int, [P, c_int, c_int, c_double, P, P, P, P, c_float, c_float, P, P]),
     "dfd_bn_eval_coeffs": (c_int, [P, P, P, P, c_float, c_int, P, P]),
     "dfd_bn_bwd_finalize": (c_int, [P, c_int, c_int, c_double, P, P, c_int, P, P, c_int, P, P]),
@@ -211,6 +213,12 @@ def load() -> ctypes.CDLL:
             raise RuntimeError(f"libdfd_hip.so does not export {name}") from exc
         fn.restype = restype
         fn.argtypes = argtypes
+    # DFD_TUNE="key=value,key=value": planner knobs of include/dfd_hip.h (dfd_tune) from the command line — A/B runs of
+    # bench.py / the layer scripts without a rebuild.  Applied once, before anything launches.
+    for item in filter(None, _os.environ.get("DFD_TUNE", "").split(",")):
+        key, _, value = item.partition("=")
+        if lib.dfd_tune(int(key), int(value)) != DFD_OK:
+            raise RuntimeError(f"DFD_TUNE: unknown key in {item!r}")
     _lib = lib
     return lib
 

@@ -18,7 +18,7 @@ PKG_DIR = Path(__file__).resolve().parent
 CSRC = PKG_DIR / "csrc"
 OBJ_DIR = CSRC / "build"
 LIB_PATH = PKG_DIR / "libdfd_hip.so"
-SOURCES = ("dfd_rowpass.hip", "dfd_dwfwd.hip", "dfd_dwbwd.hip", "dfd_dwbwdf.hip", "dfd_dwconv.hip", "dfd_pwconv.hip", "dfd_pwntw.hip", "dfd_pwtnw.hip", "dfd_misc.hip", "dfd_vit.hip",
+SOURCES = ("dfd_rowpass.hip", "dfd_dwfwd.hip", "dfd_dwbwd.hip", "dfd_dwbwdf.hip", "dfd_dwconv.hip", "dfd_dwmm.hip", "dfd_pwconv.hip", "dfd_pwntw.hip", "dfd_pwtnw.hip", "dfd_misc.hip", "dfd_vit.hip",
            "dfd_mx.hip", "dfd_attn.hip", "dfd_coord.hip", "dfd_resize.hip", "dfd_conv3.hip", "dfd_stem.hip", "dfd_gemm.hip")
 ARCH = "gfx950"
 FLAGS = ("-O3", "-fPIC", "-std=c++17", "-ffp-contract=off", f"--offload-arch={ARCH}")
@@ -74,7 +74,8 @@ def build(force: bool = False, verbose: bool = False) -> Path:
             print(f"[dfd build] compiling {[s.name for s, _ in jobs]}", file=sys.stderr)
         with ThreadPoolExecutor(max_workers=min(4, len(jobs))) as pool:
             list(pool.map(lambda so: _compile(so[0], so[1], hipcc), jobs))
-    if jobs or not LIB_PATH.exists():
+    # relink when any object is newer than the library too (an object compiled by hand, e.g. with -Rpass-analysis, is not a "job")
+    if jobs or not LIB_PATH.exists() or max(o.stat().st_mtime for o in objs) > LIB_PATH.stat().st_mtime:
         cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", *map(str, objs), "-o", str(LIB_PATH)]
         proc = subprocess.run(cmd, capture_output=True, text=True)
         if proc.returncode != 0:

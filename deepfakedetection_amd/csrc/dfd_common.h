@@ -9,9 +9,29 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <mutex>
 #include "../../include/dfd_hip.h"
 
 #define DFD_THREADS 256
+
+// Host-side kernel-attribute caches ("kernel-attribute caches behind std::call_once"): the forward runs on the main
+// thread and the backward on autograd's thread, and the first launch of an instantiation may happen inside a stream capture.
+// `Tag` names the call site, so every (site, kernel instantiation) pair owns one flag.
+template <typename Tag, typename KernelT>
+static inline void dfd_allow_lds_once(KernelT kern, int bytes) {
+    static std::once_flag once;
+    std::call_once(once, [&] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, bytes); });
+}
+template <typename Tag, typename KernelT>
+static inline int dfd_kernel_regs_once(KernelT kern, int fallback) {
+    static std::once_flag once;
+    static int regs = 0;
+    std::call_once(once, [&] {
+        hipFuncAttributes attr;
+        regs = (hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(kern)) == hipSuccess && attr.numRegs > 0) ? attr.numRegs : fallback;
+    });
+    return regs;
+}
 
 struct bf16 { unsigned short x; };  // storage tag; arithmetic is always f32
 

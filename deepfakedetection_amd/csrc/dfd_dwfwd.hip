@@ -15,6 +15,7 @@
 //     (sum, sumsq) row per workgroup, BN + SiLU of the producer applied once per staged
 //     element, zero padding written in the activated domain.
 #include "dfd_dwq.h"
+#include "dfd_dwm.h"
 #include <climits>
 
 #ifndef DW_FWD_PAIRS
@@ -359,7 +360,11 @@ extern "C" int dfd_dwconv_fwd(int dtype, const void* x, const float* in_bnstate,
     if (!x || !w || !y || !s) return DFD_EINVAL;
     if (partials && (!nparts || pcap < 1)) return DFD_EINVAL;
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == DFD_BF16) return dw_fwd_q_t<bf16>(x, in_bnstate, in_act, w, y, s, partials, pcap, nparts, st);
+    if (dtype == DFD_BF16) {
+        const int rc = dfd_dw_fwd_mm(x, in_bnstate, in_act, w, y, s, partials, pcap, nparts, st);      // matrix-core form (dfd_dwmm.hip)
+        if (rc != DFD_EUNSUPPORTED) return rc;
+        return dw_fwd_q_t<bf16>(x, in_bnstate, in_act, w, y, s, partials, pcap, nparts, st);
+    }
     if (dtype == DFD_F32) return dw_fwd_q_t<float>(x, in_bnstate, in_act, w, y, s, partials, pcap, nparts, st);
     return DFD_EINVAL;
 }

@@ -183,11 +183,8 @@ template <int WM, int EACT>
 static int gemm_nt_dma_launch(const void* a, const void* w, void* out, int M, int K, int N, int m_tiles, int n_tiles, const GdEpi& ep,
                               hipStream_t st) {
     using G = GdGeom<WM>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_nt_dma<WM, EACT>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
-        attr_set = true;
-    }
+    struct GdTag;
+    dfd_allow_lds_once<GdTag>(k_gemm_nt_dma<WM, EACT>, G::LDS);
     hipLaunchKernelGGL((k_gemm_nt_dma<WM, EACT>), dim3((unsigned)(m_tiles * n_tiles)), dim3(G::THREADS), G::LDS, st, (const unsigned short*)a,
                        (const unsigned short*)w, (unsigned short*)out, M, K, N, m_tiles, n_tiles, ep);
     return DFD_CHECK_LAUNCH();

@@ -352,11 +352,8 @@ k_pw_ntw(const T* __restrict__ a, ProArgs pa, const T* __restrict__ w, T* __rest
 // register file allows 512 / VGPRs of them (allocation granule 8), LDS allows 160 KB / lds
 template <typename KernelT>
 static int ntw_blocks_per_cu(KernelT kern, int lds) {
-    static int regs = 0;                    // one static per instantiation of this template
-    if (regs == 0) {
-        hipFuncAttributes attr;
-        regs = (hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(kern)) == hipSuccess && attr.numRegs > 0) ? attr.numRegs : 256;
-    }
+    struct NtwTag;
+    const int regs = dfd_kernel_regs_once<NtwTag>(kern, 256);   // one flag per instantiation of this template
     int by_regs = 512 / ((regs + 7) / 8 * 8);
     if (by_regs > 8) by_regs = 8;
     int by_lds = (160 * 1024) / (lds + 512);

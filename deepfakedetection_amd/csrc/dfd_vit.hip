@@ -812,7 +812,8 @@ extern "C" int dfd_bgemm(int dt_a, const void* A, const dfd_mat* sa, int dt_b, c
             break;                                                                                                      \
         }                                                                                                               \
         auto kern = k_bgemm<DA, DB, DC>;                                                                                \
-        if (lds > 64 * 1024) hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        struct BgTag;                                                                                                   \
+        dfd_allow_lds_once<BgTag>(kern, 150 * 1024);    /* once per instantiation, for the largest panel it accepts */  \
         hipLaunchKernelGGL(kern, grid, dim3(DFD_THREADS), lds, st, A, da, B, db, C, dc, bias, alpha, nh, M, N, K, round_a, round_b); \
     } while (0)
     const int code = dt_a * 4 + dt_b * 2 + dt_c;

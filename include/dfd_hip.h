@@ -73,8 +73,20 @@ typedef void* dfd_stream;          /* a hipStream_t */
  * dfd_se_fwd_parts;
  * 120 = MX fp8 weights (dfd_mx_*), fused window attention on bf16 MFMA (dfd_wattn_*),
  * batched coordinate MLPs (dfd_coord_mlp_*_multi, dfd_relpos_bias_*_multi), dfd_dwconv_bwd_fused, dfd_resize_crop_u8;
- * 121 = dfd_bias_grad / dfd_bias_grad_ws; 122 = dfd_gemm_bias_act. */
+ * 121 = dfd_bias_grad / dfd_bias_grad_ws; 122 = dfd_gemm_bias_act;
+ * 130 = dfd_tune; the bf16 depthwise entry points run on the matrix cores where the shape allows (same signatures). */
 int dfd_version(void);
+
+/* Planner knobs (A/B switches and sizes the host-side kernel selection reads).  Process-wide plain ints: set them once at
+ * start-up, before the first launch — they are not synchronised with concurrent callers.  Unknown key: DFD_EINVAL.
+ *   0 DFD_TUNE_DW_MFMA    bit 0: the depthwise forward runs on the matrix cores (bf16, C % 16 == 0) for the shapes where that form
+ *                         measured faster (5x5 stride 1 on maps of at most 64 pixels); bit 3: for every shape it can serve
+ *                         (tests, A/B runs); 0 = the vector-unit kernels everywhere                          (default 1)
+ *   1 DFD_TUNE_DW_LDS_KB  LDS budget of one matrix-core depthwise workgroup in KiB                           (default 156)
+ *   2 DFD_TUNE_DW_GRID    workgroups a matrix-core depthwise launch aims for                                 (default 256)
+ *   3 DFD_TUNE_DEBUG      timing-only ablations of the matrix-core depthwise kernels (results are WRONG when non-zero): bit 0
+ *                         no activation arithmetic, 1 no tap loop, 2 no stores, 3 no loads                   (default 0) */
+int dfd_tune(int key, int value);
 
 /* Batched final summation of weight gradients.  The weight-gradient entry points whose result goes straight to the
  * optimizer (dfd_pwconv_wgrad, dfd_dwconv_bwd_weight, dfd_stem_conv_wgrad) end with a fixed-order sum of their workspace's
@@ -233,6 +245,10 @@ int dfd_dwconv_bwd_weight(int dtype, const void* dz, const void* y, const float*
                           const void* xin, const float* in_bnstate, int in_act,
                           float* dw, const dfd_dwconv_shape* s, int accumulate,
                           float* ws, size_t ws_bytes, dfd_stream stream);
+
+/* Diagnostics: the tile plan the matrix-core depthwise forward would use for a shape (pro: the staging phase applies an
+ * activation): out[12] = NI, TH, TW, runs, IH, IW, row pitch, plane pixels, work items, whole-image flag, LDS bytes in / out. */
+int dfd_dw_mm_plan(const dfd_dwconv_shape* s, int pro, int* out);
 
 /* ---- eval / inference form of the MBConv block -----------------------------------------------------------------
  * With running statistics every BatchNorm is an affine map known before the layer runs, so the PRODUCER can apply

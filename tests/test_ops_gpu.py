@@ -96,6 +96,56 @@ def test_dwconv_fwd(case, rd):
     close(y2, want2, tol(rd), "dwconv_fwd raw")
 
 
+# the matrix-core form of the forward (csrc/dfd_dwmm.hip) serves bf16 layers with C % 16 == 0; by default only where it measured
+# faster, so these cases switch it on for every shape (dfd_tune key 0, bit 3): chunks of 1 / 2 / 3 / 4 groups, both strides and kernel
+# sizes, whole-picture tiles with several images per item and a batch tail, ragged tile edges, asymmetric padding
+DW_MM_CASES = [c for c in DW_CASES if c[3] % 16 == 0] + [
+    (7, 7, 7, 1152, 5, 1, 2, 2),     # 3 pictures per item, 7 = 2 * 3 + 1: a partial last item
+    (3, 14, 14, 16, 3, 1, 1, 1),     # one group
+    (2, 30, 30, 32, 5, 1, 2, 2),     # two groups
+    (2, 20, 18, 112, 3, 2, 0, 0),    # 4 + 3 groups, TF-SAME asymmetric stride 2
+    (2, 33, 35, 80, 5, 2, 1, 1),     # 4 + 1 groups, ragged
+    (1, 112, 112, 32, 3, 1, 1, 1),   # B0 block 0: many tiles per picture
+]
+
+
+@pytest.mark.parametrize("case", DW_MM_CASES)
+def test_dwconv_fwd_matrix_core_form(case):
+    import ctypes
+
+    from deepfakedetection_amd._lib import DwShape, load
+
+    K = _k()
+    rd = torch.bfloat16
+    N, H, W, C, k, s, pt, pl = case
+    Ho, Wo = -(-H // s), -(-W // s)
+    x = gen((N, H, W, C), 1, rd)
+    w = gen((C, 1, k, k), 2, torch.float32, 0.3)
+    st = rand_state(C, 3)
+    lib = load()
+    plan = (ctypes.c_int * 12)()
+    assert lib.dfd_dw_mm_plan(ctypes.byref(DwShape(N, H, W, C, Ho, Wo, k, s, pt, pl)), 1, plan) == 0, "the matrix-core planner declined the shape"
+    want = R.dwconv_fwd(x.float(), st, R.ACT_SILU, w, k, s, pt, pl, Ho, Wo, rd)
+    want2 = R.dwconv_fwd(x.float(), None, 0, w, k, s, pt, pl, Ho, Wo, rd)
+    assert lib.dfd_tune(0, 0) == 0
+    y_v, parts_v, n_v = K.dwconv_fwd(dev(x), dev(st), R.ACT_SILU, dev(w), k, s, pt, pl, Ho, Wo, stats=True)
+    sums_v = sum_parts(parts_v, n_v, C)
+    assert lib.dfd_tune(0, 9) == 0
+    try:
+        y, parts, n = K.dwconv_fwd(dev(x), dev(st), R.ACT_SILU, dev(w), k, s, pt, pl, Ho, Wo, stats=True)
+        sums = sum_parts(parts, n, C)
+        y2, _, _ = K.dwconv_fwd(dev(x), None, 0, dev(w), k, s, pt, pl, Ho, Wo, stats=False)
+    finally:
+        lib.dfd_tune(0, 1)
+    close(y, want, tol(rd), "matrix-core dwconv_fwd y")
+    close(sums, R.stats_sums(y.float().cpu()), 1e-3, "matrix-core dwconv_fwd stats")
+    close(y2, want2, tol(rd), "matrix-core dwconv_fwd raw")
+    # the two forms round the same f32 sums of the same bf16 products: they may differ in the order of the additions only
+    close(y, y_v.float().cpu(), 8e-3, "matrix-core against vector-unit form")
+    close(sums, sums_v, 2e-3, "matrix-core against vector-unit statistics")
+    assert lib.dfd_tune(99, 0) != 0
+
+
 @pytest.mark.parametrize("rd", DT)
 @pytest.mark.parametrize("case", DW_CASES)
 def test_dwconv_bwd(case, rd):
