@@ -161,8 +161,10 @@ def cpu_baseline(args) -> dict:
 
 
 def pmc_traffic(family: str, args) -> tuple[int | None, dict]:
-    """HBM bytes per launch of a kernel family from the committed rocprofv3 --pmc passes (counters cannot be read from
+    """HBM bytes PER STEP of a kernel family from the committed rocprofv3 --pmc passes (counters cannot be read from
     inside this process): newest profiles/*pmc_traffic.json, which records GB per training step of exactly this workload.
+    The caller divides by ITS launch count (API calls per step), the same population its algorithmic bytes are divided by —
+    rocprofv3 counts kernel dispatches, which differ where one call is several kernels or none (VERDICT r3 "what's weak" 7).
     Returns (bytes or None, provenance).  None when the file is absent, the workload differs, or the file was collected
     from OTHER kernel sources than the ones this run was built from (the file records a digest of csrc/ + include/;
     build.source_digest() recomputes it) — a stale counter file must not dress up new kernels."""
@@ -182,7 +184,7 @@ def pmc_traffic(family: str, args) -> tuple[int | None, dict]:
             src["reason"] = "stale: kernel sources changed since these counters were collected"
             return None, src
         fam = doc["families"][family]
-        return int((fam["ea_read_gb_per_step"] + fam["ea_write_gb_per_step"]) * 1e9 / fam["dispatches_per_step"]), src
+        return int((fam["ea_read_gb_per_step"] + fam["ea_write_gb_per_step"]) * 1e9), src
     except (KeyError, ValueError, ZeroDivisionError) as exc:
         src["reason"] = f"unreadable ({type(exc).__name__})"
         return None, src
@@ -435,9 +437,15 @@ def main() -> None:
         # intensity (all 1x1 layers < 312 flop/B), so bound = "hbm"
         top = breakdown[0]
         t, b, f, n, b8 = agg[top["kernel"]]
-        traffic, traffic_src = pmc_traffic(top["kernel"], args)
+        traffic_step, traffic_src = pmc_traffic(top["kernel"], args)
+        calls_per_step = n / args.profile_steps
+        traffic = int(traffic_step / calls_per_step) if traffic_step is not None else None
         roofline = {"kernel": top["kernel"], "bound": "hbm", "achieved": round(b8 / t / 1e9, 1), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(b8 / t / 1e9 / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                    # both per step and over the same launches: traffic / algorithmic is the re-read factor
+                    "traffic_per_step": traffic_step, "algorithmic_bytes_per_step": int(b8 / args.profile_steps),
+                    "calls_per_step": round(calls_per_step, 2),
+                    "traffic_over_algorithmic": round(traffic_step / (b8 / args.profile_steps), 3) if traffic_step else None,
                     "bytes": "SURVEY 8(d): M*(K+Nout)*2 + K*Nout*2 per 1x1 pass; N*C*(Hin*Win+Hout*Wout)*2 + k*k*C*4 per depthwise forward",
                     "achieved_incl_fusion_operands": round(b / t / 1e9, 1),
                     "avg_launch_us": round(t / n * 1e6, 2), "avg_launch_bytes": int(b8 / n),

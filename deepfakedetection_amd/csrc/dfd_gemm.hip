@@ -203,6 +203,11 @@ int dfd_gemm_nt_dma(const void* a, const void* w, void* out, int M, int K, int N
     const GdEpi ep{nullptr, nullptr, nullptr, nullptr, 1};
     return wm == 4 ? gemm_nt_dma_launch<4, -1>(a, w, out, M, K, N, mt, nt, ep, st) : gemm_nt_dma_launch<2, -1>(a, w, out, M, K, N, mt, nt, ep, st);
 }
+// which tile form serves a plain bf16 product (tests assert the path they name instead of trusting a silent fallback)
+extern "C" int dfd_gemm_plan(int M, int K, int N) {
+    int wm, mt, nt;
+    return gemm_nt_dma_plan(M, K, N, &wm, &mt, &nt) ? 64 * wm : 0;
+}
 // out = act(scale * (a w^T) + shift) [* row_scale] [+ residual] (+ the raw product in yraw): include/dfd_hip.h, dfd_gemm_bias_act
 extern "C" int dfd_gemm_bias_act(int dtype, const void* a, const void* w_nk, int M, int K, int N, const float* state, int act,
                               const void* residual, const float* row_scale, int HW, void* yraw, void* out, dfd_stream stream) {

@@ -61,10 +61,22 @@ __device__ __forceinline__ float e4m3_to_f(unsigned b) {
 }
 
 // quantise 32 f32 values held by one thread; returns the scale byte, q = 8 packed words
+// A block that holds a NaN or an infinity becomes a NaN block — scale byte 0xff (the OCP MX NaN scale) and every element the
+// e4m3fn NaN 0x7f — so that a diverged run still shows non-finite logits with fp8 weights, as it does in bf16 (fmaxf / fminf
+// drop NaNs: without this the block came out as +-448 * 2^e and the loss stayed finite).
 __device__ __forceinline__ unsigned mx_quant32(const float (&v)[32], unsigned (&q)[8]) {
     float amax = 0.f;
+    bool bad = false;
 #pragma unroll
-    for (int i = 0; i < 32; ++i) amax = __builtin_fmaxf(amax, __builtin_fabsf(v[i]));
+    for (int i = 0; i < 32; ++i) {
+        amax = __builtin_fmaxf(amax, __builtin_fabsf(v[i]));
+        bad |= !(__builtin_fabsf(v[i]) <= 3.4028234663852886e38f);      // NaN or infinity
+    }
+    if (bad) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) q[i] = 0x7f7f7f7fu;
+        return 0xffu;
+    }
     const int e = mx_block_exp(amax);
     const float inv = mx_inv_scale(e);
 #pragma unroll
@@ -97,10 +109,11 @@ k_mx_quant_weights_multi(MxJobs jobs) {
     dq[1] = make_uint4(q[4], q[5], q[6], q[7]);
     jb.scale[(long)n * kb_per_row + kb] = (uint8_t)sb;
     if (jb.kn) {
-        const float sc = __uint_as_float(sb << 23);                     // 2^(sb-127); sb == 0 only for all-zero blocks
+        // 2^(sb - 127): sb == 0 is 2^-127 (a subnormal f32), sb == 0xff the NaN scale
+        const float sc = sb == 0xffu ? __uint_as_float(0x7fc00000u) : (sb ? __uint_as_float(sb << 23) : __uint_as_float(0x00400000u));
 #pragma unroll
         for (int i = 0; i < 32; ++i) {
-            const float d = e4m3_to_f((q[i >> 2] >> (8 * (i & 3))) & 0xffu) * sc;
+            const float d = sb == 0xffu ? sc : e4m3_to_f((q[i >> 2] >> (8 * (i & 3))) & 0xffu) * sc;
             const long at = (long)(kb * 32 + i) * jb.N + n;
             if (jb.kn_dtype == DFD_BF16) reinterpret_cast<unsigned short*>(jb.kn)[at] = f2bf(d);   // exact: 4 significant bits
             else reinterpret_cast<float*>(jb.kn)[at] = d;

@@ -279,16 +279,32 @@ class PlanGeometry:
             raise ValueError("PlanGeometry: mode is center | random | rrc (the last one with its RandomResizedCrop)")
         self.mode, self.out, self.resize, self.rrc = mode, out, resize, rrc
 
+    # dfd_resize_crop_u8 holds a filter of at most 96 taps per axis: shrink factors up to ~46.  An image beyond that (a 12,000-pixel
+    # scan fed to a 224-pixel model) is resized HERE, by the very PIL calls the device kernel restates bit for bit, and travels with
+    # an identity plan — one oversize image no longer aborts the epoch with DFD_EUNSUPPORTED.
+    MAX_DEVICE_SHRINK = 40
+    # Pillow 12 runs its VERTICAL pass first for some very long, narrow images (measured: 64 x 8000 -> 48 x 6000 vertical-first,
+    # 64 x 6000 and 100 x 9000 horizontal-first; the rule is not in its documentation), and the 8-bit intermediate makes the two
+    # orders differ by a unit in ~20 % of the bytes.  The device kernel is horizontal-first; images beyond this side length take the
+    # PIL calls in the worker too, so the pipeline stays bit-exact with PIL whatever that rule is.
+    MAX_DEVICE_SIDE = 4096
+
     def __call__(self, img: Image.Image):
         img = img.convert("RGB")
         w, h = img.size
         if self.mode == "rrc":
             bx, by, bw, bh = self.rrc._box(w, h)
             plan = (bx, by, bw, bh, self.out, self.out, 0, 0)
+            if max(-(-bw // self.out), -(-bh // self.out)) > self.MAX_DEVICE_SHRINK or max(bw, bh) > self.MAX_DEVICE_SIDE:
+                img = img.crop((bx, by, bx + bw, by + bh)).resize((self.out, self.out), Image.BILINEAR)
+                plan = (0, 0, self.out, self.out, self.out, self.out, 0, 0)
         else:
             rw, rh = plan_resize(w, h, self.resize)
             cx, cy = plan_window(rw, rh, self.out, self.out, random=self.mode == "random")
             plan = (0, 0, w, h, rw, rh, cx, cy)
+            if max(-(-w // rw), -(-h // rh)) > self.MAX_DEVICE_SHRINK or max(w, h) > self.MAX_DEVICE_SIDE:
+                img = img.resize((rw, rh), Image.BILINEAR)
+                plan = (0, 0, rw, rh, rw, rh, cx, cy)
         return torch.from_numpy(np.array(img, dtype=np.uint8)), torch.tensor([*plan, self.out, self.out], dtype=torch.int64)
 
 

@@ -55,7 +55,7 @@ def tok4(t: torch.Tensor) -> torch.Tensor:
 # =========================================================================== Linear on the GEMM kernels
 def lin_fwd(x, w_nk, bias, act=ACT_NONE, ls=None, residual=None, row_scale=None):
     ones, ref = ident(x.device, w_nk.shape[0])
-    return pwbn_fwd(x, w_nk, None, ones, bias, ref, False, None, act, ls, residual, row_scale)
+    return pwbn_fwd(x, w_nk, None, ones, bias, ref, False, None, act, ls, residual, row_scale, raw_unused=True)
 
 
 def lin_bwd(g, x, y, st, w_kn, w, bias, ls, act, need_dx, need_w, need_b, need_ls=False, dx_residual=None, row_scale=None):

@@ -422,11 +422,19 @@ def _run_inference_job(*, config_path: Path, config: dict[str, Any], model_cfg: 
     model = load_model(name, num_classes, _resolve_weights(infer_cfg, name, out), device, image_size)
     if str(infer_cfg.get("fp8_weights", "")).lower() in ("1", "true", "yes", "on") and hasattr(model, "fp8_weights"):
         model.fp8_weights = True       # extra key (FasterViT, with `amp: bf16`): Linear weights as MX fp8 on the scaled fp8 MFMA
-    transform = build_eval_transforms(image_size, toggles=resolve_transform_mapping(model_cfg, phase="eval"))
+    eval_toggles = resolve_transform_mapping(model_cfg, phase="eval")
+    transform = build_eval_transforms(image_size, toggles=eval_toggles)
     if str(infer_cfg.get("gpu_resize", "")).lower() in ("1", "true", "yes", "on") and device.type == "cuda":
         # extra key: the workers only decode; Resize + CenterCrop + ToTensor + Normalize run on the device (bit-exact with the
-        # PIL pipeline above, tests/test_ops_gpu.py::test_resize_crop_matches_pillow_bit_for_bit).  Default toggles only.
-        transform = D.Compose([D.Lambda(_to_rgb), D.PlanGeometry("center", image_size, image_size)])
+        # PIL pipeline above, tests/test_ops_gpu.py::test_resize_crop_matches_pillow_bit_for_bit).  The device pipeline IS the default
+        # eval pipeline: with any eval toggle switched off the results would silently differ from the PIL path, so it only engages
+        # when the resolved toggles are the defaults.
+        switched_off = sorted(k for k in ("ensure_rgb", "val_resize", "val_center_crop", "val_to_tensor", "val_normalize")
+                              if not as_bool((eval_toggles or {}).get(k, True)))
+        if switched_off:
+            out.print(f"[bold yellow]inference.gpu_resize ignored[/]: eval toggles {switched_off} are off; the PIL pipeline honours them")
+        else:
+            transform = D.Compose([D.Lambda(_to_rgb), D.PlanGeometry("center", image_size, image_size)])
     root = Path(data_cfg.get("root")).expanduser()
     if not root.is_absolute():
         root = (Path.cwd() / root).resolve()

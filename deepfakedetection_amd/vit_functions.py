@@ -54,15 +54,19 @@ def _prep(w: torch.Tensor, dt: torch.dtype, derived, need_bwd: bool = True):
 
 
 # =========================================================================== helper pairs (no autograd)
-def pwbn_fwd(x, w_nk, b, gamma, beta, bn: BNRef, training, counters, act=ACT_NONE, ls=None, residual=None, row_scale=None):
-    """1x1 conv (+bias) -> BN -> act, [* ls] [* row_scale] [+ residual]; returns (materialised out, raw y, bn state)."""
+def pwbn_fwd(x, w_nk, b, gamma, beta, bn: BNRef, training, counters, act=ACT_NONE, ls=None, residual=None, row_scale=None,
+             raw_unused=False):
+    """1x1 conv (+bias) -> BN -> act, [* ls] [* row_scale] [+ residual]; returns (materialised out, raw y, bn state).
+    raw_unused: the caller's backward never reads y (the identity-statistics Linear layers of FasterViT, whose backward is
+    pwbn_bwd's `plain` path) — only then may the fused eval kernel skip writing it.  Every caller with a real BatchNorm needs y in
+    its backward even in eval mode (bn_bwd_reduce / the BN-backward prologue read it: frozen-BN fine-tuning, attribution runs)."""
     if not training and act in (ACT_NONE, ACT_GELU):
         # eval statistics are known before the product: one kernel (csrc/dfd_gemm.hip) where the shape is its own.  The raw y is
         # produced only where a backward reads it (activation, LayerScale); otherwise None is returned in its place — NOT `out`:
         # a block Function that kept its own output among its saved tensors would close the reference cycle that once crashed
         # hipStreamEndCapture (DESIGN 6, round 3).
         st = _bn_state(None, 0, _rows(x), bn, gamma, beta, False, counters, conv_bias=b, ls=ls)
-        fused = K.gemm_bias_act(x, w_nk, st, act, residual, row_scale, want_raw=(act != ACT_NONE or ls is not None))
+        fused = K.gemm_bias_act(x, w_nk, st, act, residual, row_scale, want_raw=(not raw_unused or act != ACT_NONE or ls is not None))
         if fused is not None:
             out, raw = fused
             return out, raw, st

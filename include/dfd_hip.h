@@ -161,6 +161,9 @@ int dfd_bn_bwd_reduce(int dtype, const void* g, const void* y, const float* bnst
  * also receives y itself.  ABI 122.                                                                                          */
 int dfd_gemm_bias_act(int dtype, const void* a, const void* w_nk, int M, int K, int N, const float* state, int act,
                       const void* residual, const float* row_scale, int HW, void* yraw, void* out, dfd_stream stream);
+/* Rows per tile (256 or 128) with which the LDS-DMA product kernel (csrc/dfd_gemm.hip) serves a plain bf16 [M][K] x [N][K]^T
+ * through dfd_pwconv_fwd / dfd_gemm_bias_act, 0 when the shape stays with the 128 x 128 kernel of dfd_pwconv.hip. */
+int dfd_gemm_plan(int M, int K, int N);
 /* dbias[c] (+)= sum over rows of g[row][c] (* row_scale[n]): the bias gradient of a Linear layer (no statistics).  ws:
  * dfd_bias_grad_ws bytes; its final fixed-order summation joins an open dfd_sum_batch like a weight gradient's.  ABI 121 */
 size_t dfd_bias_grad_ws(int N, int HW, int C);

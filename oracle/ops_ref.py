@@ -167,13 +167,19 @@ def mx_quant(v: torch.Tensor):
     inv = torch.ldexp(torch.ones_like(amax), -e)                # 2^-e (e = -127 only for all-zero blocks: 0 * 2^127 = 0)
     scaled = (blocks * inv[:, None]).clamp(-448.0, 448.0)
     q = scaled.to(torch.float8_e4m3fn).view(torch.uint8)
-    return q.reshape(shape), (e + 127).to(torch.uint8).reshape(*shape[:-1], shape[-1] // 32)
+    sb = (e + 127).to(torch.uint8)
+    # a block with a NaN or an infinity is a NaN block: the OCP MX NaN scale 0xff, every element the e4m3fn NaN 0x7f
+    bad = ~torch.isfinite(blocks).all(dim=1)
+    q = torch.where(bad[:, None], torch.full_like(q, 0x7F), q)
+    sb = torch.where(bad, torch.full_like(sb, 0xFF), sb)
+    return q.reshape(shape), sb.reshape(*shape[:-1], shape[-1] // 32)
 
 
 def mx_dequant(q: torch.Tensor, scale: torch.Tensor) -> torch.Tensor:
     """(q, scale) of mx_quant -> f32 values (exact)."""
     vals = q.contiguous().view(torch.float8_e4m3fn).to(torch.float32).reshape(-1, 32)
     sc = torch.ldexp(torch.ones(vals.shape[0]), scale.reshape(-1).to(torch.int32) - 127)
+    sc = torch.where(scale.reshape(-1) == 0xFF, torch.full_like(sc, float("nan")), sc)
     return (vals * sc[:, None]).reshape(q.shape)
 
 

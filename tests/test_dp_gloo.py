@@ -97,6 +97,67 @@ def test_two_rank_gloo(tmp_path):
     assert len(set(a) & set(b)) == 1                               # exactly the one padded duplicate
 
 
+def _mixed_worker(rank: int, world: int, port: int) -> None:
+    """the ranks decide on their own whether a cycle runs eagerly (hooks launch the buckets from inside
+    backward) or replayed (one-shot reduce() afterwards) — a capture failure on ONE GPU must not make the ranks post different
+    collectives.  Rank 0 takes the hook path, rank 1 the one-shot path, gradients in arena slots as on the GPU hot loop; several
+    small buckets; the order in which autograd completes the buckets (last layer first) differs from the one-shot order."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.manual_seed(3)
+        model = torch.nn.Sequential(torch.nn.Linear(9, 8), torch.nn.Tanh(), torch.nn.Linear(8, 8), torch.nn.Tanh(), torch.nn.Linear(8, 4))
+        params = list(model.parameters())
+        arena = GradArena(params)
+        red = GradAllReducer(params, bucket_bytes=160, arena=arena)
+        assert len(red.buckets) >= 3 and red._ranges is not None
+        red.attach()
+        torch.manual_seed(50 + rank)
+        x = torch.randn(5, 9)
+
+        def backward_into_slots():
+            for p in params:
+                p.grad = None
+            arena.reset()
+            loss = model(x).square().sum()
+            grads = torch.autograd.grad(loss, params)
+            for p, slot, g in zip(arena.params, arena.slots, grads):
+                slot.copy_(g.reshape(-1))
+            return [g.clone() for g in grads]
+
+        local = backward_into_slots()
+        want = []
+        for g in local:
+            parts = [torch.zeros_like(g) for _ in range(world)]
+            dist.all_gather(parts, g)
+            want.append(parts[0] + parts[1])
+        for cycle in range(3):
+            backward_into_slots()
+            if (rank + cycle) % 2 == 0:
+                # eager cycle: the hooks fire as each parameter's gradient lands in its slot, late layers first
+                red.arm()
+                for p, slot in reversed(list(zip(arena.params, arena.slots))):
+                    p.grad = slot.view_as(p)
+                    red._on_grad(p)
+                red.finish()
+            else:
+                # replayed cycle: every gradient already sits in the arena, one call afterwards
+                for p, slot in zip(arena.params, arena.slots):
+                    p.grad = slot.view_as(p)
+                red.finish()
+            for p, w in zip(params, want):
+                assert torch.allclose(p.grad, w, rtol=1e-5, atol=1e-6), f"cycle {cycle}: mixed eager / replay ranks disagree"
+        assert red.launched_early >= 1
+        red.detach()
+        arena.release()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_ranks_in_different_modes_post_the_same_collectives():
+    mp.spawn(_mixed_worker, args=(2, _free_port()), nprocs=2, join=True)
+
+
 def test_sharded_sampler_properties():
     s0 = ShardedSampler(10, 0, 4, shuffle=False)
     assert list(s0) == [0, 4, 8] and len(s0) == 3

@@ -98,18 +98,26 @@ def test_full_training_step_at_the_benchmark_configuration():
     loss.backward()
     torch.cuda.synchronize()
     assert torch.isfinite(logits).all()
-    # bf16 yardstick: the oracle itself under CPU bf16 autocast against its f32 self
+    # bf16 yardstick: the oracle itself under CPU bf16 autocast against its f32 self.  ONE such run is one realisation of bf16
+    # rounding noise amplified through 80 random-init layers; another summation order anywhere in the network is another realisation
+    # of the same noise (VERDICT r3 "what's weak" 2), so the yardstick is drawn several times — two memory formats (different oneDNN
+    # kernels) x two batch orders (different order of the BatchNorm sums) — and the bound is their maximum plus their spread (at
+    # least 15 % of their mean: four samples under-estimate the spread of a maximum over 512 logits).
     import copy
 
+    yards = []
     with torch.no_grad(), torch.autocast("cpu", dtype=BF):
-        auto = copy.deepcopy(ref)(x).float()
-    yard = rel_err(auto, ref_logits)
+        for fmt in (torch.channels_last, torch.contiguous_format):
+            for flip in (False, True):
+                xi = (x.flip(0) if flip else x).contiguous(memory_format=fmt)
+                auto = copy.deepcopy(ref)(xi).float()
+                yards.append(rel_err(auto.flip(0) if flip else auto, ref_logits))
+    spread = max(max(yards) - min(yards), 0.15 * sum(yards) / len(yards))
+    bound = max(yards) + spread
     err = rel_err(logits, ref_logits)
-    print(f"logits rel err {err:.4f} (oracle's own bf16 autocast: {yard:.4f}); loss {float(loss):.5f} vs {float(ref_loss):.5f}")
-    # the yardstick is ONE realisation of bf16 rounding noise amplified through 80 random-init layers (~0.09 here); another
-    # summation order anywhere in the network (the stem's matrix-core kernel against the f32-FMA one: 0.093 against 0.087) is
-    # another realisation of the same noise, so the bound is the yardstick's scale, not its exact value
-    assert err <= max(1.5 * yard, 2e-2), (err, yard)
+    print(f"logits rel err {err:.4f}; the oracle's own bf16 autocast, four realisations: {[round(v, 4) for v in yards]} -> bound {bound:.4f}; "
+          f"loss {float(loss):.5f} vs {float(ref_loss):.5f}")
+    assert err <= max(bound, 2e-2), (err, yards, bound)
     assert abs(float(loss) - float(ref_loss)) <= 2e-2 * max(1.0, abs(float(ref_loss)))
     # BatchNorm running statistics of the large early layers: f32 sums over 3.2 M bf16 values per channel
     rb, hb = dict(ref.named_buffers()), dict(hip.named_buffers())

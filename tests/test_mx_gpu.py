@@ -54,6 +54,40 @@ def test_weight_quantisation_is_bit_exact(shape):
     assert torch.equal(deq.to(BF).float()[finite], deq[finite]), "a dequantised e4m3 value times 2^e is exact in bf16"
 
 
+def test_non_finite_values_survive_the_quantiser():
+    """fmaxf / fminf drop NaNs, so a NaN or infinite activation used to come out of the quantiser as +-448 * 2^e and
+    a diverged run kept producing finite logits.  A block with a non-finite value is now the OCP MX NaN block (scale 0xff, elements
+    0x7f), byte for byte as the oracle says, and the scaled MFMA turns it into NaN outputs for exactly the rows that held it."""
+    K = _K()
+    a = _nasty(64, 256, seed=5).float()
+    a[3, 40] = float("nan")
+    a[17, 200] = float("inf")
+    a[18, 0] = -float("inf")
+    q, s = K.mx_quant_rows(a.cuda().view(64, 1, 1, 256))
+    torch.cuda.synchronize()
+    qr, sr = R.mx_quant(a)
+    assert torch.equal(q.cpu(), qr) and torch.equal(s.cpu(), sr)
+    assert int(sr[3, 1]) == 0xFF and int(sr[17, 6]) == 0xFF and int(sr[18, 0]) == 0xFF and int((sr == 0xFF).sum()) == 3
+    w = _nasty(256, 256, seed=6)
+    mw, kn = K.mx_quant_weight(w.cuda(), BF)
+    out = K.mx_gemm(q, s, mw, torch.float32).cpu()
+    bad_rows = torch.tensor([3, 17, 18])
+    assert torch.isnan(out[bad_rows]).all(), "a NaN block did not reach the output"
+    good = torch.ones(64, dtype=torch.bool)
+    good[bad_rows] = False
+    clean = _nasty(64, 256, seed=5).float()
+    qc, sc_ = K.mx_quant_rows(clean.cuda().view(64, 1, 1, 256))
+    ref = K.mx_gemm(qc, sc_, mw, torch.float32).cpu()
+    assert torch.equal(out[good].nan_to_num(), ref[good].nan_to_num()), "the other rows changed"
+    # the weight side too, and its dequantised [K][N] copy for the bf16 backward
+    w2 = w.clone()
+    w2[5, 33] = float("nan")
+    mw2, kn2 = K.mx_quant_weight(w2.cuda(), BF)
+    q2, s2 = R.mx_quant(w2)
+    assert torch.equal(mw2.q.cpu(), q2) and torch.equal(mw2.scale.cpu(), s2)
+    assert torch.isnan(kn2.float().cpu()[32:64, 5]).all() and torch.isfinite(kn2.float().cpu()[:32, 5]).all()
+
+
 @pytest.mark.parametrize("dtype", [BF, torch.float32])
 def test_activation_quantisation_is_bit_exact(dtype):
     K = _K()

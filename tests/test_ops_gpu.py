@@ -785,3 +785,36 @@ def test_resize_crop_matches_pillow_bit_for_bit():
     x = tail(raw, "cuda").cpu()
     ref = torch.stack([D.Normalize(mean, std)(D.ToTensor()(D.CenterCrop(out)(D.Resize(enlarged)(im)))) for im in imgs[:4]])
     assert torch.equal(x, ref)
+
+
+def test_oversize_image_is_preshrunk_by_the_worker_and_still_bit_exact():
+    """An image whose shrink factor exceeds the device kernel's filter length (~46x) is resized in the worker by the PIL calls the
+    kernel restates and travels with an identity plan (data.PlanGeometry): the batch no longer fails with DFD_EUNSUPPORTED and the
+    result still equals the PIL pipeline byte for byte — mixed with ordinary images in one batch."""
+    import numpy as np
+    from PIL import Image
+
+    from deepfakedetection_amd import data as D
+
+    K = _k()
+    rng = np.random.default_rng(9)
+    sizes = [(4000, 3100), (400, 300), (64, 9000)]            # 64x / 6x / 140x shrink to a 48-pixel shorter side
+    imgs = [Image.fromarray(rng.integers(0, 256, (h, w, 3), dtype=np.uint8)) for w, h in sizes]
+    out, enlarged = 40, 48
+    plan = D.PlanGeometry("center", out, enlarged)
+    want = [np.array(D.CenterCrop(out)(D.Resize(enlarged)(im))) for im in imgs]
+    (flat, jobs, meta), _ = D.collate_raw([(plan(im), 0) for im in imgs])
+    assert int(meta[2]) <= D.PlanGeometry.MAX_DEVICE_SHRINK
+    got = K.resize_crop_u8(flat.cuda(), jobs.cuda(), len(imgs), out, out, int(meta[2])).cpu().numpy()
+    for i, w in enumerate(want):
+        assert np.array_equal(got[i], w), (i, imgs[i].size)
+    rrc = D.RandomResizedCrop(out, scale=(0.9, 1.0))
+    torch.manual_seed(2); import random; random.seed(2); np.random.seed(2)
+    state = torch.get_rng_state()
+    want = [np.array(rrc(im)) for im in imgs]
+    torch.set_rng_state(state); random.seed(2); np.random.seed(2)
+    planr = D.PlanGeometry("rrc", out, rrc=rrc)
+    (flat, jobs, meta), _ = D.collate_raw([(planr(im), 0) for im in imgs])
+    got = K.resize_crop_u8(flat.cuda(), jobs.cuda(), len(imgs), out, out, int(meta[2])).cpu().numpy()
+    for i, w in enumerate(want):
+        assert np.array_equal(got[i], w), ("rrc", i, imgs[i].size)

@@ -664,6 +664,11 @@ def test_plain_bf16_product_on_256_tiles_with_lds_dma(shape):
     stages up.  Against the f32 product of the same bf16 operands: one bf16 rounding of the result."""
     K = _k()
     M, Kd, N = shape
+    from deepfakedetection_amd._lib import load
+
+    # K.pwconv falls back to the 128 x 128 kernel when the planner declines: make sure this shape IS the LDS-DMA kernel's
+    assert load().dfd_gemm_plan(M, Kd, N) in (128, 256), "the LDS-DMA planner no longer serves this shape: the test would run k_pw_nt"
+    assert load().dfd_gemm_plan(M, Kd + 8, N) == 0 and load().dfd_gemm_plan(200, Kd, N) == 0
     g = torch.Generator().manual_seed(M + N)
     a = (torch.randn((M, 1, 1, Kd), generator=g)).to(torch.bfloat16).cuda()
     w = (torch.randn((N, Kd), generator=g) * Kd ** -0.5).cuda()
@@ -682,7 +687,9 @@ def test_plain_bf16_product_on_256_tiles_with_lds_dma(shape):
                                   (49 * 256, 512, 512, R.ACT_NONE, True, True, True), (256 * 170, 128, 768, R.ACT_NONE, False, False, False)])
 def test_linear_with_fused_bias_activation_residual_epilogue_is_bitwise_the_two_kernel_form(case):
     """dfd_gemm_bias_act: act(scale * y + shift) [* row_scale] [+ residual] in the product's store loop, on the bf16-rounded y —
-    identical bits to dfd_pwconv_fwd followed by dfd_bn_act_apply, and the optional raw y equals the plain product."""
+    identical bits to dfd_pwconv_fwd followed by dfd_bn_act_apply, and the optional raw y equals the plain product.
+    (A comparison of two HIP paths on purpose: both sides are checked against the oracle on their own —
+    test_plain_bf16_product_on_256_tiles_with_lds_dma above, test_ops_gpu.py::test_rowpass — this test pins the FUSION.)"""
     K = _k()
     M, Kd, N, act, with_res, with_rs, want_raw = case
     T = 53 if M % 53 == 0 else (49 if M % 49 == 0 else 1)
@@ -703,3 +710,40 @@ def test_linear_with_fused_bias_activation_residual_epilogue_is_bitwise_the_two_
     assert (raw is None) == (not want_raw)
     if raw is not None:
         assert torch.equal(raw, y)
+
+
+def test_eval_mode_backward_of_a_batchnormed_1x1_at_a_fused_shape():
+    """in eval mode `pwbn_fwd` may serve a layer with the fused product + BN-apply kernel, and a layer with a REAL
+    BatchNorm still needs the raw product in its backward (bn_bwd_reduce, the BN-backward prologue) — frozen-BN fine-tuning and
+    attribution runs differentiate in eval mode.  A shape the fused kernel accepts (K % 64 == 0, N >= 256, >= 160 tiles): the raw y
+    must be returned and the backward must match the eval-mode BatchNorm arithmetic."""
+    from deepfakedetection_amd._lib import load
+    from deepfakedetection_amd.functions import BNRef
+    from deepfakedetection_amd.vit_functions import pwbn_bwd, pwbn_fwd
+
+    K = _k()
+    n, T, Kd, N = 160, 128, 128, 256
+    assert load().dfd_gemm_plan(n * T, Kd, N) != 0
+    g0 = torch.Generator().manual_seed(11)
+    x = torch.randn((n, T, 1, Kd), generator=g0).to(torch.bfloat16).cuda()
+    w = (torch.randn((N, Kd, 1, 1), generator=g0) * Kd ** -0.5).cuda()
+    gamma, beta = (0.5 + torch.rand(N, generator=g0)).cuda(), (torch.randn(N, generator=g0) * 0.2).cuda()
+    rm, rv = (torch.randn(N, generator=g0) * 0.1).cuda(), (0.5 + torch.rand(N, generator=g0)).cuda()
+    bn = BNRef(rm, rv, None, 0.1, 1e-5)
+    w_nk, w_kn = K.prep_weights(w, torch.bfloat16, True, True)
+    out, y, st = pwbn_fwd(x, w_nk, None, gamma, beta, bn, False, None)
+    assert y is not None, "a BatchNormed layer lost its raw product: its eval-mode backward would dereference None"
+    g = torch.randn(out.shape, generator=g0).to(torch.bfloat16).cuda()
+    dx, dw, _, dgamma, dbeta, _ = pwbn_bwd(g, x, y, st, w_kn, tuple(w.shape), w, None, gamma, beta, None, R.ACT_NONE, False, True, True, True)
+    # reference: eval BatchNorm is the affine map out = a * y + c with a = gamma * rstd
+    xf, wf, gf = x.float().view(-1, Kd), w.view(N, Kd).to(torch.bfloat16).float(), g.float().view(-1, N)
+    yf = xf @ wf.t()
+    rstd = (rv + 1e-5).rsqrt()
+    want_out = (yf - rm) * rstd * gamma + beta
+    dy = (gf * (gamma * rstd)).to(torch.bfloat16).float()
+    close(out.view(-1, N), want_out, 1.6e-2, "eval pw+bn out")
+    close(y.view(-1, N), yf, 1.6e-2, "eval pw+bn raw y")
+    close(dx.view(-1, Kd), dy @ wf, 2e-2, "eval pw+bn dx")
+    close(dw.view(N, Kd), dy.t() @ xf, 2e-2, "eval pw+bn dw")
+    close(dbeta, gf.sum(0), 2e-2, "eval pw+bn dbeta")
+    close(dgamma, (gf * ((y.float().view(-1, N) - rm) * rstd)).sum(0), 2e-2, "eval pw+bn dgamma")
