@@ -225,10 +225,11 @@ def main() -> None:
         print(json.dumps(cpu_baseline_measure(args)), flush=True)
         return
     from deepfakedetection_amd import kernels as K
-    from deepfakedetection_amd.dp import GradAllReducer, broadcast_module_state, init_distributed
+    from deepfakedetection_amd.dp import GradAllReducer, broadcast_module_state, init_distributed, rccl_log_request, rccl_log_summary
     from deepfakedetection_amd.efficientnet import HipEfficientNet
     from deepfakedetection_amd.optim import HipAdamW, HipCrossEntropyLoss
 
+    rccl_log = rccl_log_request("bench") if int(os.environ.get("WORLD_SIZE", "1")) > 1 and int(os.environ.get("RANK", "0")) == 0 else None
     rank, local_rank, world = init_distributed()
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
@@ -468,6 +469,7 @@ def main() -> None:
                                    f"bf16 fwd + label-smoothed CE + bwd + AdamW, random-init weights, {args.classes} classes",
                        "per_gpu_batch": args.batch, "global_batch": args.batch * world, "parallelism": f"dp{world}",
                        "launch": launch, "final_loss": round(final_loss, 4), "replicas_in_sync": in_sync,
+                       "rccl": rccl_log_summary(rccl_log) if world > 1 else None,
                        "eval_f32_images_per_sec_per_gpu": round(eval_ips, 1) if eval_ips else None},
             "roofline": roofline,
             "kernels": breakdown,

@@ -52,6 +52,46 @@ def init_distributed(backend: str | None = None) -> tuple[int, int, int]:
     return rank, local_rank, world
 
 
+def rccl_log_request(tag: str = "dfd") -> str | None:
+    """Ask RCCL to write its INIT / tuning log to a per-process file (call BEFORE init_process_group); returns the path this
+    process will write, or None when the caller already configured NCCL_DEBUG itself.  The bench line records what RCCL chose
+    (channels, ring / tree, protocol) so that a multi-GPU run leaves that evidence next to its number."""
+    if os.environ.get("NCCL_DEBUG"):
+        return None
+    import tempfile
+
+    pattern = os.path.join(tempfile.gettempdir(), f"{tag}_rccl_%h_%p.log")
+    os.environ["NCCL_DEBUG"] = "INFO"
+    os.environ.setdefault("NCCL_DEBUG_SUBSYS", "INIT,GRAPH,TUNING,ENV")
+    os.environ["NCCL_DEBUG_FILE"] = pattern
+    import socket
+
+    return pattern.replace("%h", socket.gethostname()).replace("%p", str(os.getpid()))
+
+
+def rccl_log_summary(path: str | None, limit: int = 12) -> dict | None:
+    """The lines of an RCCL INFO log that say what it will do: version, channel count, ring / tree graphs, algorithm and
+    protocol enablement, threshold tuning.  Never raises: a missing or unreadable file yields {"note": ...}."""
+    if not path:
+        return None
+    try:
+        with open(path, errors="replace") as fh:
+            lines = fh.read().splitlines()
+    except OSError as exc:
+        return {"note": f"no RCCL log ({type(exc).__name__})"}
+    keys = ("RCCL version", "NCCL version", "Channel", "channels", "Ring ", "Trees", "Tree ", "Algo", "Proto", "threadThresholds", "xgmi", "XGMI",
+            "P2P", "NCCL_ALGO", "NCCL_PROTO", "comm 0x")
+    picked, seen = [], set()
+    for ln in lines:
+        body = ln.split("NCCL INFO", 1)[-1].strip()
+        if any(k in body for k in keys) and body not in seen:
+            seen.add(body)
+            picked.append(body[:160])
+        if len(picked) >= limit:
+            break
+    return {"log_lines": len(lines), "selected": picked}
+
+
 def broadcast_module_state(module: torch.nn.Module, src: int = 0) -> None:
     """Make every replica start from rank `src`'s parameters and buffers."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
@@ -286,4 +326,5 @@ def all_reduce_counts(*values: float, device: torch.device | str = "cpu") -> lis
     return t.tolist()
 
 
-__all__ = ["GradAllReducer", "ShardedSampler", "all_reduce_counts", "broadcast_module_state", "env_rank", "init_distributed"]
+__all__ = ["GradAllReducer", "ShardedSampler", "all_reduce_counts", "broadcast_module_state", "env_rank", "init_distributed",
+           "rccl_log_request", "rccl_log_summary"]

@@ -260,3 +260,16 @@ def test_hip_adamw_state_dict_round_trips_into_torch_adamw():
     opt2.load_state_dict(ref.state_dict())
     opt2.prepare_step()
     assert all(float(opt2.state[p]["step"]) == 5.0 for p in params)
+
+
+def test_rccl_log_summary_never_raises_and_picks_the_decisions(tmp_path):
+    """bench.py --gpus N records what RCCL chose (config.rccl): the summariser must cope with any log, or none."""
+    from deepfakedetection_amd.dp import rccl_log_summary
+
+    log = tmp_path / "rccl.log"
+    log.write_text("h:1:1 [0] NCCL INFO RCCL version 2.22.3\nh:1:1 [0] NCCL INFO Channel 00/32 : 0 1 2 3 4 5 6 7\nnoise\n"
+                   "h:1:1 [0] NCCL INFO Trees [0] 1/-1/-1->0->-1\nh:1:1 [0] NCCL INFO Channel 00/32 : 0 1 2 3 4 5 6 7\n")
+    got = rccl_log_summary(str(log))
+    assert got["log_lines"] == 5 and got["selected"] == ["RCCL version 2.22.3", "Channel 00/32 : 0 1 2 3 4 5 6 7", "Trees [0] 1/-1/-1->0->-1"]
+    assert "note" in rccl_log_summary(str(tmp_path / "missing.log"))
+    assert rccl_log_summary(None) is None
