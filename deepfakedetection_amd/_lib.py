@@ -66,6 +66,7 @@ SIGNATURES: dict[str, tuple] = {
     "dfd_act_bn_bwd": (c_int, [c_int, P, P, P, P, P, c_int, P, c_int, c_int, c_int, P, c_int, _PI, P]),
     "dfd_prep_weights_multi": (c_int, [P, c_int, P]),
     "dfd_resize_crop_u8": (c_int, [P, P, P, c_int, c_int, c_int, c_int, P]),
+    "dfd_augment_u8": (c_int, [P, P, P, c_int, c_int, c_int, P]),
     "dfd_image_prep": (c_int, [P, P, c_int, c_int, c_int, POINTER(c_float), POINTER(c_float), P, P, P]),
     "dfd_pool_ws": (c_size_t, [c_int, c_int, c_int, c_int]),
     "dfd_pool_act": (c_int, [c_int, P, P, c_int, P, c_int, c_int, c_int, P, c_size_t, P]),

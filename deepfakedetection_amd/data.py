@@ -326,17 +326,81 @@ def collate_raw(batch):
     return (flat, torch.from_numpy(jobs.view(np.uint8).copy()), meta), labels
 
 
+AUGMENT_MAX_BYTES = 156 * 1024          # dfd_augment_u8 keeps one picture in a CU's LDS (csrc/dfd_augment.hip)
+
+
+def rotate_plan(w: int, h: int, angle: float) -> tuple[int, tuple[int, ...]]:
+    """What Image.rotate(angle, NEAREST, expand=False) will do to a w x h picture, for the device kernel: (mode, coefficients) with
+    mode 0 copy, 1 affine (six 16.16 fixed-point coefficients, formed as Image.rotate + Geometry.c affine_fixed form them), 2 the
+    180-degree flip, 3 / 4 the 90 / 270-degree transposes Pillow takes for square pictures."""
+    angle = angle % 360.0
+    if angle == 0:
+        return 0, (0,) * 6
+    if angle == 180:
+        return 2, (0,) * 6
+    if angle in (90, 270) and w == h:
+        return (3 if angle == 90 else 4), (0,) * 6
+    cx, cy = w / 2.0, h / 2.0
+    rad = -math.radians(angle)
+    m = [round(math.cos(rad), 15), round(math.sin(rad), 15), 0.0, round(-math.sin(rad), 15), round(math.cos(rad), 15), 0.0]
+    m[2] = m[0] * (-cx) + m[1] * (-cy) + m[2]
+    m[5] = m[3] * (-cx) + m[4] * (-cy) + m[5]
+    m[2] += cx
+    m[5] += cy
+
+    def fix(v: float) -> int:
+        return int(math.floor(v * 65536.0 + 0.5))
+
+    return 1, (fix(m[0]), fix(m[1]), fix(m[2] + m[0] * 0.5 + m[1] * 0.5), fix(m[3]), fix(m[4]), fix(m[5] + m[3] * 0.5 + m[4] * 0.5))
+
+
 class GpuInputTail:
-    """RandomHorizontalFlip -> ToTensor -> Normalize -> RandomErasing(value=0) on the device, for a uint8
-    NHWC batch.  The random decisions use the same distributions and the same
-    host RNG calls as the CPU transforms above, one image at a time; the arithmetic is the kernel
-    dfd_image_prep (bit-identical to ToTensor + Normalize).  4x fewer bytes cross PCIe than with
-    f32 batches, and the worker processes skip three tensor passes per image."""
+    """[RandomRotation] -> RandomHorizontalFlip -> [ColorJitter] -> ToTensor -> Normalize -> RandomErasing(value=0) on the device, for a
+    uint8 NHWC batch.  The random decisions use the same distributions and the same
+    host RNG calls as the CPU transforms above, one image at a time, in the pipeline's order; the arithmetic is the kernels
+    dfd_augment_u8 (rotation + colour jitter, byte-exact with Pillow) and dfd_image_prep (bit-identical to ToTensor + Normalize;
+    the flip commutes with the per-pixel colour operations and with the mean Contrast takes, so it stays in this last kernel).
+    4x fewer bytes cross PCIe than with f32 batches, and the worker processes skip every pixel pass but the decode."""
 
     def __init__(self, mean: Sequence[float], std: Sequence[float], flip_p: float = 0.0, erase_p: float = 0.0,
-                 erase_scale: tuple[float, float] = (0.02, 0.33), erase_ratio: tuple[float, float] = (0.3, 3.3)) -> None:
+                 erase_scale: tuple[float, float] = (0.02, 0.33), erase_ratio: tuple[float, float] = (0.3, 3.3),
+                 rotate_degrees: float = 0.0, jitter: Sequence[float] | None = None) -> None:
         self.mean, self.std = [float(v) for v in mean], [float(v) for v in std]
         self.flip_p, self.erase_p, self.erase_scale, self.erase_ratio = flip_p, erase_p, erase_scale, erase_ratio
+        self.rotate_degrees = float(rotate_degrees)
+        self.jitter = tuple(float(v) for v in jitter) if jitter is not None and any(float(v) > 0 for v in jitter) else None
+
+    @property
+    def augments(self) -> bool:
+        return self.rotate_degrees > 0 or self.jitter is not None
+
+    def sample_augment(self, n: int, h: int, w: int) -> torch.Tensor:
+        """One dfd_augment_job (16 int32) per picture: RandomRotation's angle and ColorJitter's permutation + factors, drawn as
+        data.RandomRotation / data.ColorJitter draw them (same calls, same order: angle; permutation; one uniform per enabled
+        operation in the permuted order)."""
+        jobs = np.zeros((n, 16), dtype=np.int32)
+        fl = jobs.view(np.float32)
+        for i in range(n):
+            if self.rotate_degrees > 0:
+                mode, coef = rotate_plan(w, h, _uniform(-self.rotate_degrees, self.rotate_degrees))
+                jobs[i, 0] = mode
+                jobs[i, 1:7] = coef
+            jobs[i, 7:11] = -1
+            if self.jitter is not None:
+                b, c, s, hue = self.jitter
+                order = torch.randperm(4).tolist()
+                jobs[i, 7:11] = order
+                for which in order:
+                    if which == 0 and b > 0:
+                        fl[i, 11] = _uniform(max(0.0, 1 - b), 1 + b)
+                    elif which == 1 and c > 0:
+                        fl[i, 12] = _uniform(max(0.0, 1 - c), 1 + c)
+                    elif which == 2 and s > 0:
+                        fl[i, 13] = _uniform(max(0.0, 1 - s), 1 + s)
+                    elif which == 3 and hue > 0:
+                        jobs[i, 14] = int(round(_uniform(-hue, hue) * 255)) % 256
+                jobs[i, 15] = (1 if b > 0 else 0) | (2 if c > 0 else 0) | (4 if s > 0 else 0) | (8 if hue > 0 else 0)
+        return torch.from_numpy(jobs)
 
     def sample(self, n: int, h: int, w: int) -> tuple[torch.Tensor | None, torch.Tensor | None]:
         flip = erase = None
@@ -367,16 +431,22 @@ class GpuInputTail:
             flat, jobs, meta = batch_u8
             oh, ow, shrink = (int(v) for v in meta)
             n = jobs.numel() // _JOB_DTYPE.itemsize
+            aug = self.sample_augment(n, oh, ow) if self.augments else None
             flip, erase = self.sample(n, oh, ow)
             dev = K.resize_crop_u8(flat.to(device, non_blocking=True), jobs.to(device, non_blocking=True), n, oh, ow, shrink)
+            if aug is not None:
+                dev = K.augment_u8(dev, aug.to(device, non_blocking=True))
             return K.image_prep(dev, self.mean, self.std,
                                 flip.to(device, non_blocking=True) if flip is not None else None,
                                 erase.to(device, non_blocking=True) if erase is not None else None)
         if batch_u8.dim() != 4 or batch_u8.shape[3] != 3 or batch_u8.dtype != torch.uint8:
             raise ValueError("GpuInputTail expects a uint8 [N, H, W, 3] batch (ToUint8HWC at the end of the CPU pipeline)")
         n, h, w, _ = batch_u8.shape
+        aug = self.sample_augment(n, h, w) if self.augments else None
         flip, erase = self.sample(n, h, w)
         dev = batch_u8.to(device, non_blocking=True).contiguous()
+        if aug is not None:
+            dev = K.augment_u8(dev, aug.to(device, non_blocking=True))
         return K.image_prep(dev, self.mean, self.std,
                             flip.to(device, non_blocking=True) if flip is not None else None,
                             erase.to(device, non_blocking=True) if erase is not None else None)

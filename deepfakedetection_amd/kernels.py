@@ -453,6 +453,19 @@ def resize_crop_u8(flat_u8: torch.Tensor, jobs_u8: torch.Tensor, n: int, oh: int
     return out
 
 
+def augment_u8(src_u8: torch.Tensor, jobs_i32: torch.Tensor) -> torch.Tensor:
+    """uint8 [N, H, W, 3] on the device + one 16-int job per picture (data.GpuInputTail.sample_augment) -> the rotated and
+    colour-jittered uint8 batch, byte-exact with the PIL transforms of data.py (csrc/dfd_augment.hip)."""
+    if src_u8.dtype != torch.uint8 or src_u8.dim() != 4 or src_u8.shape[3] != 3 or not src_u8.is_contiguous():
+        raise ValueError("expected a contiguous uint8 [N, H, W, 3] tensor")
+    N, H, W, _ = src_u8.shape
+    if jobs_i32.dtype != torch.int32 or jobs_i32.numel() != 16 * N or not jobs_i32.is_contiguous():
+        raise ValueError("augment_u8: expected N jobs of 16 int32 each")
+    out = torch.empty_like(src_u8)
+    check(_L().dfd_augment_u8(_p(src_u8), _p(jobs_i32), _p(out), N, H, W, _stream()), "dfd_augment_u8", f"{tuple(src_u8.shape)}")
+    return out
+
+
 def image_prep(src_u8: torch.Tensor, mean, std, flip: torch.Tensor | None, erase: torch.Tensor | None) -> torch.Tensor:
     """uint8 [N, H, W, 3] on the device -> f32, returned as an [N, 3, H, W] channels_last view of the
     NHWC result (zero-copy: exactly what HipEfficientNet.forward turns back into NHWC)."""

@@ -77,7 +77,9 @@ def build_transforms(img_size: int, gpu_tail: bool = False, *, rotation_default:
     rotation placed after the horizontal flip.
     gpu_resize (with gpu_tail): Resize / CenterCrop / RandomCrop / RandomResizedCrop move onto the device as well
     (D.PlanGeometry + csrc/dfd_resize.hip, bit-exact with PIL): always for the validation pipeline, and for the training
-    pipeline when nothing between the crop and ToTensor needs a PIL image (no rotation, no colour jitter)."""
+    pipeline too — RandomRotation and ColorJitter, which the reference's DEFAULT toggles at 224 pixels switch on
+    (trainers/efficientnet.py:134-135), run on the device as well (csrc/dfd_augment.hip, byte-exact with Pillow) as long as
+    one picture fits a CU's LDS (img_size <= 228); larger pictures with rotation / jitter keep those two in the PIL workers."""
     small = img_size <= 64
     toggles = load_transform_toggles(
         {
@@ -119,7 +121,10 @@ def build_transforms(img_size: int, gpu_tail: bool = False, *, rotation_default:
             train.append(D.RandomHorizontalFlip())
         if on("train_random_rotation", False):
             train.append(D.RandomRotation(10))
-    train_on_gpu = (gpu_tail and gpu_resize and not on("train_random_rotation", False) and not on("train_color_jitter", False))
+    want_rot = on("train_random_rotation", False) and (rotation_after_flip or not small)
+    want_jit = on("train_color_jitter", False)
+    aug_fits = img_size * img_size * 3 <= D.AUGMENT_MAX_BYTES
+    train_on_gpu = gpu_tail and gpu_resize and (aug_fits or not (want_rot or want_jit))
     if train_on_gpu:
         # the geometric head of the pipeline as a PLAN (same decisions, same RNG calls), pixels untouched
         train = [D.Lambda(_rgb)] if on("ensure_rgb", True) else []
@@ -133,7 +138,8 @@ def build_transforms(img_size: int, gpu_tail: bool = False, *, rotation_default:
         train_tail = D.GpuInputTail(mean if on("train_normalize", True) else [0.0] * 3,
                                     std if on("train_normalize", True) else [1.0] * 3,
                                     flip_p=0.5 if on("train_random_horizontal_flip", True) else 0.0,
-                                    erase_p=0.5 if on("train_random_erasing", False) else 0.0)
+                                    erase_p=0.5 if on("train_random_erasing", False) else 0.0,
+                                    rotate_degrees=10.0 if want_rot else 0.0, jitter=jitter if want_jit else None)
     elif gpu_tail:
         if rotation_after_flip and on("train_random_rotation", False):
             train.append(D.RandomRotation(10))      # rotation by a random angle commutes in distribution with the flip

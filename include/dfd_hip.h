@@ -373,6 +373,26 @@ typedef struct dfd_resize_job {
 } dfd_resize_job;
 int dfd_resize_crop_u8(const unsigned char* src, const dfd_resize_job* jobs_dev, unsigned char* dst, int N, int OH, int OW,
                        int max_shrink, dfd_stream stream);
+/* RandomRotation + ColorJitter on the device for a uint8 [N][H][W][3] batch (between dfd_resize_crop_u8 and dfd_image_prep): the
+ * reference's DEFAULT 224-pixel training pipeline has both (trainers/efficientnet.py:173-181).  Byte-exact with the PIL pipeline of
+ * deepfakedetection_amd/data.py (csrc/dfd_augment.hip restates Pillow's rotate / blend / HSV arithmetic; oracle/image_ref.py).
+ * One job per picture, drawn by the host with the same distributions as the CPU transforms:
+ *   mode   0 copy, 1 affine rotation with the 16.16 coefficients a[6] (data.rotate_plan), 2 / 3 / 4 rotation by 180 / 90 / 270 degrees
+ *          (the last two for square pictures only);
+ *   order  the permutation of (0 brightness, 1 contrast, 2 saturation, 3 hue) ColorJitter drew; enable bit k: operation k runs;
+ *   fb, fc, fs the three blend factors; dh the hue shift in 8-bit hue units (0..255).
+ * src != dst.  DFD_EUNSUPPORTED when H * W * 3 exceeds 156 KiB (the picture stays in one CU's LDS): callers keep the PIL pipeline. */
+typedef struct {
+    int mode;
+    int a[6];
+    int order[4];
+    float fb, fc, fs;
+    int dh;
+    int enable;
+} dfd_augment_job;   /* 64 bytes */
+int dfd_augment_u8(const unsigned char* src, const dfd_augment_job* jobs_dev, unsigned char* dst, int N, int H, int W,
+                   dfd_stream stream);
+
 /* Input tail on the device (trainers/efficientnet.py:111-234): a uint8 NHWC
  * batch [N][H][W][3] -> RandomHorizontalFlip -> ToTensor (/255) -> Normalize((x-mean)/std) ->
  * RandomErasing(value 0) -> f32 NHWC, which is the stem kernel's input layout.  The random decisions

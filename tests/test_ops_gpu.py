@@ -818,3 +818,72 @@ def test_oversize_image_is_preshrunk_by_the_worker_and_still_bit_exact():
     got = K.resize_crop_u8(flat.cuda(), jobs.cuda(), len(imgs), out, out, int(meta[2])).cpu().numpy()
     for i, w in enumerate(want):
         assert np.array_equal(got[i], w), ("rrc", i, imgs[i].size)
+
+
+AUG_SIZES = [(224, 224), (37, 53), (1, 1), (228, 228), (64, 64), (5, 200)]
+
+
+@pytest.mark.parametrize("size", AUG_SIZES)
+def test_device_rotation_and_colour_jitter_match_the_oracle_byte_for_byte(size):
+    """csrc/dfd_augment.hip against oracle/image_ref.py (itself pinned against Pillow): rotation modes incl. the 0 / 90 / 180 / 270
+    special cases, every permutation class of the four colour operations, factors below and above 1, disabled operations."""
+    import numpy as np
+
+    from deepfakedetection_amd import data as D
+    from oracle import image_ref as IR
+
+    K = _k()
+    h, w = size
+    rng = np.random.default_rng(h * 1000 + w)
+    n = 26
+    imgs = rng.integers(0, 256, (n, h, w, 3), dtype=np.uint8)
+    imgs[1, : max(1, h // 2)] = 0
+    imgs[2] = 255
+    jobs = np.zeros((n, 16), dtype=np.int32)
+    fl = jobs.view(np.float32)
+    want = []
+    perms = [list(p) for p in __import__("itertools").permutations(range(4))]
+    for i in range(n):
+        angle = [0.0, 180.0, 90.0, 270.0, 45.0, -7.3, 9.99, 0.001][i % 8] if i < 16 else float(rng.uniform(-10, 10))
+        mode, coef = D.rotate_plan(w, h, angle)
+        assert (mode, tuple(coef)) == IR.rotate_plan(w, h, angle)
+        order = perms[i % 24]
+        fb, fc, fs = (float(rng.uniform(0.0, 2.0)) for _ in range(3))
+        dh = float(rng.uniform(-0.5, 0.5))
+        enable = 15 if i % 5 else int(rng.integers(0, 16))
+        jobs[i, 0] = mode; jobs[i, 1:7] = coef; jobs[i, 7:11] = order
+        fl[i, 11], fl[i, 12], fl[i, 13] = fb, fc, fs
+        jobs[i, 14] = IR.hue_delta(dh); jobs[i, 15] = enable
+        # the oracle takes the f32 factors the job carries (the PIL transform hands Blend.c a C float too)
+        ref = IR.rotate(imgs[i], angle)
+        ref = IR.jitter(ref, order, float(fl[i, 11]) if enable & 1 else None, float(fl[i, 12]) if enable & 2 else None,
+                        float(fl[i, 13]) if enable & 4 else None, dh if enable & 8 else None)
+        want.append(ref)
+    got = K.augment_u8(torch.from_numpy(imgs).cuda(), torch.from_numpy(jobs).cuda()).cpu().numpy()
+    for i in range(n):
+        assert np.array_equal(got[i], want[i]), (i, size, int((got[i] != want[i]).sum()), jobs[i].tolist())
+
+
+def test_device_augment_draws_what_the_pil_transforms_draw():
+    """GpuInputTail.sample_augment makes the RNG calls of data.RandomRotation followed by data.ColorJitter, so with one seed the
+    device result equals the PIL pipeline's image exactly (the whole tail: + ToTensor + Normalize)."""
+    import numpy as np
+    from PIL import Image
+
+    from deepfakedetection_amd import data as D
+
+    rng = np.random.default_rng(4)
+    mean, std = [0.485, 0.456, 0.406], [0.229, 0.224, 0.225]
+    tail = D.GpuInputTail(mean, std, rotate_degrees=10.0, jitter=(0.2, 0.2, 0.2, 0.05))
+    rot, cj = D.RandomRotation(10), D.ColorJitter(0.2, 0.2, 0.2, 0.05)
+    for trial in range(6):
+        img = rng.integers(0, 256, (224, 224, 3), dtype=np.uint8)
+        torch.manual_seed(100 + trial); import random; random.seed(100 + trial); np.random.seed(100 + trial)
+        state = torch.get_rng_state()
+        want = D.Normalize(mean, std)(D.ToTensor()(cj(rot(Image.fromarray(img)))))
+        torch.set_rng_state(state); random.seed(100 + trial); np.random.seed(100 + trial)
+        got = tail(torch.from_numpy(img)[None], "cuda").cpu()[0]
+        assert torch.equal(got, want), (trial, float((got - want).abs().max()))
+    big = torch.zeros((1, 300, 300, 3), dtype=torch.uint8)
+    with pytest.raises(RuntimeError, match="DFD_EUNSUPPORTED"):
+        _k().augment_u8(big.cuda(), torch.zeros((1, 16), dtype=torch.int32).cuda())

@@ -273,3 +273,48 @@ def test_rccl_log_summary_never_raises_and_picks_the_decisions(tmp_path):
     assert got["log_lines"] == 5 and got["selected"] == ["RCCL version 2.22.3", "Channel 00/32 : 0 1 2 3 4 5 6 7", "Trees [0] 1/-1/-1->0->-1"]
     assert "note" in rccl_log_summary(str(tmp_path / "missing.log"))
     assert rccl_log_summary(None) is None
+
+
+def test_default_224_training_pipeline_qualifies_for_the_device_path(monkeypatch):
+    """the reference's default toggles at 224 pixels switch rotation AND colour jitter on
+    (/root/reference/trainers/efficientnet.py:134-135); with training.gpu_resize the whole training pipeline must still move to the
+    device (workers decode + plan only, GpuInputTail rotates / jitters), and fall back to PIL for pictures too large for the kernel."""
+    from deepfakedetection_amd import data as D
+    from deepfakedetection_amd.trainers.efficientnet import build_transforms
+
+    monkeypatch.delenv("TRANSFORMS", raising=False)
+    train, val, train_tail, val_tail = build_transforms(224, gpu_tail=True, gpu_resize=True)
+    assert isinstance(train.ops[-1], D.PlanGeometry) and train.ops[-1].mode == "rrc"
+    assert not any(isinstance(op, (D.RandomRotation, D.ColorJitter)) for op in train.ops)
+    assert train_tail.augments and train_tail.rotate_degrees == 10.0 and train_tail.jitter == (0.2, 0.2, 0.2, 0.05)
+    assert train_tail.flip_p == 0.5 and train_tail.erase_p == 0.5 and not val_tail.augments
+    big_train, _, big_tail, _ = build_transforms(300, gpu_tail=True, gpu_resize=True)
+    assert any(isinstance(op, D.RandomRotation) for op in big_train.ops) and any(isinstance(op, D.ColorJitter) for op in big_train.ops)
+    assert not big_tail.augments
+    # the sampler: one 16-int job per picture, rotation plan + permutation + factors inside their ranges
+    import torch
+
+    torch.manual_seed(0)
+    jobs = train_tail.sample_augment(64, 224, 224)
+    assert jobs.shape == (64, 16) and jobs.dtype == torch.int32
+    f = jobs.view(torch.float32)
+    assert set(jobs[:, 0].tolist()) <= {0, 1} and (jobs[:, 15] == 15).all()
+    assert all(sorted(row) == [0, 1, 2, 3] for row in jobs[:, 7:11].tolist())
+    for col in (11, 12, 13):
+        assert float(f[:, col].min()) >= 0.8 and float(f[:, col].max()) <= 1.2
+    dh = jobs[:, 14]
+    assert ((dh <= 13) | (dh >= 243)).all()                     # |0.05 * 255| = 12.75 -> shifts of at most 13 either way, modulo 256
+
+
+def test_rotate_plan_is_the_oracles():
+    import numpy as np
+
+    from deepfakedetection_amd import data as D
+    from oracle import image_ref as IR
+
+    rng = np.random.default_rng(3)
+    for _ in range(200):
+        w, h = int(rng.integers(1, 400)), int(rng.integers(1, 400))
+        a = float(rng.uniform(-400, 400)) if rng.random() < 0.8 else float(rng.choice([0, 90, 180, 270, -90, 360, 450]))
+        assert D.rotate_plan(w, h, a) == IR.rotate_plan(w, h, a)
+        assert D.rotate_plan(h, h, a) == IR.rotate_plan(h, h, a)
