@@ -335,7 +335,11 @@ def main() -> None:
                 if stepper.failed or stepper.step_graph is None:
                     raise RuntimeError("GraphedTrainStep fell back to eager")
                 coll = "rccl" if dist.get_backend() == "nccl" else dist.get_backend()
-                launch = f"hipgraph(fwd+bwd) | {coll} all-reduce | hipgraph(adamw)"
+                if stepper.cut_modules and stepper.segmented_replays:
+                    launch = (f"hipgraph(fwd) | {len(stepper.cut_modules) + 1} x [hipgraph(bwd segment) -> {coll} all-reduce of the buckets it "
+                              f"completed, overlapped with the next segment] | hipgraph(adamw)")
+                else:
+                    launch = f"hipgraph(fwd+bwd) | {coll} all-reduce | hipgraph(adamw)"
         except Exception as exc:  # noqa: BLE001 - any capture failure means: measure eagerly
             if rank == 0:
                 import traceback

@@ -178,9 +178,9 @@ class GradAllReducer:
 
     def arm(self) -> None:
         """The next backward() completes the gradients of this step: let the hooks launch buckets."""
+        self._next = 0
         if self._hooks:
             self._left = [len(b) for b in self.buckets]
-            self._next = 0
             self._armed = True
 
     def detach(self) -> None:
@@ -242,19 +242,36 @@ class GradAllReducer:
                 self._launch(self._next, early=True)
                 self._next += 1
 
+    # ------------------------------------------------------------------ segmented replay (graph_step.GraphedTrainStep)
+    def bucket_needs(self, seg_of: dict[int, int]) -> list[int]:
+        """seg_of: id(parameter) -> index of the backward segment that produces its gradient (higher = runs earlier).  Returns,
+        per bucket, the lowest segment it waits for: the bucket is complete once the segments down to that one have run."""
+        return [min(seg_of[id(p)] for p in bucket) for bucket in self.buckets]
+
+    def begin_cycle(self) -> None:
+        """A replayed backward is about to run segment by segment: buckets will be launched by launch_completed()."""
+        self._next = 0
+
     @torch.no_grad()
-    def finish(self) -> None:
-        """After backward(): launch what the hooks did not (parameters without gradient this step),
-        wait for every bucket, re-point gradients at the reduced flats where a copy was made."""
+    def launch_completed(self, needs: list[int], seg: int) -> None:
+        """Backward segments down to `seg` have been enqueued: launch, in index order, every bucket they complete — its all-reduce
+        then runs on RCCL's stream beside the segments still to come (the overlap a single replayed graph cannot give)."""
         if self.world == 1:
             return
-        if not self._hooks or not self._armed:
-            self.reduce()
+        while self._next < len(self.buckets) and needs[self._next] >= seg:
+            self._launch(self._next, early=True)
+            self._next += 1
+
+    @torch.no_grad()
+    def finish(self) -> None:
+        """After backward(): launch what the hooks / the segment loop did not (parameters without gradient this step, the
+        first segment's buckets), wait for every bucket, re-point gradients at the reduced flats where a copy was made."""
+        if self.world == 1:
             return
         self._armed = False
         for b in range(self._next, len(self.buckets)):
             self._launch(b, early=False)
-        self._next = len(self.buckets)
+        self._next = 0
         self._drain()
 
     def _drain(self) -> None:
@@ -271,12 +288,11 @@ class GradAllReducer:
     # ------------------------------------------------------------------ one-shot path
     @torch.no_grad()
     def reduce(self) -> None:
-        """Sum the gradients over ranks, in place of each parameter's .grad."""
+        """Sum the gradients over ranks, in place of each parameter's .grad (every bucket, in index order, at once)."""
         if self.world == 1:
             return
-        for b in range(len(self.buckets)):
-            self._launch(b, early=False)
-        self._drain()
+        self._next = 0
+        self.finish()
 
 
 class ShardedSampler:

@@ -310,6 +310,10 @@ class HipEfficientFormerV2(nn.Module):
             cur = self.__dict__["_rng_obj"] = K.DeviceRng(device)
         return cur
 
+    def dp_cut_modules(self) -> list[nn.Module]:
+        """Where a replayed data-parallel backward may be cut into segments (graph_step.plan_cuts): the four stages."""
+        return list(self.stages)
+
     def forward_features_nhwc(self, x: torch.Tensor, counters: list | None = None) -> torch.Tensor:
         if not x.is_cuda:
             raise RuntimeError("HipEfficientFormerV2 runs on a HIP device only (no CPU fallback); move the input with .to('cuda')")

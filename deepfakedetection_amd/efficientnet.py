@@ -228,6 +228,11 @@ class HipEfficientNet(nn.Module):
             cur = self.__dict__["_rng_obj"] = K.DeviceRng(device)
         return cur
 
+    def dp_cut_modules(self) -> list[nn.Module]:
+        """Modules after which a replayed data-parallel backward may be cut into segments (graph_step.plan_cuts): the MBConv blocks —
+        one tensor in, one tensor out, in forward order."""
+        return list(self.block_list())
+
     def forward_features_nhwc(self, x: torch.Tensor, drop_masks=None, counters: list | None = None) -> torch.Tensor:
         stem, stem_bn, blocks, _, _, _ = self._parts()
         if not x.is_cuda:

@@ -439,6 +439,11 @@ class HipFasterViT(nn.Module):
             table.update({w.data_ptr(): pair for w, pair in zip(fp8, cache.out)})
         return table
 
+    def dp_cut_modules(self) -> list[nn.Module]:
+        """Where a replayed data-parallel backward may be cut into segments (graph_step.plan_cuts): the four levels (one tensor in,
+        one tensor out; the blocks inside levels 2-3 carry a (windows, carrier tokens) pair and are not cut points)."""
+        return list(self.levels)
+
     def _forward(self, x: torch.Tensor) -> torch.Tensor:
         if x.shape[2] != self.resolution or x.shape[3] != self.resolution:
             raise ValueError(f"FasterViT was built for {self.resolution}x{self.resolution} inputs, got {tuple(x.shape[2:])}")

@@ -22,9 +22,18 @@ behave identically with GRAPH_STEP=0.  Everything random in the step (dropout, d
 Philox kernels whose state advances on the device (kernels.DeviceRng), so replays draw fresh numbers.
 
 Data parallel (`reducer`, dp.GradAllReducer): eager micro-batches that complete a cycle arm the reducer's hooks, so
-their buckets leave from inside backward; after replayed micro-batches the flat arena is reduced in place in bucket-sized
-chunks.  Either way `optimizer_step()` waits for the exchange and then runs (replays) AdamW with grad_scale = 1/world —
-bench.py --gpus N and the trainers drive this same object.
+their buckets leave from inside backward.  A REPLAYED micro-batch that completes a cycle is captured as SEVERAL graphs —
+forward, then the backward cut into segments at module outputs chosen from the model's `dp_cut_modules()` so that every
+gradient bucket becomes complete at the end of a segment — and replayed segment by segment: after each one the buckets
+it completed are handed to RCCL, whose all-reduce runs on its own stream beside the segments still to come (VERDICT r3
+item 6: one graph for the whole backward left the exchange un-overlapped — harmless for EfficientNet-B0's 16 MB, not for
+FasterViT-0's 125 MB).  The cut is a forward hook that replaces a module's output by a detached leaf; the segments are
+`loss.backward()` and then `output.backward(leaf.grad)` back to front — the same kernels in the same order as one
+backward, so the result equals the eager step bit for bit.  (HIP 7.2 rejects external event-record nodes under stream
+capture — scripts/probes/external_event_probe.py — so "one graph + events" is not available.)  Models without
+`dp_cut_modules()` keep the single graph and the one-shot exchange after it.  Either way `optimizer_step()` waits for
+the exchange and then runs (replays) AdamW with grad_scale = 1/world — bench.py --gpus N and the trainers drive this
+same object.
 
 By-address hazards.  A graph records raw addresses.  Every tensor whose address reached the library during a capture
 is journalled (kernels.capture_journal); the ones owned by something outside the captured body (parameters, buffers,
@@ -54,6 +63,56 @@ def _check_guard(guard, what: str) -> None:
                               "rebuild the GraphedTrainStep / GraphedForward after moving or re-creating model state")
 
 
+class _Cuts:
+    """While active, the chosen modules' outputs are replaced by detached leaves: (output, leaf) pairs in forward order."""
+
+    def __init__(self, modules) -> None:
+        self.modules, self.pairs, self._handles = list(modules), [], []
+
+    def _hook(self, module, inputs, output):
+        if not isinstance(output, torch.Tensor) or not output.requires_grad:
+            return None
+        leaf = output.detach().requires_grad_(True)
+        self.pairs.append((output, leaf))
+        return leaf
+
+    def __enter__(self):
+        self._handles = [m.register_forward_hook(self._hook) for m in self.modules]
+        return self
+
+    def __exit__(self, *exc) -> None:
+        for h in self._handles:
+            h.remove()
+        self._handles = []
+
+
+def plan_cuts(model: torch.nn.Module, reducer) -> tuple[list, dict[int, int]]:
+    """(modules to cut after, id(parameter) -> backward segment index) so that each gradient bucket of `reducer` is complete
+    at the end of one segment.  Candidates come from model.dp_cut_modules() (forward order, single-tensor outputs); parameters are
+    taken in registration order, which is the forward order for the engine's models (the reducer's buckets rely on it too).
+    Segment s holds the parameters between cut s and cut s + 1; the backward runs the segments from the highest down."""
+    cands = list(getattr(model, "dp_cut_modules", lambda: [])())
+    params = [p for p in model.parameters() if p.requires_grad]
+    index = {id(p): i for i, p in enumerate(params)}
+    if not cands or reducer is None or len(reducer.buckets) < 2:
+        return [], {id(p): 0 for p in params}
+    # position of a candidate: one past the last parameter registered inside it (or before it)
+    pos = []
+    for m in cands:
+        inside = [index[id(p)] for p in m.parameters() if id(p) in index]
+        pos.append(max(inside) + 1 if inside else 0)
+    chosen: list[int] = []
+    for bucket in reducer.buckets[:-1]:                          # the last bucket ends at parameter 0: nothing left to overlap
+        lo = min(index[id(p)] for p in bucket)
+        best = max((j for j in range(len(cands)) if 0 < pos[j] <= lo), key=lambda j: pos[j], default=None)
+        if best is not None and best not in chosen:
+            chosen.append(best)
+    chosen.sort()
+    cut_pos = [pos[j] for j in chosen]
+    seg_of = {id(p): sum(1 for c in cut_pos if c <= i) for p, i in ((p, index[id(p)]) for p in params)}
+    return [cands[j] for j in chosen], seg_of
+
+
 class GraphedTrainStep:
     MAX_SHAPES = 4
 
@@ -71,6 +130,13 @@ class GraphedTrainStep:
         self.eager_cycles = eager_cycles
         self.replays = 0
         self.reducer = reducer if (reducer is not None and getattr(reducer, "world", 1) > 1) else None
+        self.cut_modules, self.needs = [], []
+        if self.reducer is not None and os.environ.get("DFD_DP_SEGMENTS", "1") != "0":
+            self.cut_modules, seg_of = plan_cuts(model, self.reducer)
+            if self.cut_modules:
+                params = {id(p) for b in self.reducer.buckets for p in b}
+                self.needs = self.reducer.bucket_needs({k: v for k, v in seg_of.items() if k in params})
+        self.segmented_replays = 0
 
     # ------------------------------------------------------------------ the loop body (eager, and what gets captured)
     def _fwd_bwd(self, x, y, first: bool, arm: bool = False) -> torch.Tensor:
@@ -84,6 +150,34 @@ class GraphedTrainStep:
             self.reducer.arm()          # eager backward that completes the cycle: buckets leave as they fill
         loss.backward()
         return loss.detach()
+
+    def _capture_segments(self, sx, sy, first: bool):
+        """forward | backward of the last segment | ... | backward of the first segment, one hipGraph each (one shared pool: they are
+        replayed in this order, so memory freed by one and reused by the next is reused in the same order at replay)."""
+        graphs = []
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, pool=self.pool, capture_error_mode="thread_local"):
+            if first:
+                self.opt.zero_grad(set_to_none=True)
+            with _Cuts(self.cut_modules) as cuts:
+                with torch.autocast(device_type="cuda", dtype=torch.bfloat16, enabled=self.use_amp):
+                    loss = self.criterion(self.model(sx), sy)
+                    if self.accum > 1:
+                        loss = loss / self.accum
+        graphs.append(g)
+        if len(cuts.pairs) != len(self.cut_modules):
+            raise RuntimeError(f"{len(self.cut_modules)} cut modules produced {len(cuts.pairs)} cuts (a module ran twice, or returned no tensor)")
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, pool=self.pool, capture_error_mode="thread_local"):
+            loss.backward()
+        graphs.append(g)
+        for out, leaf in reversed(cuts.pairs):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=self.pool, capture_error_mode="thread_local"):
+                out.backward(leaf.grad)
+            graphs.append(g)
+        self._seg_keep = getattr(self, "_seg_keep", []) + [cuts.pairs]      # the leaves and their .grad tensors are graph memory in use
+        return graphs, loss.detach()
 
     def _graphable(self, x: torch.Tensor) -> bool:
         if self.failed or not x.is_cuda:
@@ -107,7 +201,8 @@ class GraphedTrainStep:
         last = self.accum == 1 if last is None else last
         if not self._graphable(x):
             return self._fwd_bwd(x, y, first, arm=last)
-        key = (tuple(x.shape), x.dtype, tuple(y.shape), "first" if first else "next")
+        segmented = bool(self.cut_modules) and last
+        key = (tuple(x.shape), x.dtype, tuple(y.shape), "first" if first else "next", segmented)
         entry = self.graphs.get(key)
         if entry is None:
             fresh = key not in self.seen
@@ -119,10 +214,13 @@ class GraphedTrainStep:
                     self.pool = torch.cuda.graph_pool_handle()
                 sx, sy = x.clone(), y.clone()
                 torch.cuda.synchronize()
-                g = torch.cuda.CUDAGraph()
                 with K.capture_journal() as notes:
-                    with torch.cuda.graph(g, pool=self.pool, capture_error_mode="thread_local"):
-                        sloss = self._fwd_bwd(sx, sy, first)
+                    if segmented:
+                        g, sloss = self._capture_segments(sx, sy, first)
+                    else:
+                        g = torch.cuda.CUDAGraph()
+                        with torch.cuda.graph(g, pool=self.pool, capture_error_mode="thread_local"):
+                            sloss = self._fwd_bwd(sx, sy, first)
                 # after the capture every trainable parameter's .grad IS its arena slot; a replay rewrites the slots but
                 # cannot re-attach them if Python code in between (zero_grad(set_to_none=True) at the start of an epoch)
                 # dropped the references, so the views are kept and re-attached after each replay
@@ -136,7 +234,18 @@ class GraphedTrainStep:
         _check_guard(guard, "training-step graph")
         sx.copy_(x, non_blocking=True)
         sy.copy_(y, non_blocking=True)
-        g.replay()
+        if isinstance(g, list):
+            # forward, then the backward segments from the back; behind each one the buckets it completed start their exchange
+            self.reducer.begin_cycle()
+            g[0].replay()
+            top = len(g) - 2                                    # segment index of the first backward graph
+            for j, seg_graph in enumerate(g[1:]):
+                seg_graph.replay()
+                if j < top:                                     # (the buckets of the last segment leave in optimizer_step -> finish())
+                    self.reducer.launch_completed(self.needs, top - j)
+            self.segmented_replays += 1
+        else:
+            g.replay()
         self.replays += 1
         if views and views[0][0].grad is None:
             for p, gv in views:

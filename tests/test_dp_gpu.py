@@ -119,7 +119,8 @@ def _graph_worker(rank: int, world: int, port: int, accum: int) -> None:
         batches = [(torch.randn(8, 3, 64, 64, generator=g).to(dev).contiguous(memory_format=torch.channels_last),
                     torch.randint(0, 2, (8,), generator=g).to(dev)) for _ in range(cycles * accum)]
 
-        def run(graph: bool):
+        def run(graph: bool, segments: bool = True):
+            os.environ["DFD_DP_SEGMENTS"] = "1" if segments else "0"
             torch.manual_seed(10 + rank)                             # different init: broadcast must fix it
             model = HipEfficientNet("b0", "timm", 2).to(dev).train()
             broadcast_module_state(model)
@@ -139,11 +140,17 @@ def _graph_worker(rank: int, world: int, port: int, accum: int) -> None:
             return model, step, red
 
         m_e, _, red_e = run(False)
-        m_g, step, _ = run(True)
+        m_g, step, red_g = run(True)
+        m_1, step1, _ = run(True, segments=False)
         assert red_e.launched_early > 0, "eager DP: no bucket left from inside backward"
         assert not step.failed and step.step_graph is not None and step.replays == (cycles - 1) * accum, step.replays
-        for (name, a), (_, b) in zip(m_e.state_dict().items(), m_g.state_dict().items()):
-            assert torch.equal(a, b), f"graphed DP differs from eager DP at {name}"
+        # the replayed backward that completes a cycle ran as segments, and buckets left between them (overlap under replay)
+        assert len(step.cut_modules) >= 2 and step.segmented_replays == cycles - 1, (len(step.cut_modules), step.segmented_replays)
+        assert red_g.launched_early >= (cycles - 1) * 2, red_g.launched_early
+        assert not step1.cut_modules and step1.segmented_replays == 0 and step1.replays == (cycles - 1) * accum
+        for (name, a), (_, b), (_, c) in zip(m_e.state_dict().items(), m_g.state_dict().items(), m_1.state_dict().items()):
+            assert torch.equal(a, b), f"graphed (segmented) DP differs from eager DP at {name}"
+            assert torch.equal(a, c), f"graphed (single graph) DP differs from eager DP at {name}"
         flat = torch.cat([p.detach().flatten() for p in m_g.parameters()])
         parts = [torch.zeros_like(flat) for _ in range(world)]
         dist.all_gather(parts, flat)
