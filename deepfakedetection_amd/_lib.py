@@ -82,6 +82,7 @@ SIGNATURES: dict[str, tuple] = {
     "dfd_pwconv_fwd": (c_int, [c_int, P, POINTER(Prologue), P, P, P, c_int, c_int, c_int, P, c_int, _PI, P]),
     "dfd_pwconv_wgrad": (c_int, [c_int, P, POINTER(Prologue), c_int, P, POINTER(Prologue), c_int, c_int, P, c_int, P, c_size_t, P]),
     "dfd_pwconv_wgrad_ws": (c_size_t, [c_int, c_int, c_int]),
+    "dfd_pwconv_bwd_fused": (c_int, [c_int, P, P, P, P, P, P, c_int, c_int, c_int, P, P, c_int, P, c_size_t, P]),
     "dfd_pw_prep_weights": (c_int, [c_int, P, P, P, c_int, c_int, P]),
     "dfd_stem_conv_fwd": (c_int, [c_int, P, P, P, POINTER(StemShape), P, c_int, _PI, P]),
     "dfd_stem_conv_wgrad": (c_int, [c_int, P, P, P, P, P, POINTER(StemShape), c_int, P, c_size_t, P]),

@@ -15,6 +15,14 @@
 //     wave order (fixed order: reproducible) and the workgroup writes ONE partial slab, summed over
 //     workgroups by the same two-stage k_sum_partials as the tiled kernel.
 // Either operand may be the first GEMM operand: `swap` writes the slab transposed.
+//
+// DG (round 4): the EXPAND layer's backward in one pass.  Its weight gradient dW = d^T x and its data gradient dx = d W (+ skip)
+// both start from d = a * dz + b * y + c, the BN-backward map of two [M][Cmid] tensors — the widest tensors of the network —
+// and as two kernels each of them read that pair (blocks 1-3: 2 x 1.1 GB per step).  Here the wave that has just written its rows
+// of d into its private tile for the transposed weight-gradient reads also multiplies them (plain 16-byte reads of the same tile,
+// rows as the MFMA's N index) with the layer's [Cin][Cmid] weight, resident in LDS, and stores its rows of dx as 8-byte pieces
+// (a lane's accumulator = 4 consecutive input channels of one row; 16 rows x Cin channels are contiguous in memory).  Same
+// d values, same MFMA instruction and K order as dfd_pwntw.hip's data-gradient kernel: identical bits.
 #include "dfd_pw.h"
 
 // rows per wave step: 32 (v_mfma_f32_16x16x32_bf16) or, for the widest outputs where the accumulators
@@ -22,10 +30,12 @@
 #define TNW_MIN_ROWS 16
 
 // PA: prologue of the narrow operand (NONE / AFFINE2); PB: of the wide one (NONE / AFFINE2 / BN_ACT_GATE)
-template <int ROWS, int NA, int NBT, int PA, int PB, int ACT>
+// DG: 0 weight gradient only; 1 also dx[M][Na] = B(b) w^T (w_kn = [Na][Nb] in bf16); 2 the same plus a residual added to dx
+template <int ROWS, int NA, int NBT, int PA, int PB, int ACT, int DG = 0>
 __global__ void __launch_bounds__(DFD_THREADS, 2)
 k_pw_tnw(const bf16* __restrict__ a, ProArgs pa, int Na, const bf16* __restrict__ b, ProArgs pb, int Nb, int M,
-         int rows_per_block, int swap, float* __restrict__ ws) {
+         int rows_per_block, int swap, float* __restrict__ ws, const bf16* __restrict__ w_kn = nullptr,
+         const bf16* __restrict__ res = nullptr, bf16* __restrict__ dx = nullptr, int wstride = 0, int woff = 0) {
     constexpr int ITA = (ROWS * NA * 2 + 63) / 64;          // 16-byte items per lane and step
     constexpr int ITB = (ROWS * NBT * 2 + 63) / 64;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -52,6 +62,17 @@ k_pw_tnw(const bf16* __restrict__ a, ProArgs pa, int Na, const bf16* __restrict_
     // chunks past the operand's width are never written: clear the tiles once so that partly valid
     // 16-wide MFMA tiles read zeros there
     for (int i = t; i < 4 * 2 * ROWS * 256 / 16; i += DFD_THREADS) reinterpret_cast<uint4*>(smem)[i] = make_uint4(0, 0, 0, 0);
+    if constexpr (DG) {
+        // the layer's weight as the data gradient's A operand: NA * 16 rows (input channels) x Nb (zero padded to the row stride),
+        // row stride = 64-byte k-steps + 16 so that the 16 rows of a fragment read land on different bank groups
+        const int chunks = wstride >> 4;
+        for (int i = t; i < NA * 16 * chunks; i += DFD_THREADS) {
+            const int r = i / chunks, c = i - r * chunks;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (r < Na && c < cb) v = *reinterpret_cast<const uint4*>(w_kn + (long)r * Nb + c * 8);
+            *reinterpret_cast<uint4*>(smem + woff + r * wstride + c * 16) = v;
+        }
+    }
     __syncthreads();
 
     // item -> (row, chunk) of this lane, fixed for the whole kernel
@@ -77,6 +98,8 @@ k_pw_tnw(const bf16* __restrict__ a, ProArgs pa, int Na, const bf16* __restrict_
 #pragma unroll
         for (int y = 0; y < NBT; ++y) acc[x][y] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
     const int na = (Na + 15) >> 4, nbt = (Nb + 15) >> 4;        // valid 16-wide tiles
+    constexpr int RT = ROWS / 16;                               // 16-row tiles of a step (the data gradient's N tiles)
+    f32x4_t accd[DG ? NA : 1][RT];
 
     const int rows_per_wave = rows_per_block / 4;
     const int mbeg = blockIdx.x * rows_per_block + wave * rows_per_wave;
@@ -212,6 +235,12 @@ k_pw_tnw(const bf16* __restrict__ a, ProArgs pa, int Na, const bf16* __restrict_
                 wave_sync();
             }
         }
+        if constexpr (DG) {
+#pragma unroll
+            for (int x = 0; x < NA; ++x)
+#pragma unroll
+                for (int j = 0; j < RT; ++j) accd[x][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        }
         s_store_a(m0);
         s_store_b(m0, 0, std::integral_constant<bool, NGRP == 1>{});
         wave_sync();
@@ -233,6 +262,53 @@ k_pw_tnw(const bf16* __restrict__ a, ProArgs pa, int Na, const bf16* __restrict_
                 for (int x = 0; x < NA; ++x)
                     if (x < na)
                         acc[x][y] = mma(fa[x], fb, acc[x][y]);
+            }
+            if constexpr (DG) {
+                // data gradient over this group's channels: k-steps of 32 channels = 4 chunks; a lane's B fragment is chunk
+                // 4 ks + (lane >> 4) of row (lane & 15) of the tile, as stored (no transpose), zero past the operand's width
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {                                            // a group = 128 channels = 4 k-steps
+                    if (grp * 8 + 2 * ks >= NBT || grp * 8 + 2 * ks >= nbt) continue;
+                    const int chl = 4 * ks + g, chg = grp * 16 + chl;                       // chunk inside the tile / the operand
+                    uint4 fd[RT];
+#pragma unroll
+                    for (int j = 0; j < RT; ++j) {
+                        fd[j] = *reinterpret_cast<const uint4*>(bt + tn_off_bf16(j * 16 + li, chl));
+                        if (chg >= cb) fd[j] = make_uint4(0, 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int x = 0; x < NA; ++x) {
+                        if (x >= na) continue;
+                        const uint4 fw = *reinterpret_cast<const uint4*>(smem + woff + (x * 16 + li) * wstride + chg * 16);
+#pragma unroll
+                        for (int j = 0; j < RT; ++j)
+                            accd[x][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, fw), __builtin_bit_cast(bf16x8_t, fd[j]),
+                                                                               accd[x][j], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        if constexpr (DG) {
+            // dx rows of this step: lane (row li of tile j, input channels 16 x + 4 g .. + 3); rounded to bf16 as the NT kernel rounds
+            // (through its LDS patch) before the skip connection's gradient is added, then rounded again
+#pragma unroll
+            for (int j = 0; j < RT; ++j) {
+                const int m = m0 + j * 16 + li;
+#pragma unroll
+                for (int x = 0; x < NA; ++x) {
+                    const int ci = x * 16 + 4 * g;
+                    if (x < na && m < mend && ci < Na) {
+                        float v[4];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = round_to<bf16>(accd[x][j][r]);
+                        if constexpr (DG == 2) {
+                            const uint2 rq = *reinterpret_cast<const uint2*>(res + (long)m * Na + ci);
+                            v[0] = round_to<bf16>(v[0] + __uint_as_float(rq.x << 16)); v[1] = round_to<bf16>(v[1] + __uint_as_float(rq.x & 0xffff0000u));
+                            v[2] = round_to<bf16>(v[2] + __uint_as_float(rq.y << 16)); v[3] = round_to<bf16>(v[3] + __uint_as_float(rq.y & 0xffff0000u));
+                        }
+                        *reinterpret_cast<uint2*>(dx + (long)m * Na + ci) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+                    }
+                }
             }
         }
         wave_sync();                                    // reads done before the next step's stores
@@ -315,6 +391,48 @@ static int tnw_launch(const void* a, const dfd_prologue* pro_a, int Na, const vo
 #undef LAUNCH_TNW
     if (hipGetLastError() != hipSuccess) return DFD_ELAUNCH;
     return dfd_launch_sum_partials(ws, nblocks, (long)Na * Nb, dw, accumulate, st);
+}
+
+// Expand layer backward in one pass (kernel comment, DG): x [M][Cin] narrow and plain, (dz, y) [M][Cm] wide with the BN-backward map;
+// dw [Cm][Cin] (the layer's weight layout), dx [M][Cin].  DFD_EUNSUPPORTED: shapes the wave-autonomous kernel does not hold.
+template <int ROWS, int NA, int NBT>
+static int tnw_dg_launch(const void* x, int Cin, const void* dz, const dfd_prologue* pro_d, int Cm, const void* w_kn, const void* residual,
+                         int M, void* dx, float* dw, int accumulate, float* ws, size_t ws_bytes, hipStream_t st) {
+    const ProArgs pa = pro_args(nullptr), pb = pro_args(pro_d);
+    int nblocks = 512;
+    int rpb = (M + nblocks - 1) / nblocks;
+    rpb = (rpb + 4 * ROWS - 1) / (4 * ROWS) * (4 * ROWS);
+    nblocks = (M + rpb - 1) / rpb;
+    if ((size_t)(nblocks + nblocks / 32 + 2) * Cin * Cm * 4 > ws_bytes) return DFD_EUNSUPPORTED;
+    const int wstride = (Cm + 31) / 32 * 64 + 16;
+    int woff = 4 * 2 * ROWS * 256 + 3 * (Cin + Cm) * 4;
+    woff = (woff + 15) / 16 * 16;
+    const int lds = woff + NA * 16 * wstride;
+    if (lds > 80 * 1024) return DFD_EUNSUPPORTED;               // two workgroups per CU
+    struct TnwDgTag;
+    dfd_allow_lds_once<TnwDgTag>(k_pw_tnw<ROWS, NA, NBT, DFD_PRO_NONE, DFD_PRO_AFFINE2, DFD_ACT_NONE, 2>, 80 * 1024);
+    dfd_allow_lds_once<TnwDgTag>(k_pw_tnw<ROWS, NA, NBT, DFD_PRO_NONE, DFD_PRO_AFFINE2, DFD_ACT_NONE, 1>, 80 * 1024);
+    if (residual)
+        hipLaunchKernelGGL((k_pw_tnw<ROWS, NA, NBT, DFD_PRO_NONE, DFD_PRO_AFFINE2, DFD_ACT_NONE, 2>), dim3(nblocks), dim3(DFD_THREADS), lds, st,
+                           (const bf16*)x, pa, Cin, (const bf16*)dz, pb, Cm, M, rpb, 1, ws, (const bf16*)w_kn, (const bf16*)residual, (bf16*)dx,
+                           wstride, woff);
+    else
+        hipLaunchKernelGGL((k_pw_tnw<ROWS, NA, NBT, DFD_PRO_NONE, DFD_PRO_AFFINE2, DFD_ACT_NONE, 1>), dim3(nblocks), dim3(DFD_THREADS), lds, st,
+                           (const bf16*)x, pa, Cin, (const bf16*)dz, pb, Cm, M, rpb, 1, ws, (const bf16*)w_kn, (const bf16*)nullptr, (bf16*)dx,
+                           wstride, woff);
+    if (hipGetLastError() != hipSuccess) return DFD_ELAUNCH;
+    return dfd_launch_sum_partials(ws, nblocks, (long)Cin * Cm, dw, accumulate, st);
+}
+extern "C" int dfd_pwconv_bwd_fused(int dtype, const void* dz, const void* y, const float* coef, const void* x, const void* w_kn,
+                                    const void* residual, int M, int Cm, int Cin, void* dx, float* dw, int accumulate, float* ws,
+                                    size_t ws_bytes, dfd_stream stream) {
+    if (!dz || !y || !coef || !x || !w_kn || !dx || !dw || !ws || M < 1 || Cm < 8 || Cin < 8 || Cm % 8 || Cin % 8) return DFD_EINVAL;
+    if (dtype != DFD_BF16 || M < 2048 * 32 * 3 || Cin > 32 || Cin > Cm || !(Cm <= 128 || (Cm <= 144 && Cm % 16 == 0))) return DFD_EUNSUPPORTED;
+    dfd_prologue pro{};
+    pro.mode = DFD_PRO_AFFINE2; pro.act = DFD_ACT_NONE; pro.HW = 1; pro.a2 = y; pro.coef = coef; pro.gate = nullptr;
+    hipStream_t st = (hipStream_t)stream;
+    if (Cm <= 96) return tnw_dg_launch<32, 2, 6>(x, Cin, dz, &pro, Cm, w_kn, residual, M, dx, dw, accumulate, ws, ws_bytes, st);
+    return tnw_dg_launch<16, 2, 9>(x, Cin, dz, &pro, Cm, w_kn, residual, M, dx, dw, accumulate, ws, ws_bytes, st);
 }
 
 int dfd_pw_tnw(const void* p, const dfd_prologue* pro_p, int Ni, const void* q, const dfd_prologue* pro_q, int Nj, int M,

@@ -312,13 +312,19 @@ class MBConvFunction(torch.autograd.Function):
             coef1, dg_exp, db_exp = K.bn_bwd_finalize(parts, n, N * H * W, g_exp, st1, tr, need[2] or need[3],
                                                       _dest(ctx, 2, (Cmid,)), _dest(ctx, 3, (Cmid,)))
             pro_dy1 = K.pro_affine2(y1, coef1)
+            # blocks 1-3: data and weight gradient of the expand layer from ONE pass over (dz1, y1), the widest tensors of the
+            # network (csrc/dfd_pwtnw.hip, DG) — bit-identical to the two kernels below
+            both = K.pwconv_bwd_fused(dz1, y1, coef1, x, wexp_kn, g if cfg.skip else None, _dest(ctx, 1, (Cmid, Cin))) \
+                if (need[0] and need[1] and K.pwconv_bwd_fused_ok(dz1, x)) else None
             with K.side_stream(N * Ho * Wo):
                 if need[4] and not fused:
                     dw_dw = K.dwconv_bwd_weight(dz2, y2, coef2, y1, st1, ACT_SILU, geom.kernel, geom.stride,
                                                 geom.pad_lead, geom.pad_lead, _dest(ctx, 4, (Cmid, 1, kk, kk)))
-                if need[1]:
+                if need[1] and both is None:
                     dw_exp = K.pwconv_wgrad(dz1, pro_dy1, x, None, _dest(ctx, 1, (Cmid, Cin))).view(Cmid, Cin, 1, 1)
-            if need[0]:
+            if both is not None:
+                dx, dw_exp = both[0], both[1].view(Cmid, Cin, 1, 1)
+            elif need[0]:
                 dx, _, _ = K.pwconv(dz1, pro_dy1, wexp_kn, g if cfg.skip else None, stats=False)
         else:
             if need[4]:

@@ -986,6 +986,36 @@ def pwconv_wgrad(p: torch.Tensor, pro_p: Prologue | None, q: torch.Tensor, pro_q
     return dw
 
 
+_FUSE_EXPAND_BWD = os.environ.get("DFD_FUSE_EXPAND_BWD", "1") != "0"      # A/B switch
+
+
+def pwconv_bwd_fused_ok(dz: torch.Tensor, x: torch.Tensor) -> bool:
+    """Shapes dfd_pwconv_bwd_fused serves (include/dfd_hip.h).  Asked BEFORE the caller takes the weight gradient's arena slot:
+    a slot handed to a call that then declines would be lost to the fallback (its gradient would land outside the arena)."""
+    Cm, Cin = dz.shape[-1], x.shape[-1]
+    M = dz.numel() // Cm
+    return (_FUSE_EXPAND_BWD and dz.dtype == torch.bfloat16 and M >= 2048 * 32 * 3 and Cin <= 32 and Cin <= Cm and Cin % 8 == 0
+            and (Cm <= 128 or (Cm <= 144 and Cm % 16 == 0)) and Cm % 8 == 0)
+
+
+def pwconv_bwd_fused(dz: torch.Tensor, y: torch.Tensor, coef: torch.Tensor, x: torch.Tensor, w_kn: torch.Tensor,
+                     residual: torch.Tensor | None, out_w: torch.Tensor | None = None):
+    """The expand layer's data AND weight gradient from one pass over (dz, y) (csrc/dfd_pwtnw.hip, DG): returns (dx, dw [Cm, Cin])
+    or None when the shape is not the fused kernel's (the caller runs pwconv + pwconv_wgrad; see pwconv_bwd_fused_ok)."""
+    if not pwconv_bwd_fused_ok(dz, x):
+        return None
+    Cm, Cin = dz.shape[-1], x.shape[-1]
+    M = dz.numel() // Cm
+    nbytes = _L().dfd_pwconv_wgrad_ws(M, Cm, Cin)
+    ws = scratch(dz.device, "wgrad_ws", nbytes)
+    dx = torch.empty_like(x)
+    dw = _dst(None if out_w is None else out_w.view(Cm, Cin), (Cm, Cin), dz.device)
+    rc = _L().dfd_pwconv_bwd_fused(_dt(dz), _p(dz), _p(y), _p(coef), _p(x), _p(w_kn), _p(residual), M, Cm, Cin, _p(dx), _p(dw), 0,
+                                   _p(ws), ws.numel() * 4, _stream())
+    check(rc, "dfd_pwconv_bwd_fused", f"M={M} Cm={Cm} Cin={Cin}")       # (declining here would have cost the caller its arena slot)
+    return dx, dw
+
+
 # ------------------------------------------------------------------ stem
 def _stem_shape(x_shape, Cout: int, Ho: int, Wo: int, k: int, stride: int, pt: int, pl: int) -> StemShape:
     N, H, W, _ = x_shape
@@ -1485,7 +1515,7 @@ class DeviceRng:
 # the DESIGN.md per-kernel figure, not counter traffic.
 _profile_sink: list | None = None
 _TIMED = ("bn_act_apply", "bn_bwd_reduce", "act_bn_bwd", "pool_act", "pool_bwd_reduce", "scale_rows", "dwconv_fwd",
-          "dwconv_bwd_data", "dwconv_bwd_weight", "dwconv_bwd_fused", "pwconv", "pwconv_wgrad", "stem_conv_fwd", "stem_conv_wgrad",
+          "dwconv_bwd_data", "dwconv_bwd_weight", "dwconv_bwd_fused", "pwconv", "pwconv_wgrad", "pwconv_bwd_fused", "stem_conv_fwd", "stem_conv_wgrad",
           "se_fc_fwd", "se_fc_bwd", "linear_fwd", "linear_bwd", "ce_loss", "adamw_step", "prep_weights", "bn_finalize",
           "bn_bwd_finalize", "bn_bwd_finalize_ex", "dropout", "bgemm", "attn_softmax_fwd", "attn_softmax_bwd", "im2col", "col2im",
           "wattn_fwd", "wattn_bwd", "mx_quant_rows", "mx_gemm",
@@ -1517,6 +1547,9 @@ def _flops(name: str, args) -> float:
     if name == "pwconv_wgrad":
         p, q = args[0], args[2]
         return 2.0 * (p.numel() // p.shape[-1]) * p.shape[-1] * q.shape[-1]
+    if name == "pwconv_bwd_fused":                           # data gradient + weight gradient
+        dz, x = args[0], args[3]
+        return 4.0 * (dz.numel() // dz.shape[-1]) * dz.shape[-1] * x.shape[-1]
     return 0.0
 
 
@@ -1538,6 +1571,12 @@ def _bytes_8d(name: str, args, fallback: int) -> int:
             p, q = args[0], args[2]
             M = p.numel() // p.shape[-1]
             return M * (p.shape[-1] + q.shape[-1]) * p.element_size() + p.shape[-1] * q.shape[-1] * 4
+        if name == "pwconv_bwd_fused":
+            # the TWO ops it replaces, each with its own 8(d) bytes (the kernel moves the shared operands once: that is the point)
+            dz, x = args[0], args[3]
+            Cm, Cin, es = dz.shape[-1], x.shape[-1], dz.element_size()
+            M = dz.numel() // Cm
+            return 2 * M * (Cm + Cin) * es + Cm * Cin * (es + 4)
         if name == "dwconv_fwd":
             x, k, Ho, Wo = args[0], args[4], args[8], args[9]
             N, H, W, C = x.shape

@@ -74,7 +74,8 @@ typedef void* dfd_stream;          /* a hipStream_t */
  * 120 = MX fp8 weights (dfd_mx_*), fused window attention on bf16 MFMA (dfd_wattn_*),
  * batched coordinate MLPs (dfd_coord_mlp_*_multi, dfd_relpos_bias_*_multi), dfd_dwconv_bwd_fused, dfd_resize_crop_u8;
  * 121 = dfd_bias_grad / dfd_bias_grad_ws; 122 = dfd_gemm_bias_act;
- * 130 = dfd_tune; the bf16 depthwise entry points run on the matrix cores where the shape allows (same signatures). */
+ * 130 = dfd_tune; the bf16 depthwise entry points run on the matrix cores where the shape allows (same signatures);
+ * 131 = dfd_augment_u8, dfd_gemm_plan, dfd_dw_mm_plan, dfd_pwconv_bwd_fused. */
 int dfd_version(void);
 
 /* Planner knobs (A/B switches and sizes the host-side kernel selection reads).  Process-wide plain ints: set them once at
@@ -313,6 +314,16 @@ int dfd_pwconv_wgrad(int dtype, const void* p, const dfd_prologue* pro_p, int Ni
                      const void* q, const dfd_prologue* pro_q, int Nj, int M,
                      float* dw, int accumulate, float* ws, size_t ws_bytes,
                      dfd_stream stream);
+/* The EXPAND 1x1 layer's backward in one pass over its widest operands (MBConvBlock._expand_conv / timm conv_pw):
+ *   d = coef[0]*dz + coef[1]*y + coef[2]  (the BN-backward map, as the AFFINE2 prologue),  dx = d * w (+ residual),  dw = d^T * x.
+ * dz, y [M][Cm]; x [M][Cin]; w_kn = the layer's weight in the activation dtype as [Cin][Cm] (the [K][N] copy dfd_pw_prep_weights /
+ * dfd_prep_weights_multi write); residual [M][Cin] or NULL; dx [M][Cin]; dw f32 [Cm][Cin]; ws as for dfd_pwconv_wgrad(M, Cm, Cin).
+ * Bit-identical to dfd_pwconv_fwd(dz, AFFINE2, w_kn, residual) + dfd_pwconv_wgrad(dz, AFFINE2, x) — (dz, y) cross HBM once
+ * instead of twice.  bf16, Cin <= 32, Cm <= 144, M >= 196,608 (EfficientNet blocks 1-3 at the benchmark batch); anything else:
+ * DFD_EUNSUPPORTED, the caller runs the two entry points. */
+int dfd_pwconv_bwd_fused(int dtype, const void* dz, const void* y, const float* coef, const void* x, const void* w_kn,
+                         const void* residual, int M, int Cm, int Cin, void* dx, float* dw, int accumulate, float* ws,
+                         size_t ws_bytes, dfd_stream stream);
 size_t dfd_pwconv_wgrad_ws(int M, int Ni, int Nj);
 /* f32 master [N][K] -> w_nk [N][K] and w_kn [K][N] in `dtype` (either may be NULL) */
 int dfd_pw_prep_weights(int dtype, const float* w, void* w_nk, void* w_kn, int N, int K,

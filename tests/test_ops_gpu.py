@@ -887,3 +887,45 @@ def test_device_augment_draws_what_the_pil_transforms_draw():
     big = torch.zeros((1, 300, 300, 3), dtype=torch.uint8)
     with pytest.raises(RuntimeError, match="DFD_EUNSUPPORTED"):
         _k().augment_u8(big.cuda(), torch.zeros((1, 16), dtype=torch.int32).cuda())
+
+
+@pytest.mark.parametrize("case", [(256 * 28 * 28, 96, 16, True), (256 * 28 * 28 + 37, 144, 24, True), (3 * 256 * 256 + 5, 144, 24, False),
+                                  (2048 * 96 + 3, 128, 32, True), (2048 * 96, 64, 8, False)])
+def test_expand_backward_in_one_pass(case):
+    """dfd_pwconv_bwd_fused (csrc/dfd_pwtnw.hip, DG): data and weight gradient of the expand 1x1 layer from one pass over (dz, y) —
+    against the f32 arithmetic of the oracle's ops (BN-backward map, two products) and, bit for bit, against the two kernels it
+    replaces; ragged row counts, both step sizes (Cm <= 96: 32 rows, else 16), with and without the skip connection's gradient."""
+    K = _k()
+    M, Cm, Cin, with_res = case
+    g = torch.Generator().manual_seed(M % 1000 + Cm)
+    dz = (torch.randn((M, 1, 1, Cm), generator=g) * 0.5).to(torch.bfloat16).cuda()
+    y = torch.randn((M, 1, 1, Cm), generator=g).to(torch.bfloat16).cuda()
+    x = torch.randn((M, 1, 1, Cin), generator=g).to(torch.bfloat16).cuda()
+    res = torch.randn((M, 1, 1, Cin), generator=g).to(torch.bfloat16).cuda() if with_res else None
+    w = (torch.randn((Cm, Cin), generator=g) * Cin ** -0.5).cuda()
+    coef = torch.stack([0.5 + torch.rand(Cm, generator=g), torch.randn(Cm, generator=g) * 0.1, torch.randn(Cm, generator=g) * 0.05]).cuda()
+    w_nk, w_kn = K.prep_weights(w, torch.bfloat16, True, True)
+    both = K.pwconv_bwd_fused(dz, y, coef, x, w_kn, res)
+    assert both is not None, "shape expected to be served by the fused kernel"
+    dx, dw = both
+    pro = K.pro_affine2(y, coef)
+    dx2, _, _ = K.pwconv(dz, pro, w_kn, res, stats=False)
+    dw2 = K.pwconv_wgrad(dz, pro, x, None)
+    assert torch.equal(dx, dx2), float((dx.float() - dx2.float()).abs().max())
+    assert torch.equal(dw, dw2), float((dw - dw2).abs().max())
+    # and against plain f32 arithmetic on the bf16-rounded d
+    d = R.rnd(coef[0].cpu() * dz.float().cpu().view(M, Cm) + coef[1].cpu() * y.float().cpu().view(M, Cm) + coef[2].cpu(), torch.bfloat16)
+    want_dx = d @ w.cpu().to(torch.bfloat16).float()
+    if with_res:
+        want_dx = R.rnd(want_dx, torch.bfloat16) + res.float().cpu().view(M, Cin)
+    close(dx.view(M, Cin), want_dx, 1.6e-2, "fused expand backward dx")
+    close(dw, d.t() @ x.float().cpu().view(M, Cin), 5e-3, "fused expand backward dw")
+
+
+def test_expand_backward_fused_declines_other_shapes():
+    K = _k()
+    for M, Cm, Cin in [(1000, 96, 16), (256 * 28 * 28, 240, 40), (256 * 28 * 28, 152, 24)]:
+        dz = torch.zeros((M, 1, 1, Cm), dtype=torch.bfloat16, device="cuda")
+        x = torch.zeros((M, 1, 1, Cin), dtype=torch.bfloat16, device="cuda")
+        w_kn = torch.zeros((Cin, Cm), dtype=torch.bfloat16, device="cuda")
+        assert K.pwconv_bwd_fused(dz, dz, torch.zeros((3, Cm), device="cuda"), x, w_kn, None) is None
