@@ -168,11 +168,17 @@ def pmc_traffic(family: str, args) -> tuple[int | None, dict]:
     Returns (bytes or None, provenance).  None when the file is absent, the workload differs, or the file was collected
     from OTHER kernel sources than the ones this run was built from (the file records a digest of csrc/ + include/;
     build.source_digest() recomputes it) — a stale counter file must not dress up new kernels."""
-    if (args.model, args.variant, args.flavour, args.batch, args.size) != ("efficientnet", "b0", "timm", 256, 224):
-        return None, {"file": None, "reason": "counter passes exist for the default workload only"}
-    files = sorted((ROOT / "profiles").glob("*pmc_traffic.json"))
+    if (args.batch, args.size) != (256, 224) or args.fp8_weights:
+        return None, {"file": None, "reason": "counter passes exist for batch 256 at 224 px (bf16) only"}
+    if (args.model, args.variant, args.flavour) == ("efficientnet", "b0", "timm"):
+        pattern = "*pmc_traffic.json"
+    elif args.model != "efficientnet":
+        pattern = f"*pmc_traffic_{args.model}.json"                # the other models of the bench line (scripts/profile_pmc.sh --model ...)
+    else:
+        return None, {"file": None, "reason": "counter passes exist for the bench line's three models only"}
+    files = sorted((ROOT / "profiles").glob(pattern))
     if not files:
-        return None, {"file": None, "reason": "no profiles/*pmc_traffic.json"}
+        return None, {"file": None, "reason": f"no profiles/{pattern}"}
     from deepfakedetection_amd.build import source_digest
 
     src = {"file": f"profiles/{files[-1].name}"}
@@ -456,6 +462,13 @@ def main() -> None:
                     "avg_launch_us": round(t / n * 1e6, 2), "avg_launch_bytes": int(b8 / n),
                     "share_of_step": top["share"], "mfma_tflops": round(f / t / 1e12, 2),
                     "mfma_frac": round(f / t / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4)}
+        pw = [agg[k] for k in ("pwconv", "pwconv_wgrad", "pwconv_bwd_fused") if k in agg]
+        if pw:
+            tpw, bpw, fpw = sum(a[0] for a in pw), sum(a[4] for a in pw), sum(a[2] for a in pw)
+            # every 1x1 launch of the step (forward, data gradient, weight gradient, the fused expand backward) as one family
+            roofline["pointwise_family"] = {"achieved": round(bpw / tpw / 1e9, 1), "frac": round(bpw / tpw / 1e9 / HBM_PEAK_GBS, 4),
+                                            "ms_per_step": round(tpw / args.profile_steps * 1e3, 3),
+                                            "mfma_frac": round(fpw / tpw / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4)}
         dw = [agg[k] for k in ("dwconv_fwd", "dwconv_bwd_data", "dwconv_bwd_weight") if k in agg]
         if dw:
             tdw, bdw = sum(a[0] for a in dw), sum(a[4] for a in dw)

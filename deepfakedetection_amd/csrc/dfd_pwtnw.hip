@@ -427,6 +427,8 @@ extern "C" int dfd_pwconv_bwd_fused(int dtype, const void* dz, const void* y, co
                                     const void* residual, int M, int Cm, int Cin, void* dx, float* dw, int accumulate, float* ws,
                                     size_t ws_bytes, dfd_stream stream) {
     if (!dz || !y || !coef || !x || !w_kn || !dx || !dw || !ws || M < 1 || Cm < 8 || Cin < 8 || Cm % 8 || Cin % 8) return DFD_EINVAL;
+    // wider layers (192 x 48, 240 x 40: EfficientFormerV2 stage 2, EfficientNet blocks 4-5) were instantiated and spill 230-554
+    // registers at two waves per SIMD (a wave's weight-gradient accumulators alone are 144-180): they keep the two kernels
     if (dtype != DFD_BF16 || M < 2048 * 32 * 3 || Cin > 32 || Cin > Cm || !(Cm <= 128 || (Cm <= 144 && Cm % 16 == 0))) return DFD_EUNSUPPORTED;
     dfd_prologue pro{};
     pro.mode = DFD_PRO_AFFINE2; pro.act = DFD_ACT_NONE; pro.HW = 1; pro.a2 = y; pro.coef = coef; pro.gate = nullptr;

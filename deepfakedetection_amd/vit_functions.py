@@ -118,6 +118,12 @@ def pwbn_bwd(g, x, y, st, w_kn, w_shape, w, b, gamma, beta, ls, act, training, n
             pro_d = K.pro_bn_act(coef, ACT_NONE) if dx_residual is None else pro_w
     else:
         pro_d = pro_w = K.pro_affine2(y, coef)
+        if need_dx and need_w and K.pwconv_bwd_fused_ok(dz, x):
+            # narrow input, wide BatchNormed output at many rows (EfficientFormerV2 stage-1 fc1: 32 -> 128 at 802,816 rows): data and
+            # weight gradient from one pass over (dz, y) — csrc/dfd_pwtnw.hip, DG; bit-identical to the two kernels below
+            O, I = w_shape[0], w_shape[1]
+            dx, dw = K.pwconv_bwd_fused(dz, y, coef, x, w_kn, dx_residual, _slot(w, True, (O, I)))
+            return dx, dw.view(w_shape), db, dgamma, dbeta, dls
     dx = dx_residual
     if need_dx:
         dx, _, _ = K.pwconv(dz, pro_d, w_kn, dx_residual, stats=False)
@@ -464,10 +470,15 @@ class ConvMlpFunction(torch.autograd.Function):
             dwd = K.dwconv_bwd_weight(dz2, y2, coef2, a1, None, ACT_NONE, 3, 1, 1, 1, _slot(wd, True, (Cm, 1, 3, 3)))
         pro1 = K.pro_affine2(y1, coef1)
         dw1 = dx = None
-        if need[1]:
-            dw1 = K.pwconv_wgrad(dz1, pro1, x, None, _slot(w1, True, (Cm, C))).view(Cm, C, 1, 1)
-        if need[0]:
-            dx, _, _ = K.pwconv(dz1, pro1, w1_kn, g, stats=False)
+        if need[0] and need[1] and K.pwconv_bwd_fused_ok(dz1, x):
+            # fc1 of the early stages (32 -> 128 at 802,816 rows): both gradients from ONE pass over (dz1, y1) — csrc/dfd_pwtnw.hip, DG
+            dx, dw1 = K.pwconv_bwd_fused(dz1, y1, coef1, x, w1_kn, g, _slot(w1, True, (Cm, C)))
+            dw1 = dw1.view(Cm, C, 1, 1)
+        else:
+            if need[1]:
+                dw1 = K.pwconv_wgrad(dz1, pro1, x, None, _slot(w1, True, (Cm, C))).view(Cm, C, 1, 1)
+            if need[0]:
+                dx, _, _ = K.pwconv(dz1, pro1, w1_kn, g, stats=False)
         return (dx, dw1, db1, dg1, dbe1, dwd, dbd, dgd, dbed, dw2, db2, dg2, dbe2, dls, None, None)
 
 

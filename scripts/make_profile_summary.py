@@ -15,6 +15,10 @@ import sys
 from pathlib import Path
 
 tag, prof_dir, pmc_dir, bench_json = sys.argv[1], Path(sys.argv[2]), Path(sys.argv[3]), Path(sys.argv[4])
+# optional 5th argument: "ef:efficientformerv2_s1" / "fv:faster_vit_0_224" — counter passes of ANOTHER model of the bench line
+# (scripts/profile_pmc.sh <tag> --model <name>): only profiles/<tag>_pmc_traffic_<name>.json is written (bench.py quotes it in
+# models.<name>.roofline.traffic)
+OTHER = sys.argv[5].split(":") if len(sys.argv) > 5 else None
 ROOT = Path(__file__).resolve().parents[1]
 out = ROOT / "profiles"
 sys.path.insert(0, str(ROOT))
@@ -37,7 +41,14 @@ FAM = collections.OrderedDict([
     ("dwconv_bwd_data", ("k_dw_bwd_data_q",)), ("dwconv_bwd_weight", ("k_dw_bwd_weight_q",)), ("dwconv_fwd", ("k_dw_fwd_q", "k_dw_fwd_mp")),
     ("act_bn_bwd", ("k_act_bn_bwd",)), ("pool", ("k_pool",)), ("bn_finalize", ("k_bn_finalize", "k_bn_bwd_finalize")),
     ("sum_partials", ("k_sum_partials", "k_sum_multi")), ("bn_bwd_reduce", ("k_bn_bwd_reduce",)), ("bn_act_apply", ("k_bn_act_apply",)),
-    ("stem", ("k_stem",)), ("se_mlp", ("k_se_", "k_transpose")), ("prep_weights", ("k_prep_weights",)), ("adamw", ("k_adamw",))])
+    ("stem", ("k_stem",)), ("se_mlp", ("k_se_", "k_transpose")), ("prep_weights", ("k_prep_weights",)), ("adamw", ("k_adamw",)),
+    ("pwconv_bwd_fused", ("k_pw_tnw<32, 2, 6, 0, 3, 0, 1>", "k_pw_tnw<32, 2, 6, 0, 3, 0, 2>", "k_pw_tnw<16, 2, 9, 0, 3, 0, 1>", "k_pw_tnw<16, 2, 9, 0, 3, 0, 2>")),
+    # the token-mixer families of EfficientFormerV2 / FasterViT (bench.py's names)
+    ("layernorm_fwd", ("k_layernorm_fwd",)), ("layernorm_bwd", ("k_layernorm_bwd",)), ("wattn_fwd", ("k_wattn_fwd",)), ("wattn_bwd", ("k_wattn_bwd",)),
+    ("bgemm", ("k_bgemm",)), ("attn_softmax_fwd", ("k_attn_softmax_fwd",)), ("attn_softmax_bwd", ("k_attn_softmax_bwd",)),
+    ("bn_add_act", ("k_bn_add_act",)), ("conv3", ("k_conv3_",))])
+# (the fused expand backward is an instance of k_pw_tnw: it must be matched before the plain weight-gradient family)
+FAM.move_to_end("pwconv_wgrad")
 
 
 def family(name):
@@ -47,7 +58,7 @@ def family(name):
     return "other"
 
 
-stats_path = next(iter(sorted(prof_dir.glob("b0_kernel_stats.csv")) or sorted(prof_dir.glob("*kernel_stats.csv"))))
+stats_path = next(iter(sorted(prof_dir.glob(f"{OTHER[0] if OTHER else 'b0'}_kernel_stats.csv")) or sorted(prof_dir.glob("*kernel_stats.csv"))))
 stats = list(csv.DictReader(open(stats_path)))
 steps = int([r for r in stats if "k_stem_fwd" in r["Name"]][0]["Calls"])
 agg = collections.OrderedDict((f, [0, 0.0]) for f in list(FAM) + ["other"])
@@ -91,7 +102,7 @@ for f in agg:
                   "ea_read_gb_per_step": round(ea_rd, 4),
                   "write_size_gb_per_step": round(ws[f]["WRITE_SIZE"] * 1024 / PMC_STEPS / 1e9, 4),
                   "ea_write_gb_per_step": round(ea_wr, 4)}
-doc = {"_about": "HBM traffic per kernel family and training step (EfficientNet-B0, batch 256, 224 px, bf16). rocprofv3 --pmc in "
+doc = {"_about": f"HBM traffic per kernel family and training step ({OTHER[1] if OTHER else 'EfficientNet-B0'}, batch 256, 224 px, bf16). rocprofv3 --pmc in "
                  "SEPARATE passes (FETCH_SIZE | WRITE_SIZE | TCC_EA0_RDREQ_* | TCC_EA0_WRREQ_*) over `bench.py --steps 2 --warmup 1 "
                  "--no-cpu-baseline --no-graph --profile-steps 0` (6 eager steps; sums divided by 6). FETCH_SIZE is the raw counter "
                  "(KB -> bytes): on gfx950 it under-reports reads by 2x for every family here — TCC_EA0_RDREQ (128-byte requests x 128 B) "
@@ -99,6 +110,11 @@ doc = {"_about": "HBM traffic per kernel family and training step (EfficientNet-
        "steps": PMC_STEPS, "families": traffic,
        # provenance: bench.py refuses to quote these counters once the kernel sources differ from the ones measured
        "csrc_sha256": SOURCE_DIGEST, "git_commit": GIT_COMMIT}
+if OTHER:
+    doc["model"] = OTHER[1]
+    (out / f"{tag}_pmc_traffic_{OTHER[1]}.json").write_text(json.dumps(doc, indent=1))
+    print(f"wrote profiles/{tag}_pmc_traffic_{OTHER[1]}.json: " + ", ".join(f"{k} {v['ea_read_gb_per_step'] + v['ea_write_gb_per_step']:.2f} GB" for k, v in traffic.items() if v["dispatches_per_step"]))
+    sys.exit(0)
 (out / f"{tag}_pmc_traffic.json").write_text(json.dumps(doc, indent=1))
 # ---- SQ / GRBM group: MFMA busy cycles, effective clock, how waves spend their life
 N_SIMD = 256 * 4
