@@ -954,7 +954,7 @@ extern "C" size_t dfd_pwconv_wgrad_ws(int M, int Ni, int Nj) {
     }
     // the wave-autonomous kernels (dfd_pwtnw.hip: weight gradient, fused expand backward) write one slab per workgroup, up to 512
     const int narrow = Ni < Nj ? Ni : Nj, wide = Ni < Nj ? Nj : Ni;
-    if (narrow <= 48 && wide <= 144) {
+    if (narrow <= 48 && wide <= 240) {
         const size_t b = (size_t)(512 + 512 / 32 + 2) * Ni * Nj * 4;
         if (b > best) best = b;
     }

@@ -31,8 +31,10 @@
 
 // PA: prologue of the narrow operand (NONE / AFFINE2); PB: of the wide one (NONE / AFFINE2 / BN_ACT_GATE)
 // DG: 0 weight gradient only; 1 also dx[M][Na] = B(b) w^T (w_kn = [Na][Nb] in bf16); 2 the same plus a residual added to dx
+// NBT > 9 (the fused backward of 192- / 240-wide layers): one workgroup per CU — a wave's accumulators alone are 144-180 registers,
+// at two waves per SIMD the kernel spilled 230-554 — and a wave's 16 rows in flight are ~16 KB, so four waves still keep a CU streaming
 template <int ROWS, int NA, int NBT, int PA, int PB, int ACT, int DG = 0>
-__global__ void __launch_bounds__(DFD_THREADS, 2)
+__global__ void __launch_bounds__(DFD_THREADS, NBT > 9 ? 1 : 2)
 k_pw_tnw(const bf16* __restrict__ a, ProArgs pa, int Na, const bf16* __restrict__ b, ProArgs pb, int Nb, int M,
          int rows_per_block, int swap, float* __restrict__ ws, const bf16* __restrict__ w_kn = nullptr,
          const bf16* __restrict__ res = nullptr, bf16* __restrict__ dx = nullptr, int wstride = 0, int woff = 0) {
@@ -399,7 +401,7 @@ template <int ROWS, int NA, int NBT>
 static int tnw_dg_launch(const void* x, int Cin, const void* dz, const dfd_prologue* pro_d, int Cm, const void* w_kn, const void* residual,
                          int M, void* dx, float* dw, int accumulate, float* ws, size_t ws_bytes, hipStream_t st) {
     const ProArgs pa = pro_args(nullptr), pb = pro_args(pro_d);
-    int nblocks = 512;
+    int nblocks = NBT > 9 ? 256 : 512;                          // one / two workgroups per CU
     int rpb = (M + nblocks - 1) / nblocks;
     rpb = (rpb + 4 * ROWS - 1) / (4 * ROWS) * (4 * ROWS);
     nblocks = (M + rpb - 1) / rpb;
@@ -427,14 +429,15 @@ extern "C" int dfd_pwconv_bwd_fused(int dtype, const void* dz, const void* y, co
                                     const void* residual, int M, int Cm, int Cin, void* dx, float* dw, int accumulate, float* ws,
                                     size_t ws_bytes, dfd_stream stream) {
     if (!dz || !y || !coef || !x || !w_kn || !dx || !dw || !ws || M < 1 || Cm < 8 || Cin < 8 || Cm % 8 || Cin % 8) return DFD_EINVAL;
-    // wider layers (192 x 48, 240 x 40: EfficientFormerV2 stage 2, EfficientNet blocks 4-5) were instantiated and spill 230-554
-    // registers at two waves per SIMD (a wave's weight-gradient accumulators alone are 144-180): they keep the two kernels
-    if (dtype != DFD_BF16 || M < 2048 * 32 * 3 || Cin > 32 || Cin > Cm || !(Cm <= 128 || (Cm <= 144 && Cm % 16 == 0))) return DFD_EUNSUPPORTED;
+    if (dtype != DFD_BF16 || M < 2048 * 32 * 3 || Cin > 48 || Cin > Cm || !(Cm <= 128 || (Cm <= 240 && Cm % 16 == 0))) return DFD_EUNSUPPORTED;
+    if (Cin > 32 && Cm <= 144) return DFD_EUNSUPPORTED;           // (no such layer: not instantiated)
     dfd_prologue pro{};
     pro.mode = DFD_PRO_AFFINE2; pro.act = DFD_ACT_NONE; pro.HW = 1; pro.a2 = y; pro.coef = coef; pro.gate = nullptr;
     hipStream_t st = (hipStream_t)stream;
     if (Cm <= 96) return tnw_dg_launch<32, 2, 6>(x, Cin, dz, &pro, Cm, w_kn, residual, M, dx, dw, accumulate, ws, ws_bytes, st);
-    return tnw_dg_launch<16, 2, 9>(x, Cin, dz, &pro, Cm, w_kn, residual, M, dx, dw, accumulate, ws, ws_bytes, st);
+    if (Cm <= 144) return tnw_dg_launch<16, 2, 9>(x, Cin, dz, &pro, Cm, w_kn, residual, M, dx, dw, accumulate, ws, ws_bytes, st);
+    if (Cm <= 192) return tnw_dg_launch<16, 3, 12>(x, Cin, dz, &pro, Cm, w_kn, residual, M, dx, dw, accumulate, ws, ws_bytes, st);
+    return tnw_dg_launch<16, 3, 15>(x, Cin, dz, &pro, Cm, w_kn, residual, M, dx, dw, accumulate, ws, ws_bytes, st);
 }
 
 int dfd_pw_tnw(const void* p, const dfd_prologue* pro_p, int Ni, const void* q, const dfd_prologue* pro_q, int Nj, int M,

@@ -987,6 +987,9 @@ def pwconv_wgrad(p: torch.Tensor, pro_p: Prologue | None, q: torch.Tensor, pro_q
 
 
 _FUSE_EXPAND_BWD = os.environ.get("DFD_FUSE_EXPAND_BWD", "1") != "0"      # A/B switch
+# the 192- / 240-wide instances need one workgroup per CU (a wave's accumulators are 144-180 registers) and measured a hair SLOWER
+# than the two kernels they replace: EfficientNet-B0 13.38 vs 13.33 ms/step, EfficientFormerV2-S1 18.01 vs 17.94 — off, kept for A/B
+_FUSE_EXPAND_WIDE = os.environ.get("DFD_FUSE_EXPAND_WIDE", "0") == "1"
 
 
 def pwconv_bwd_fused_ok(dz: torch.Tensor, x: torch.Tensor) -> bool:
@@ -994,8 +997,11 @@ def pwconv_bwd_fused_ok(dz: torch.Tensor, x: torch.Tensor) -> bool:
     a slot handed to a call that then declines would be lost to the fallback (its gradient would land outside the arena)."""
     Cm, Cin = dz.shape[-1], x.shape[-1]
     M = dz.numel() // Cm
-    return (_FUSE_EXPAND_BWD and dz.dtype == torch.bfloat16 and M >= 2048 * 32 * 3 and Cin <= 32 and Cin <= Cm and Cin % 8 == 0
-            and (Cm <= 128 or (Cm <= 144 and Cm % 16 == 0)) and Cm % 8 == 0)
+    if not (_FUSE_EXPAND_BWD and dz.dtype == torch.bfloat16 and M >= 2048 * 32 * 3 and Cin <= Cm and Cin % 8 == 0 and Cm % 8 == 0):
+        return False
+    if Cin <= 32 and (Cm <= 128 or (Cm <= 144 and Cm % 16 == 0)):
+        return True
+    return _FUSE_EXPAND_WIDE and Cin <= 48 and 144 < Cm <= 240 and Cm % 16 == 0
 
 
 def pwconv_bwd_fused(dz: torch.Tensor, y: torch.Tensor, coef: torch.Tensor, x: torch.Tensor, w_kn: torch.Tensor,

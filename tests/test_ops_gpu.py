@@ -890,13 +890,15 @@ def test_device_augment_draws_what_the_pil_transforms_draw():
 
 
 @pytest.mark.parametrize("case", [(256 * 28 * 28, 96, 16, True), (256 * 28 * 28 + 37, 144, 24, True), (3 * 256 * 256 + 5, 144, 24, False),
-                                  (2048 * 96 + 3, 128, 32, True), (2048 * 96, 64, 8, False)])
+                                  (2048 * 96 + 3, 128, 32, True), (2048 * 96, 64, 8, False),
+                                  (256 * 28 * 28, 240, 40, True), (256 * 28 * 28 + 11, 192, 48, False), (2048 * 96 + 5, 160, 24, True)])
 def test_expand_backward_in_one_pass(case):
     """dfd_pwconv_bwd_fused (csrc/dfd_pwtnw.hip, DG): data and weight gradient of the expand 1x1 layer from one pass over (dz, y) —
     against the f32 arithmetic of the oracle's ops (BN-backward map, two products) and, bit for bit, against the two kernels it
     replaces; ragged row counts, both step sizes (Cm <= 96: 32 rows, else 16), with and without the skip connection's gradient."""
     K = _k()
     M, Cm, Cin, with_res = case
+    K._FUSE_EXPAND_WIDE = True           # the 192- / 240-wide instances are off by default (measured slower): tested all the same
     g = torch.Generator().manual_seed(M % 1000 + Cm)
     dz = (torch.randn((M, 1, 1, Cm), generator=g) * 0.5).to(torch.bfloat16).cuda()
     y = torch.randn((M, 1, 1, Cm), generator=g).to(torch.bfloat16).cuda()
@@ -912,7 +914,10 @@ def test_expand_backward_in_one_pass(case):
     dx2, _, _ = K.pwconv(dz, pro, w_kn, res, stats=False)
     dw2 = K.pwconv_wgrad(dz, pro, x, None)
     assert torch.equal(dx, dx2), float((dx.float() - dx2.float()).abs().max())
-    assert torch.equal(dw, dw2), float((dw - dw2).abs().max())
+    if Cm <= 144 and Cin <= 32:
+        assert torch.equal(dw, dw2), float((dw - dw2).abs().max())      # the separate weight gradient is the same wave-autonomous kernel
+    else:
+        close(dw, dw2, 2e-5, "fused dw against the tiled kernel's (another split and summation order of the same f32 products)")
     # and against plain f32 arithmetic on the bf16-rounded d
     d = R.rnd(coef[0].cpu() * dz.float().cpu().view(M, Cm) + coef[1].cpu() * y.float().cpu().view(M, Cm) + coef[2].cpu(), torch.bfloat16)
     want_dx = d @ w.cpu().to(torch.bfloat16).float()
@@ -920,11 +925,13 @@ def test_expand_backward_in_one_pass(case):
         want_dx = R.rnd(want_dx, torch.bfloat16) + res.float().cpu().view(M, Cin)
     close(dx.view(M, Cin), want_dx, 1.6e-2, "fused expand backward dx")
     close(dw, d.t() @ x.float().cpu().view(M, Cin), 5e-3, "fused expand backward dw")
+    K._FUSE_EXPAND_WIDE = False
 
 
 def test_expand_backward_fused_declines_other_shapes():
     K = _k()
-    for M, Cm, Cin in [(1000, 96, 16), (256 * 28 * 28, 240, 40), (256 * 28 * 28, 152, 24)]:
+    assert not K._FUSE_EXPAND_WIDE
+    for M, Cm, Cin in [(1000, 96, 16), (256 * 28 * 28, 256, 40), (256 * 28 * 28, 152, 24), (256 * 28 * 28, 240, 56)]:
         dz = torch.zeros((M, 1, 1, Cm), dtype=torch.bfloat16, device="cuda")
         x = torch.zeros((M, 1, 1, Cin), dtype=torch.bfloat16, device="cuda")
         w_kn = torch.zeros((Cin, Cm), dtype=torch.bfloat16, device="cuda")
