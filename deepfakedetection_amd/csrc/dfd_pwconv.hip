@@ -430,7 +430,11 @@ k_pw_nt(const T* __restrict__ a, ProArgs pa, const T* __restrict__ w, T* __restr
 #define TN_TARGET_WGS 512   // workgroups a weight-gradient launch aims for (tiles x row splits)
 #endif
 #ifndef TN_MIN_STEPS
-#define TN_MIN_STEPS 8   // reduction steps a row split must have (fewer splits = fewer partial rows, less parallelism)
+// reduction steps (of 64 rows) a row split must have at least.  8 starved the small-M layers of workgroups — 1,568 rows (batch 32 at
+// 7x7) or 12,544 (batch 256) gave 3 / 24 splits for 18 output tiles and each split walked 8 exposed load -> barrier -> MFMA steps.
+// Measured 8 / 4 / 2 / 1: EfficientNet-B0 batch 32 4.62 / 4.55 / 4.43 / 4.44 ms, batch 256 13.45 / 13.49 / 13.32 / 13.42,
+// FasterViT-0 20.5 / - / 19.78 / 19.77, EfficientFormerV2-S1 18.0 / - / 18.03 / 18.02 (round 4).
+#define TN_MIN_STEPS 2
 #endif
 
 #define TN_F32_ROW 576  // (128 + 16) floats: kq rows land on disjoint bank halves
