@@ -61,6 +61,7 @@ SIGNATURES: dict[str, tuple] = {
     "dfd_bn_bwd_reduce": (c_int, [c_int, P, P, P, P, c_int, c_int, c_int, P, c_int, _PI, P]),
     "dfd_gemm_bias_act": (c_int, [c_int, P, P, c_int, c_int, c_int, P, c_int, P, P, c_int, P, P, P]),
     "dfd_gemm_plan": (c_int, [c_int, c_int, c_int]),
+    "dfd_pw_ntd_plan": (c_int, [c_int, c_int, c_int]),
     "dfd_bias_grad_ws": (c_size_t, [c_int, c_int, c_int]),
     "dfd_bias_grad": (c_int, [c_int, P, P, c_int, c_int, c_int, P, c_int, P, c_size_t, P]),
     "dfd_act_bn_bwd": (c_int, [c_int, P, P, P, P, P, c_int, P, c_int, c_int, c_int, P, c_int, _PI, P]),

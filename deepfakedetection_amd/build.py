@@ -18,7 +18,7 @@ PKG_DIR = Path(__file__).resolve().parent
 CSRC = PKG_DIR / "csrc"
 OBJ_DIR = CSRC / "build"
 LIB_PATH = PKG_DIR / "libdfd_hip.so"
-SOURCES = ("dfd_rowpass.hip", "dfd_dwfwd.hip", "dfd_dwbwd.hip", "dfd_dwbwdf.hip", "dfd_dwconv.hip", "dfd_dwmm.hip", "dfd_pwconv.hip", "dfd_pwntw.hip", "dfd_pwtnw.hip", "dfd_misc.hip", "dfd_vit.hip",
+SOURCES = ("dfd_rowpass.hip", "dfd_dwfwd.hip", "dfd_dwbwd.hip", "dfd_dwbwdf.hip", "dfd_dwconv.hip", "dfd_dwmm.hip", "dfd_pwconv.hip", "dfd_pwntw.hip", "dfd_pwntd.hip", "dfd_pwtnw.hip", "dfd_misc.hip", "dfd_vit.hip",
            "dfd_mx.hip", "dfd_attn.hip", "dfd_coord.hip", "dfd_resize.hip", "dfd_augment.hip", "dfd_conv3.hip", "dfd_stem.hip", "dfd_gemm.hip")
 ARCH = "gfx950"
 FLAGS = ("-O3", "-fPIC", "-std=c++17", "-ffp-contract=off", f"--offload-arch={ARCH}")

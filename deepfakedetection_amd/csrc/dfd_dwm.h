@@ -41,7 +41,8 @@ struct DwMGeom {
 };
 
 // knobs (dfd_tune): A/B switches and sizes read by the host-side planners; set once at start-up, before any launch
-enum { DFD_TUNE_DW_MFMA = 0, DFD_TUNE_DW_LDS_KB = 1, DFD_TUNE_DW_GRID = 2, DFD_TUNE_DEBUG = 3, DFD_TUNE_COUNT = 16 };
+enum { DFD_TUNE_DW_MFMA = 0, DFD_TUNE_DW_LDS_KB = 1, DFD_TUNE_DW_GRID = 2, DFD_TUNE_DEBUG = 3, DFD_TUNE_PW_NTD = 4, DFD_TUNE_NTD_NS = 5,
+       DFD_TUNE_COUNT = 16 };
 int dfd_tune_get(int key);
 
 // host entry points of the matrix-core kernels; DFD_EUNSUPPORTED: not served (switched off, f32, C % 16, ...) — the caller runs

@@ -184,6 +184,11 @@ int dfd_pw_ntw(int dtype, const void* a, const dfd_prologue* pro, const void* w,
                int K, int Nout, float* partials, int pcap, int* nparts, hipStream_t st, const float* ebn = nullptr,
                int eact = DFD_ACT_NONE);
 
+// mid-size layers (12.5 k .. 64 k rows): LDS-DMA ring, one 64-row tile per workgroup (dfd_pwntd.hip, bf16 only); DFD_EUNSUPPORTED
+// when the shape or the prologue / epilogue combination is not served
+int dfd_pw_ntd(int dtype, const void* a, const dfd_prologue* pro, const void* w, void* out, const void* residual, int M, int K,
+               int Nout, float* partials, int pcap, int* nparts, hipStream_t st);
+
 // direct 3x3 stride-1 pad-1 dense convolution with resident weights (dfd_conv3.hip, bf16 only); DFD_EUNSUPPORTED when the shape
 // does not qualify (dfd_conv_fwd then runs the implicit GEMM)
 int dfd_conv3_direct(const void* x, const dfd_dwconv_shape* s, const float* in_bnstate, int in_act, const void* w_nk, int Cout,

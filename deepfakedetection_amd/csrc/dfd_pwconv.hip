@@ -909,6 +909,11 @@ extern "C" int dfd_pwconv_fwd(int dtype, const void* a, const dfd_prologue* pro,
     // small weight panels (the large-M layers): wave-autonomous kernel with the panel resident in LDS
     const int rc = dfd_pw_ntw(dtype, a, pro, w, out, residual, M, K, Nout, partials, pcap, nparts, st);
     if (rc != DFD_EUNSUPPORTED) return rc;
+    // mid-size layers: LDS-DMA ring kernel (plain products that fill the chip with 256-wide tiles stay with dfd_gemm.hip)
+    if (dtype == DFD_BF16 && !(!pro && !residual && !partials && dfd_gemm_plan(M, K, Nout))) {
+        const int rd = dfd_pw_ntd(dtype, a, pro, w, out, residual, M, K, Nout, partials, pcap, nparts, st);
+        if (rd != DFD_EUNSUPPORTED) return rd;
+    }
     if (dtype == DFD_BF16) return pw_nt_t<bf16>(a, pro, w, out, residual, M, K, Nout, partials, pcap, nparts, st);
     if (dtype == DFD_F32) return pw_nt_t<float>(a, pro, w, out, residual, M, K, Nout, partials, pcap, nparts, st);
     return DFD_EINVAL;

@@ -75,7 +75,8 @@ typedef void* dfd_stream;          /* a hipStream_t */
  * batched coordinate MLPs (dfd_coord_mlp_*_multi, dfd_relpos_bias_*_multi), dfd_dwconv_bwd_fused, dfd_resize_crop_u8;
  * 121 = dfd_bias_grad / dfd_bias_grad_ws; 122 = dfd_gemm_bias_act;
  * 130 = dfd_tune; the bf16 depthwise entry points run on the matrix cores where the shape allows (same signatures);
- * 131 = dfd_augment_u8, dfd_gemm_plan, dfd_dw_mm_plan, dfd_pwconv_bwd_fused. */
+ * 131 = dfd_augment_u8, dfd_gemm_plan, dfd_dw_mm_plan, dfd_pwconv_bwd_fused;
+ * 132 = dfd_pw_ntd_plan (mid-size 1x1 layers on the LDS-DMA ring kernel; same entry points), tune keys 4 and 5. */
 int dfd_version(void);
 
 /* Planner knobs (A/B switches and sizes the host-side kernel selection reads).  Process-wide plain ints: set them once at
@@ -86,7 +87,10 @@ int dfd_version(void);
  *   1 DFD_TUNE_DW_LDS_KB  LDS budget of one matrix-core depthwise workgroup in KiB                           (default 156)
  *   2 DFD_TUNE_DW_GRID    workgroups a matrix-core depthwise launch aims for                                 (default 256)
  *   3 DFD_TUNE_DEBUG      timing-only ablations of the matrix-core depthwise kernels (results are WRONG when non-zero): bit 0
- *                         no activation arithmetic, 1 no tap loop, 2 no stores, 3 no loads                   (default 0) */
+ *                         no activation arithmetic, 1 no tap loop, 2 no stores, 3 no loads                   (default 0)
+ *   4 DFD_TUNE_PW_NTD     bit 0: dfd_pwconv_fwd runs bf16 layers of 8 k .. 64 k rows on the LDS-DMA ring kernel (dfd_pw_ntd_plan
+ *                         tells which); 0 = the register-staged tile kernel everywhere (A/B runs)             (default 1)
+ *   5 DFD_TUNE_NTD_NS     stages of that kernel's LDS ring, 2..4; 0 = chosen from the LDS budget              (default 0) */
 int dfd_tune(int key, int value);
 
 /* Batched final summation of weight gradients.  The weight-gradient entry points whose result goes straight to the
@@ -165,6 +169,9 @@ int dfd_gemm_bias_act(int dtype, const void* a, const void* w_nk, int M, int K, 
 /* Rows per tile (256 or 128) with which the LDS-DMA product kernel (csrc/dfd_gemm.hip) serves a plain bf16 [M][K] x [N][K]^T
  * through dfd_pwconv_fwd / dfd_gemm_bias_act, 0 when the shape stays with the 128 x 128 kernel of dfd_pwconv.hip. */
 int dfd_gemm_plan(int M, int K, int N);
+/* Column-tile width (64 / 96 / 128 / 192) with which the LDS-DMA ring kernel serves a bf16 dfd_pwconv_fwd of this shape; 0: the
+ * shape stays with the register-staged kernels (the prologue / epilogue combination can still decline at launch).            */
+int dfd_pw_ntd_plan(int M, int K, int Nout);
 /* dbias[c] (+)= sum over rows of g[row][c] (* row_scale[n]): the bias gradient of a Linear layer (no statistics).  ws:
  * dfd_bias_grad_ws bytes; its final fixed-order summation joins an open dfd_sum_batch like a weight gradient's.  ABI 121 */
 size_t dfd_bias_grad_ws(int N, int HW, int C);

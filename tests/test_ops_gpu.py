@@ -254,6 +254,48 @@ def _pwconv_fwd_case(case, mode, rd):
         close(out2, R.rnd(want + res.float(), rd), tol(rd), "pwconv residual")
 
 
+# mid-size layers (8 k .. 64 k rows): the LDS-DMA ring kernel k_pw_ntd (csrc/dfd_pwntd.hip).  Ragged last row tiles, K with a partial
+# last 64-wide step (80, 112, 240, 672), one and several column tiles, a 64-row tile that spans three images (HW 49 / 25)
+PW_MID_CASES = [(256, 49, 1152, 192), (67, 196, 480, 80), (67, 196, 80, 480), (50, 197, 112, 672), (131, 64, 672, 112),
+                (401, 25, 240, 40), (200, 49, 192, 320), (180, 49, 320, 1280)]
+
+
+@pytest.mark.parametrize("mode", [0, 2, 3])
+@pytest.mark.parametrize("case", PW_MID_CASES)
+def test_pwconv_fwd_mid_m_ring_kernel(case, mode):
+    """Against the oracle (as every pwconv case), AND against the register-staged kernel bit for bit: same prologue arithmetic, same
+    order of the 32-wide MFMA steps over k.  The plan function is asserted so that a silent fallback cannot pass for the ring kernel."""
+    K = _k()
+    lib = K._L()
+    N, HW, Kd, No = case
+    assert lib.dfd_pw_ntd_plan(N * HW, Kd, No) > 0
+    _pwconv_fwd_case(case, mode, torch.bfloat16)
+    a = gen((N, HW, 1, Kd), 11, torch.bfloat16)
+    a2 = gen((N, HW, 1, Kd), 12, torch.bfloat16)
+    w = gen((No, Kd), 13, torch.float32, Kd ** -0.5)
+    w_nk, _ = K.prep_weights(dev(w), torch.bfloat16, True, False)
+    dst, dgate, da2, dcoef = dev(rand_state(Kd, 14)), dev(torch.rand((N, Kd), generator=torch.Generator().manual_seed(15))), dev(a2), dev(rand_state(Kd, 16)[:3].contiguous())
+    pro = None if mode == 0 else (K.pro_bn_act_gate(dst, R.ACT_SILU, dgate, HW) if mode == 2 else K.pro_affine2(da2, dcoef))
+    res = dev(gen((N, HW, 1, No), 17, torch.bfloat16)) if mode == 3 else None
+    stats = mode != 3
+    def run():                                  # (the partial rows live in a scratch buffer the next call reuses: copy them)
+        out, parts, n = K.pwconv(dev(a), pro, w_nk, res, stats=stats)
+        return out, (parts[: n * 2 * No].clone() if stats else None), n
+
+    ring, ring2 = run(), run()
+    try:
+        assert lib.dfd_tune(4, 0) == 0
+        tiled = run()
+    finally:
+        lib.dfd_tune(4, 1)
+    assert torch.equal(ring[0], tiled[0]), "ring kernel and tile kernel disagree"
+    assert torch.equal(ring[0], ring2[0])
+    if stats:
+        assert ring[2] == (N * HW + 63) // 64
+        assert torch.equal(ring[1], ring2[1]), "statistics are not reproducible"
+        close(sum_parts(ring[1], ring[2], No), sum_parts(tiled[1], tiled[2], No), 1e-4, "ring vs tile statistics")
+
+
 @pytest.mark.parametrize("rd", DT)
 @pytest.mark.parametrize("qmode", [0, 1, 2])
 @pytest.mark.parametrize("case", PW_CASES)
