@@ -340,7 +340,8 @@ static int ntd_nt(const void* a, const dfd_prologue* pro, const void* w, void* o
 
 // column-tile width (in 16-column fragments) for an output of Nout channels: the narrowest instance that covers it in the fewest tiles
 static int ntd_pick(int Nout) {
-    const int tiles = (Nout + 191) / 192;
+    const int wmax = dfd_tune_get(DFD_TUNE_NTD_MAXN) > 0 ? dfd_tune_get(DFD_TUNE_NTD_MAXN) : 192;   // (A/B: narrower column tiles)
+    const int tiles = (Nout + wmax - 1) / wmax;
     const int per = ((Nout + tiles - 1) / tiles + 15) / 16;
     return per <= 4 ? 4 : per <= 6 ? 6 : per <= 8 ? 8 : 12;
 }
@@ -351,7 +352,7 @@ int dfd_pw_ntd(int dtype, const void* a, const dfd_prologue* pro, const void* w,
     const int m_tiles = (M + ND_BM - 1) / ND_BM;
     const int cap = partials ? (pcap < DFD_MAX_PARTIALS ? pcap : DFD_MAX_PARTIALS) : DFD_MAX_PARTIALS;
     // rows: enough tiles to give most CUs one, few enough for one partial row per tile; K: at least one full step
-    if (m_tiles < 128 || m_tiles > cap || K < 64 || (long)M * K >= (1l << 30)) return DFD_EUNSUPPORTED;
+    if (m_tiles < dfd_tune_get(DFD_TUNE_NTD_MINT) || m_tiles > cap || K < 64 || (long)M * K >= (1l << 30)) return DFD_EUNSUPPORTED;
     switch (ntd_pick(Nout)) {
         case 4: return ntd_nt<4>(a, pro, w, out, residual, M, K, Nout, partials, nparts, st);
         case 6: return ntd_nt<6>(a, pro, w, out, residual, M, K, Nout, partials, nparts, st);
@@ -362,6 +363,6 @@ int dfd_pw_ntd(int dtype, const void* a, const dfd_prologue* pro, const void* w,
 // which column-tile width serves this shape (0: not this kernel) — tests assert the path they name
 extern "C" int dfd_pw_ntd_plan(int M, int K, int Nout) {
     const int m_tiles = (M + ND_BM - 1) / ND_BM;
-    if (!(dfd_tune_get(DFD_TUNE_PW_NTD) & 1) || m_tiles < 128 || m_tiles > DFD_MAX_PARTIALS || K < 64 || (long)M * K >= (1l << 30)) return 0;
+    if (!(dfd_tune_get(DFD_TUNE_PW_NTD) & 1) || m_tiles < dfd_tune_get(DFD_TUNE_NTD_MINT) || m_tiles > DFD_MAX_PARTIALS || K < 64 || (long)M * K >= (1l << 30)) return 0;
     return 16 * ntd_pick(Nout);
 }

@@ -76,7 +76,7 @@ typedef void* dfd_stream;          /* a hipStream_t */
  * 121 = dfd_bias_grad / dfd_bias_grad_ws; 122 = dfd_gemm_bias_act;
  * 130 = dfd_tune; the bf16 depthwise entry points run on the matrix cores where the shape allows (same signatures);
  * 131 = dfd_augment_u8, dfd_gemm_plan, dfd_dw_mm_plan, dfd_pwconv_bwd_fused;
- * 132 = dfd_pw_ntd_plan (mid-size 1x1 layers on the LDS-DMA ring kernel; same entry points), tune keys 4 and 5. */
+ * 132 = dfd_pw_ntd_plan (mid-size 1x1 layers on the LDS-DMA ring kernel; same entry points), tune keys 4-7. */
 int dfd_version(void);
 
 /* Planner knobs (A/B switches and sizes the host-side kernel selection reads).  Process-wide plain ints: set them once at
@@ -88,9 +88,12 @@ int dfd_version(void);
  *   2 DFD_TUNE_DW_GRID    workgroups a matrix-core depthwise launch aims for                                 (default 256)
  *   3 DFD_TUNE_DEBUG      timing-only ablations of the matrix-core depthwise kernels (results are WRONG when non-zero): bit 0
  *                         no activation arithmetic, 1 no tap loop, 2 no stores, 3 no loads                   (default 0)
- *   4 DFD_TUNE_PW_NTD     bit 0: dfd_pwconv_fwd runs bf16 layers of 8 k .. 64 k rows on the LDS-DMA ring kernel (dfd_pw_ntd_plan
+ *   4 DFD_TUNE_PW_NTD     bit 0: dfd_pwconv_fwd runs bf16 layers of 1 k .. 64 k rows on the LDS-DMA ring kernel (dfd_pw_ntd_plan
  *                         tells which); 0 = the register-staged tile kernel everywhere (A/B runs)             (default 1)
- *   5 DFD_TUNE_NTD_NS     stages of that kernel's LDS ring, 2..4; 0 = chosen from the LDS budget              (default 0) */
+ *   5 DFD_TUNE_NTD_NS     stages of that kernel's LDS ring, 2..4; 0 = chosen from the LDS budget              (default 0)
+ *   6 DFD_TUNE_NTD_MAXN   widest column tile of that kernel (A/B: 96 / 128); 0 = 192                          (default 0)
+ *   7 DFD_TUNE_NTD_MINT   fewest 64-row tiles for which it is used: 16 measured best at batch 32 / 64 (4.40 -> 4.25 ms,
+ *                         5.74 -> 5.64 ms per EfficientNet-B0 step), neutral at 256                          (default 16) */
 int dfd_tune(int key, int value);
 
 /* Batched final summation of weight gradients.  The weight-gradient entry points whose result goes straight to the
