@@ -37,7 +37,7 @@ except Exception:  # noqa: BLE001
 FAM = collections.OrderedDict([
     # every kernel that serves a family's API calls belongs to it (the LDS-DMA product serves dfd_pwconv_fwd calls, the matrix-core
     # depthwise kernel dfd_dwconv_fwd calls): bench.py's algorithmic bytes are per API call, so bytes and time must cover one population
-    ("pwconv", ("k_pw_ntw", "k_pw_nt<", "k_gemm_nt_dma")), ("pwconv_wgrad", ("k_pw_tnw", "k_pw_tn<")),
+    ("pwconv", ("k_pw_ntw", "k_pw_ntd", "k_pw_nt<", "k_gemm_nt_dma")), ("pwconv_wgrad", ("k_pw_tnw", "k_pw_tn<")),
     ("dwconv_bwd_data", ("k_dw_bwd_data_q",)), ("dwconv_bwd_weight", ("k_dw_bwd_weight_q",)), ("dwconv_fwd", ("k_dw_fwd_q", "k_dw_fwd_mp")),
     ("act_bn_bwd", ("k_act_bn_bwd",)), ("pool", ("k_pool",)), ("bn_finalize", ("k_bn_finalize", "k_bn_bwd_finalize")),
     ("sum_partials", ("k_sum_partials", "k_sum_multi")), ("bn_bwd_reduce", ("k_bn_bwd_reduce",)), ("bn_act_apply", ("k_bn_act_apply",)),

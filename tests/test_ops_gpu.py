@@ -257,7 +257,9 @@ def _pwconv_fwd_case(case, mode, rd):
 # mid-size layers (8 k .. 64 k rows): the LDS-DMA ring kernel k_pw_ntd (csrc/dfd_pwntd.hip).  Ragged last row tiles, K with a partial
 # last 64-wide step (80, 112, 240, 672), one and several column tiles, a 64-row tile that spans three images (HW 49 / 25)
 PW_MID_CASES = [(256, 49, 1152, 192), (67, 196, 480, 80), (67, 196, 80, 480), (50, 197, 112, 672), (131, 64, 672, 112),
-                (401, 25, 240, 40), (200, 49, 192, 320), (180, 49, 320, 1280)]
+                (401, 25, 240, 40), (200, 49, 192, 320), (180, 49, 320, 1280),
+                # the smallest shapes it takes: 17 row tiles, K = 64 + 8, outputs that are not a multiple of 16 channels
+                (17, 64, 72, 24), (10, 103, 64, 8), (21, 50, 200, 56)]
 
 
 @pytest.mark.parametrize("mode", [0, 2, 3])
