@@ -152,6 +152,8 @@ SIGNATURES: dict[str, tuple] = {
     "dfd_wattn_parts": (c_int, [c_int]),
     "dfd_wattn_fwd": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_float, P]),
     "dfd_wattn_bwd": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_float, P]),
+    "dfd_attn_scores": (c_int, [P, P, P, P, c_float, c_int, c_int, c_int, c_int, c_int, P]),
+    "dfd_attn_apply": (c_int, [P, c_int, P, P, c_float, c_int, c_int, c_int, c_int, c_int, P]),
     "dfd_coord_mlp_fwd_multi": (c_int, [P, c_int, P]),
     "dfd_coord_mlp_bwd_multi": (c_int, [P, c_int, P]),
     "dfd_relpos_bias_fwd_multi": (c_int, [P, c_int, P]),

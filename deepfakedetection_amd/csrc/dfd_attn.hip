@@ -382,3 +382,168 @@ extern "C" int dfd_wattn_bwd(const void* qkv, const void* dout, const float* L, 
                            (const unsigned short*)dout, L, bias, (unsigned short*)dqkv, dbias_parts, n, T, H, scale);
     return DFD_CHECK_LAUNCH();
 }
+
+// =====================================================================================================================
+// The attention GEMMs of EfficientFormerV2's Attention2d (timm; forward at trainers/efficientformer_v2.py:244) on the matrix
+// cores.  Talking heads mix the 8 heads of a (query, key) pair before and after the softmax, so S / P / T2 stay f32 tensors
+// [B][H][Nq][Nk] that the softmax kernels of dfd_vit.hip read and write; what moves here are the six batched products around
+// them, which ran on dfd_bgemm (one 256-thread workgroup per (image, head): stage both operands element-wise into f32 LDS,
+// 4 x 4 register tiles on the vector unit, scalar stores: 19-50 us per call for 0.2-0.7 GFLOP).  ONE WAVE per (image, head),
+// <= 64 tokens on either side, fragments straight from global memory where the reduction index is contiguous, the other
+// operand staged once as a [token][32] bf16 tile and read transposed (the helpers of the window-attention kernels above):
+//   dfd_attn_scores   out[b][h][i][j] = alpha * sum_d x[b][i][h D + d] * y[b][j][h D + d] (+ bias[h][i][j])      S, dT2
+//   dfd_attn_apply    out[b][i][h D + d] = alpha * sum_t f[b][h][i][t] * x[b][t][h D + d]  (f_trans: f[b][h][t][i])   O, dQ | dV, dK
+// The f32 operand of dfd_attn_apply is rounded to bf16 for its product (f32 accumulation), as P and dS are in the window
+// attention; everything else is the arithmetic of the bgemm path.
+template <int KS>
+__global__ void __launch_bounds__(256)
+k_attn_scores(const unsigned short* __restrict__ x, const unsigned short* __restrict__ y, float* __restrict__ out,
+              const float* __restrict__ bias, float alpha, int n, int H, int Tx, int Ty) {
+    constexpr int D = 32 * KS;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
+    const long bh = (long)blockIdx.x * 4 + wave;
+    if (bh >= (long)n * H) return;
+    const int b = (int)(bh / H), h = (int)(bh - (long)b * H);
+    const long pitch = (long)H * D;
+    const unsigned short* xb = x + (long)b * Tx * pitch + h * D + 8 * g;
+    const unsigned short* yb = y + (long)b * Ty * pitch + h * D + 8 * g;
+    f32x4_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        bf16x8_t xf[4], yf[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int rx = 16 * t + c < Tx ? 16 * t + c : Tx - 1, ry = 16 * t + c < Ty ? 16 * t + c : Ty - 1;
+            xf[t] = as_bf(*reinterpret_cast<const uint4*>(xb + rx * pitch + 32 * ks));
+            yf[t] = as_bf(*reinterpret_cast<const uint4*>(yb + ry * pitch + 32 * ks));
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = mma32(xf[i], yf[j], acc[i][j]);       // [x row 16 i + 4 g + r][y row 16 j + c]
+    }
+    float* ob = out + bh * Tx * Ty;
+    const float* bb = bias ? bias + (long)h * Tx * Ty : nullptr;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 16 * i + 4 * g + r;
+            if (row >= Tx) continue;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int col = 16 * j + c;
+                if (col >= Ty) continue;
+                float v = alpha * acc[i][j][r];
+                if (bb) v += bb[row * Ty + col];
+                ob[row * Ty + col] = v;
+            }
+        }
+}
+
+// TRANS = false: f[b][h][i][t] (To x Tc);  true: f[b][h][t][i] (Tc x To)
+template <bool TRANS>
+__global__ void __launch_bounds__(256)
+k_attn_apply(const float* __restrict__ f, const unsigned short* __restrict__ x, unsigned short* __restrict__ out, float alpha,
+             int n, int H, int To, int Tc, int D) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
+    long bh = (long)blockIdx.x * 4 + wave;
+    const bool live = bh < (long)n * H;
+    if (!live) bh = (long)n * H - 1;                     // (idle waves redo the last pair, store nothing: tr_frag needs EXEC all ones)
+    const int b = (int)(bh / H), h = (int)(bh - (long)b * H);
+    const long pitch = (long)H * D;
+    unsigned char* tile = smem + wave * (64 * AT_LDS_ROW);
+    // the f32 operand as bf16 B fragments: lane (output row 16 it + c), k-slot (g, j) of step s <-> t = 32 s + 16 (j >> 2) + 4 g + (j & 3)
+    const float* fb = f + bh * To * Tc;
+    bf16x8_t ff[4][2];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int i = 16 * it + c;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            f32x4_t lo, hi;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int t0 = 32 * s + 4 * g + u, t1 = t0 + 16;
+                const bool ok0 = i < To && t0 < Tc, ok1 = i < To && t1 < Tc;
+                const float v0 = fb[ok0 ? (TRANS ? t0 * To + i : i * Tc + t0) : 0];
+                const float v1 = fb[ok1 ? (TRANS ? t1 * To + i : i * Tc + t1) : 0];
+                lo[u] = ok0 ? v0 : 0.f;
+                hi[u] = ok1 ? v1 : 0.f;
+            }
+            ff[it][s] = pack8(lo, hi);
+        }
+    }
+    const unsigned short* xb = x + (long)b * Tc * pitch + h * D;
+    unsigned short* ob = out + (long)b * To * pitch + h * D;
+    for (int dc = 0; dc < D / 32; ++dc) {
+        stage_tile<4>(tile, xb + 32 * dc, pitch, Tc, lane);               // rows >= Tc are zero
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        f32x4_t acc[2][4];
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int it = 0; it < 4; ++it) acc[dt][it] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                const bf16x8_t xt = tr_frag(tile, dt, s, lane);
+#pragma unroll
+                for (int it = 0; it < 4; ++it) acc[dt][it] = mma32(xt, ff[it][s], acc[dt][it]);      // [d 16 dt + 4 g + r][row 16 it + c]
+            }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();                                  // every lane's transposed reads are done before the tile is restaged
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (live) {
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int row = 16 * it + c;
+                if (row >= To) continue;
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                    const f32x4_t o = acc[dt][it];
+                    *reinterpret_cast<uint2*>(ob + row * pitch + 32 * dc + 16 * dt + 4 * g) =
+                        make_uint2(pack_bf2(alpha * o[0], alpha * o[1]), pack_bf2(alpha * o[2], alpha * o[3]));
+                }
+            }
+        }
+    }
+}
+
+static bool attn2_ok(int n, int H, int Ta, int Tb, int D) { return n >= 1 && H >= 1 && Ta >= 1 && Ta <= 64 && Tb >= 1 && Tb <= 64 && D >= 32 && D <= 128 && D % 32 == 0; }
+
+extern "C" int dfd_attn_scores(const void* x, const void* y, float* out, const float* bias, float alpha, int n, int H, int Tx, int Ty,
+                               int D, dfd_stream stream) {
+    if (!x || !y || !out) return DFD_EINVAL;
+    if (!attn2_ok(n, H, Tx, Ty, D)) return DFD_EUNSUPPORTED;
+    const dim3 grid((unsigned)(((long)n * H + 3) / 4));
+    hipStream_t st = (hipStream_t)stream;
+#define SC_GO(KSV) hipLaunchKernelGGL((k_attn_scores<KSV>), grid, dim3(256), 0, st, (const unsigned short*)x, (const unsigned short*)y, out, bias, alpha, n, H, Tx, Ty)
+    switch (D / 32) {
+        case 1: SC_GO(1); break;
+        case 2: SC_GO(2); break;
+        case 3: SC_GO(3); break;
+        default: SC_GO(4); break;
+    }
+#undef SC_GO
+    return DFD_CHECK_LAUNCH();
+}
+extern "C" int dfd_attn_apply(const float* f, int f_trans, const void* x, void* out, float alpha, int n, int H, int To, int Tc, int D,
+                              dfd_stream stream) {
+    if (!f || !x || !out) return DFD_EINVAL;
+    if (!attn2_ok(n, H, To, Tc, D)) return DFD_EUNSUPPORTED;
+    const dim3 grid((unsigned)(((long)n * H + 3) / 4));
+    const size_t lds = 4 * 64 * AT_LDS_ROW;
+    hipStream_t st = (hipStream_t)stream;
+    if (f_trans) hipLaunchKernelGGL((k_attn_apply<true>), grid, dim3(256), lds, st, f, (const unsigned short*)x, (unsigned short*)out, alpha, n, H, To, Tc, D);
+    else hipLaunchKernelGGL((k_attn_apply<false>), grid, dim3(256), lds, st, f, (const unsigned short*)x, (unsigned short*)out, alpha, n, H, To, Tc, D);
+    return DFD_CHECK_LAUNCH();
+}

@@ -1212,6 +1212,38 @@ def bgemm(A: torch.Tensor, sa: tuple, B: torch.Tensor, sb: tuple, C: torch.Tenso
                          int(round_b), _stream()), "dfd_bgemm", f"nb={nb} nh={nh} M={M} N={N} K={Kd}")
 
 
+def attn_mfma_supported(dtype: torch.dtype, Nq: int, Nk: int, dk: int, dv: int) -> bool:
+    """The one-wave-per-(image, head) attention products (csrc/dfd_attn.hip, dfd_attn_scores / dfd_attn_apply): bf16 activations,
+    at most 64 tokens on either side, head dimensions that are multiples of 32 up to 128.  DFD_ATTN_MFMA=0 keeps dfd_bgemm (A/B)."""
+    if os.environ.get("DFD_ATTN_MFMA", "1") == "0":
+        return False
+    return dtype == torch.bfloat16 and 1 <= Nq <= 64 and 1 <= Nk <= 64 and all(d % 32 == 0 and 32 <= d <= 128 for d in (dk, dv))
+
+
+def attn_scores(x: torch.Tensor, y: torch.Tensor, H: int, alpha: float = 1.0, bias: torch.Tensor | None = None) -> torch.Tensor:
+    """x [B, .., H*D] (Tx tokens per image), y [B, .., H*D] (Ty tokens) bf16 -> f32 [B, H, Tx, Ty] = alpha * x_h y_h^T (+ bias[H, Tx*Ty])."""
+    B = x.shape[0]
+    D = x.shape[-1] // H
+    Tx, Ty = x.numel() // (B * H * D), y.numel() // (B * H * D)
+    out = torch.empty((B, H, Tx, Ty), dtype=torch.float32, device=x.device)
+    check(_L().dfd_attn_scores(_p(x), _p(y), _p(out), _p(bias), float(alpha), B, H, Tx, Ty, D, _stream()), "dfd_attn_scores",
+          f"B={B} H={H} Tx={Tx} Ty={Ty} D={D}")
+    return out
+
+
+def attn_apply(f: torch.Tensor, x: torch.Tensor, out_shape, H: int, alpha: float = 1.0, transpose: bool = False) -> torch.Tensor:
+    """f f32 [B, H, To, Tc] (transpose: [B, H, Tc, To]), x [B, .., H*D] with Tc tokens per image -> bf16 tensor of `out_shape`
+    ([B, .., H*D], To tokens): out_h = alpha * f_h x_h (or f_h^T x_h)."""
+    B = x.shape[0]
+    D = x.shape[-1] // H
+    Tc = x.numel() // (B * H * D)
+    To = f.shape[3] if transpose else f.shape[2]
+    out = torch.empty(tuple(out_shape), dtype=x.dtype, device=x.device)
+    check(_L().dfd_attn_apply(_p(f), int(transpose), _p(x), _p(out), float(alpha), B, H, To, Tc, D, _stream()), "dfd_attn_apply",
+          f"B={B} H={H} To={To} Tc={Tc} D={D}")
+    return out
+
+
 def wattn_supported(dtype: torch.dtype, T: int, hd: int) -> bool:
     """The fused MFMA window attention (csrc/dfd_attn.hip) covers bf16, head_dim 32, at most 64 tokens per window."""
     return dtype == torch.bfloat16 and hd == 32 and 1 <= T <= 64

@@ -175,6 +175,11 @@ def attn_core_fwd(q, k, v, table, idx, th, geo: AttnGeom):
     B = q.shape[0]
     H, dk, dv, Nq, Nk = geo.heads, geo.dk, geo.dv, geo.Nq, geo.Nk
     bias_full = K.bias_gather(table, idx)                                        # [H, Nq*Nk]
+    if K.attn_mfma_supported(q.dtype, Nq, Nk, dk, dv):
+        # bf16, <= 64 tokens: the two products on the matrix cores, one wave per (image, head) (csrc/dfd_attn.hip)
+        S = K.attn_scores(q, k, H, geo.scale, bias_full)
+        P, T2 = K.attn_softmax_fwd(S, th)
+        return K.attn_apply(T2, v, (*q.shape[:3], H * dv), H), S, P, T2
     S = torch.empty((B, H, Nq, Nk), dtype=torch.float32, device=q.device)
     K.bgemm(q, (Nq * H * dk, dk, H * dk, 1), k, (Nk * H * dk, dk, 1, H * dk), S, (H * Nq * Nk, Nq * Nk, Nk, 1),
             B, H, Nq, Nk, dk, alpha=geo.scale, bias=bias_full)
@@ -197,10 +202,16 @@ def attn_core_bwd(gO, q, k, v, S, P, T2, table, idx, th, geo: AttnGeom, need_tab
     dev = q.device
     if B > 1024:
         raise RuntimeError("attention backward sums per-image partials in one two-stage pass: batch <= 1024")
-    dT2 = torch.empty((B, H, Nq, Nk), dtype=torch.float32, device=dev)
-    K.bgemm(gO, (Nq * H * dv, dv, H * dv, 1), v, (Nk * H * dv, dv, 1, H * dv), dT2, (H * L, L, Nk, 1), B, H, Nq, Nk, dv)
-    dV = torch.empty_like(v)
-    K.bgemm(T2, (H * L, L, 1, Nk), gO, (Nq * H * dv, dv, H * dv, 1), dV, (Nk * H * dv, dv, H * dv, 1), B, H, Nk, dv, Nq)
+    mfma = K.attn_mfma_supported(q.dtype, Nq, Nk, dk, dv) and gO.dtype == q.dtype
+    if mfma:
+        gO = _c(gO)
+        dT2 = K.attn_scores(gO, v, H)
+        dV = K.attn_apply(T2, gO, v.shape, H, transpose=True)
+    else:
+        dT2 = torch.empty((B, H, Nq, Nk), dtype=torch.float32, device=dev)
+        K.bgemm(gO, (Nq * H * dv, dv, H * dv, 1), v, (Nk * H * dv, dv, 1, H * dv), dT2, (H * L, L, Nk, 1), B, H, Nq, Nk, dv)
+        dV = torch.empty_like(v)
+        K.bgemm(T2, (H * L, L, 1, Nk), gO, (Nq * H * dv, dv, H * dv, 1), dV, (Nk * H * dv, dv, H * dv, 1), B, H, Nk, dv, Nq)
     # dS gets room for the two-stage row sum that turns it into the bias gradient
     dS_buf = torch.empty((_partial_rows(B), H, Nq, Nk), dtype=torch.float32, device=dev)
     dS = dS_buf[:B]
@@ -214,10 +225,14 @@ def attn_core_bwd(gO, q, k, v, S, P, T2, table, idx, th, geo: AttnGeom, need_tab
     else:
         check(lib.dfd_attn_softmax_bwd(dT2.data_ptr(), P.data_ptr(), th[0].data_ptr(), th[2].data_ptr(), dT1.data_ptr(),
                                        dS.data_ptr(), B, H, Nq, Nk, K._stream()), "dfd_attn_softmax_bwd")
-    dQ = torch.empty_like(q)
-    K.bgemm(dS, (H * L, L, Nk, 1), k, (Nk * H * dk, dk, H * dk, 1), dQ, (Nq * H * dk, dk, H * dk, 1), B, H, Nq, dk, Nk, alpha=geo.scale)
-    dK = torch.empty_like(k)
-    K.bgemm(dS, (H * L, L, 1, Nk), q, (Nq * H * dk, dk, H * dk, 1), dK, (Nk * H * dk, dk, H * dk, 1), B, H, Nk, dk, Nq, alpha=geo.scale)
+    if mfma:
+        dQ = K.attn_apply(dS, k, q.shape, H, alpha=geo.scale)
+        dK = K.attn_apply(dS, q, k.shape, H, alpha=geo.scale, transpose=True)
+    else:
+        dQ = torch.empty_like(q)
+        K.bgemm(dS, (H * L, L, Nk, 1), k, (Nk * H * dk, dk, H * dk, 1), dQ, (Nq * H * dk, dk, H * dk, 1), B, H, Nq, dk, Nk, alpha=geo.scale)
+        dK = torch.empty_like(k)
+        K.bgemm(dS, (H * L, L, 1, Nk), q, (Nq * H * dk, dk, H * dk, 1), dK, (Nk * H * dk, dk, H * dk, 1), B, H, Nk, dk, Nq, alpha=geo.scale)
     dth = None
     if th is not None and need_th:
         w1, b1, w2, b2 = th

@@ -76,7 +76,8 @@ typedef void* dfd_stream;          /* a hipStream_t */
  * 121 = dfd_bias_grad / dfd_bias_grad_ws; 122 = dfd_gemm_bias_act;
  * 130 = dfd_tune; the bf16 depthwise entry points run on the matrix cores where the shape allows (same signatures);
  * 131 = dfd_augment_u8, dfd_gemm_plan, dfd_dw_mm_plan, dfd_pwconv_bwd_fused;
- * 132 = dfd_pw_ntd_plan (mid-size 1x1 layers on the LDS-DMA ring kernel; same entry points), tune keys 4-7. */
+ * 132 = dfd_pw_ntd_plan (mid-size 1x1 layers on the LDS-DMA ring kernel; same entry points), tune keys 4-7;
+ * 133 = dfd_attn_scores / dfd_attn_apply. */
 int dfd_version(void);
 
 /* Planner knobs (A/B switches and sizes the host-side kernel selection reads).  Process-wide plain ints: set them once at
@@ -600,6 +601,21 @@ int dfd_wattn_fwd(const void* qkv, const float* bias, void* out, float* L, int n
                   dfd_stream stream);
 int dfd_wattn_bwd(const void* qkv, const void* dout, const float* L, const float* bias, void* dqkv, float* dbias_parts,
                   int n, int T, int H, int hd, float scale, dfd_stream stream);
+
+/* ------------------------------------------------ attention GEMMs of Attention2d (EfficientFormerV2) ---
+ * timm's Attention2d (forward at trainers/efficientformer_v2.py:244) mixes the heads of a (query, key) pair before and after the
+ * softmax ("talking heads"), so S / P / T2 stay f32 [B][H][Nq][Nk] tensors for dfd_attn_softmax_*; the six batched products
+ * around them run here on v_mfma_f32_16x16x32_bf16, one wave per (image, head), instead of on dfd_bgemm:
+ *   dfd_attn_scores  out[b][h][i][j] = alpha * sum_d x[b][i][h*D + d] * y[b][j][h*D + d] (+ bias[h][i][j])
+ *                    x [n][Tx][H*D], y [n][Ty][H*D] bf16; out f32 [n][H][Tx][Ty]; bias f32 [H][Tx][Ty] or NULL         (S, dT2)
+ *   dfd_attn_apply   out[b][i][h*D + d] = alpha * sum_t f[b][h][i][t] * x[b][t][h*D + d]      (f_trans = 0, f [n][H][To][Tc])
+ *                                       = alpha * sum_t f[b][h][t][i] * x[b][t][h*D + d]      (f_trans = 1, f [n][H][Tc][To])
+ *                    f f32 (rounded to bf16 for the product, f32 accumulation); x [n][Tc][H*D], out [n][To][H*D] bf16  (O, dQ | dV, dK)
+ * Token counts <= 64, D % 32 == 0, D <= 128; anything else: DFD_EUNSUPPORTED (callers keep dfd_bgemm).                        */
+int dfd_attn_scores(const void* x, const void* y, float* out, const float* bias, float alpha, int n, int H, int Tx, int Ty,
+                    int D, dfd_stream stream);
+int dfd_attn_apply(const float* f, int f_trans, const void* x, void* out, float alpha, int n, int H, int To, int Tc, int D,
+                   dfd_stream stream);
 
 /* -------------------------------------------- batched coordinate MLPs (FasterViT) ---
  * PosEmbMLPSwinv1D / PosEmbMLPSwinv2D of the third-party module:  table[t][:] = W2 . relu(W0 . coords[t] + b0), f32,

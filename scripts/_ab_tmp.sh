@@ -1,3 +1,3 @@
-for t in "7=128" "7=64" "7=16" "7=8"; do echo "== DFD_TUNE=$t batch 32"; DFD_TUNE=$t python bench.py --batch 32 --no-cpu-baseline --profile-steps 0 --eval-steps 0 --extra-models none 2>/dev/null | python3 scripts/bench_ms.py; done
-for t in "7=128" "7=16"; do echo "== DFD_TUNE=$t batch 64"; DFD_TUNE=$t python bench.py --batch 64 --no-cpu-baseline --profile-steps 0 --eval-steps 0 --extra-models none 2>/dev/null | python3 scripts/bench_ms.py; done
-for t in "7=128" "7=16"; do echo "== DFD_TUNE=$t batch 256 all models"; DFD_TUNE=$t python bench.py --no-cpu-baseline --profile-steps 0 --eval-steps 0 2>/dev/null | python3 scripts/bench_ms.py; done
+timeout -k 10 300 python -m pytest tests/test_vit_ops_gpu.py -m gpu -x -q -k "attention_products or bgemm" 2>&1 | tail -15
+timeout -k 10 400 python -m pytest tests/test_efformer_gpu.py tests/test_fullsize_vit_gpu.py -m gpu -x -q 2>&1 | tail -8
+for v in 1 0; do echo "== DFD_ATTN_MFMA=$v"; DFD_ATTN_MFMA=$v python bench.py --model efficientformerv2_s1 --no-cpu-baseline --profile-steps 0 --eval-steps 0 --extra-models none 2>/dev/null | python3 scripts/bench_ms.py; done

@@ -213,6 +213,39 @@ def test_bgemm_reads_heads_in_place_from_nhwc(din, dout):
     close(dV, (P.transpose(-1, -2) @ dOh).permute(0, 2, 1, 3).reshape(B * N, H * dv), 1e-4 if dout == torch.float32 else 1.6e-2, "dV")
 
 
+@pytest.mark.parametrize("shape", [(3, 8, 49, 49, 32, 128), (2, 8, 49, 37, 32, 64), (5, 3, 16, 64, 64, 32), (1, 8, 64, 1, 96, 96)])
+def test_attention_products_on_the_matrix_cores(shape):
+    """dfd_attn_scores / dfd_attn_apply (one wave per (image, head), csrc/dfd_attn.hip) against the f32 products of the same bf16
+    inputs — the six GEMMs around the talking-head softmax of timm's Attention2d.  The f32 operand of dfd_attn_apply is rounded to
+    bf16 for the product: the bound is that rounding (2^-9 relative per term), as for P and dS in the window attention."""
+    K = _k()
+    B, H, Nq, Nk, dk, dv = shape
+    assert K.attn_mfma_supported(torch.bfloat16, Nq, Nk, dk, dv)
+    bf = torch.bfloat16
+    q, k, v = gen((B, Nq, 1, H * dk), 1, bf), gen((B, Nk, 1, H * dk), 2, bf), gen((B, Nk, 1, H * dv), 3, bf)
+    bias = gen((H, Nq * Nk), 4)
+    heads = lambda t, T, D: t.float().view(B, T, H, D).permute(0, 2, 1, 3)
+    back = lambda t, T, D: t.permute(0, 2, 1, 3).reshape(B, T, 1, H * D)
+    qh, kh, vh = heads(q, Nq, dk), heads(k, Nk, dk), heads(v, Nk, dv)
+    S = K.attn_scores(q.cuda(), k.cuda(), H, dk ** -0.5, bias.cuda())
+    want_S = qh @ kh.transpose(-1, -2) * dk ** -0.5 + bias.view(H, Nq, Nk)
+    close(S, want_S, 1e-5, "S = scale q k^T + bias")
+    T2 = torch.softmax(want_S, -1) + 0.1 * gen((B, H, Nq, Nk), 5)
+    O = K.attn_apply(T2.cuda(), v.cuda(), (B, Nq, 1, H * dv), H)
+    close(O, back(T2 @ vh, Nq, dv), 1.2e-2, "O = T2 v")
+    gO = gen((B, Nq, 1, H * dv), 6, bf)
+    gOh = heads(gO, Nq, dv)
+    close(K.attn_scores(gO.cuda(), v.cuda(), H), gOh @ vh.transpose(-1, -2), 1e-5, "dT2 = dO v^T")
+    close(K.attn_apply(T2.cuda(), gO.cuda(), (B, Nk, 1, H * dv), H, transpose=True), back(T2.transpose(-1, -2) @ gOh, Nk, dv), 1.2e-2, "dV = T2^T dO")
+    dS = gen((B, H, Nq, Nk), 7)
+    close(K.attn_apply(dS.cuda(), k.cuda(), (B, Nq, 1, H * dk), H, alpha=0.25), back(0.25 * (dS @ kh), Nq, dk), 1.2e-2, "dQ = scale dS k")
+    close(K.attn_apply(dS.cuda(), q.cuda(), (B, Nk, 1, H * dk), H, alpha=0.25, transpose=True), back(0.25 * (dS.transpose(-1, -2) @ qh), Nk, dk), 1.2e-2,
+          "dK = scale dS^T q")
+    # the same calls give the same bits
+    assert torch.equal(K.attn_scores(q.cuda(), k.cuda(), H, dk ** -0.5, bias.cuda()), S)
+    assert torch.equal(K.attn_apply(T2.cuda(), v.cuda(), (B, Nq, 1, H * dv), H), O)
+
+
 def test_bgemm_large_k_and_rect():
     K = _k()
     B, H, Nq, Nk, dk = 2, 8, 49, 196, 16
