@@ -395,48 +395,82 @@ extern "C" int dfd_wattn_bwd(const void* qkv, const void* dout, const float* L, 
 //   dfd_attn_apply    out[b][i][h D + d] = alpha * sum_t f[b][h][i][t] * x[b][t][h D + d]  (f_trans: f[b][h][t][i])   O, dQ | dV, dK
 // The f32 operand of dfd_attn_apply is rounded to bf16 for its product (f32 accumulation), as P and dS are in the window
 // attention; everything else is the arithmetic of the bgemm path.
-template <int KS>
+__device__ __forceinline__ void wave_sync_lds() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// stage rows [r0, r0 + 64) of a [T][.] bf16 matrix, columns [0, dvalid) of a 32-column chunk, into a wave-private [64][32] tile;
+// rows >= T and columns >= dvalid are zero (never read from memory: the last chunk of the last head may end the tensor)
+__device__ __forceinline__ void stage_tile_w(unsigned char* tile, const unsigned short* __restrict__ src, long pitch, int r0, int T,
+                                             int dvalid, int lane) {
+    uint4 r[4];
+    const bool cok = (lane & 3) * 8 < dvalid;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = r0 + 16 * i + (lane >> 2);
+        r[i] = *reinterpret_cast<const uint4*>(src + (long)(row < T ? row : T - 1) * pitch + (cok ? (lane & 3) * 8 : 0));
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int lrow = 16 * i + (lane >> 2);
+        const uint4 v = (r0 + lrow < T && cok) ? r[i] : make_uint4(0, 0, 0, 0);
+        uint2* d = reinterpret_cast<uint2*>(tile + lrow * AT_LDS_ROW + (lane & 3) * 16);
+        d[0] = make_uint2(v.x, v.y);
+        d[1] = make_uint2(v.z, v.w);
+    }
+}
+
+// one wave per (image, head, 64-row block of x, 64-row block of y); D % 8 == 0 (a partial last 32-wide step is zero-filled)
 __global__ void __launch_bounds__(256)
 k_attn_scores(const unsigned short* __restrict__ x, const unsigned short* __restrict__ y, float* __restrict__ out,
-              const float* __restrict__ bias, float alpha, int n, int H, int Tx, int Ty) {
-    constexpr int D = 32 * KS;
+              const float* __restrict__ bias, float alpha, int n, int H, int Tx, int Ty, int D, int XB, int YB) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
-    const long bh = (long)blockIdx.x * 4 + wave;
-    if (bh >= (long)n * H) return;
+    const long item = (long)blockIdx.x * 4 + wave;
+    if (item >= (long)n * H * XB * YB) return;
+    const int yblk = (int)(item % YB), xblk = (int)((item / YB) % XB);
+    const long bh = item / ((long)XB * YB);
     const int b = (int)(bh / H), h = (int)(bh - (long)b * H);
     const long pitch = (long)H * D;
-    const unsigned short* xb = x + (long)b * Tx * pitch + h * D + 8 * g;
-    const unsigned short* yb = y + (long)b * Ty * pitch + h * D + 8 * g;
+    const int x0 = 64 * xblk, y0 = 64 * yblk;
+    const unsigned short* xb = x + (long)b * Tx * pitch + h * D;
+    const unsigned short* yb = y + (long)b * Ty * pitch + h * D;
     f32x4_t acc[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
+    for (int k0 = 0; k0 < D; k0 += 32) {
+        const bool kok = k0 + 8 * g < D;                                   // (lanes past D feed zeros; their address is clamped)
+        const int ko = kok ? k0 + 8 * g : 0;
         bf16x8_t xf[4], yf[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            const int rx = 16 * t + c < Tx ? 16 * t + c : Tx - 1, ry = 16 * t + c < Ty ? 16 * t + c : Ty - 1;
-            xf[t] = as_bf(*reinterpret_cast<const uint4*>(xb + rx * pitch + 32 * ks));
-            yf[t] = as_bf(*reinterpret_cast<const uint4*>(yb + ry * pitch + 32 * ks));
+            const int rx = x0 + 16 * t + c < Tx ? x0 + 16 * t + c : Tx - 1, ry = y0 + 16 * t + c < Ty ? y0 + 16 * t + c : Ty - 1;
+            const uint4 qx = *reinterpret_cast<const uint4*>(xb + rx * pitch + ko), qy = *reinterpret_cast<const uint4*>(yb + ry * pitch + ko);
+            xf[t] = as_bf(kok ? qx : make_uint4(0, 0, 0, 0));
+            yf[t] = as_bf(kok ? qy : make_uint4(0, 0, 0, 0));
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = mma32(xf[i], yf[j], acc[i][j]);       // [x row 16 i + 4 g + r][y row 16 j + c]
     }
+    // straight from the accumulators: a store instruction covers 4 rows x 16 consecutive columns.  (Going through an LDS patch for
+    // row-contiguous stores and bias reads measured SLOWER — 19.8 -> 22.9 us at 49 x 49 x 32: the index arithmetic and the round trip
+    // cost more than the 64-byte segments do.)
     float* ob = out + bh * Tx * Ty;
     const float* bb = bias ? bias + (long)h * Tx * Ty : nullptr;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int row = 16 * i + 4 * g + r;
+            const int row = x0 + 16 * i + 4 * g + r;
             if (row >= Tx) continue;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int col = 16 * j + c;
+                const int col = y0 + 16 * j + c;
                 if (col >= Ty) continue;
                 float v = alpha * acc[i][j][r];
                 if (bb) v += bb[row * Ty + col];
@@ -445,105 +479,137 @@ k_attn_scores(const unsigned short* __restrict__ x, const unsigned short* __rest
         }
 }
 
-// TRANS = false: f[b][h][i][t] (To x Tc);  true: f[b][h][t][i] (Tc x To)
-template <bool TRANS>
+// one wave per (image, head, 64-row block of the output); the contraction index is walked in blocks of 64 tokens.
+// TRANS = false: f[b][h][i][t] (To x Tc);  true: f[b][h][t][i] (Tc x To).
+// DC > 0: accumulators of all DC 32-column chunks of D live across the token blocks (Tc > 64);  DC = 0: one token block (Tc <= 64) — the
+// chunks are walked one after the other with 8 accumulator tiles (25 / 17 us against 26 / 25 for the general form at 49 x 49 x 128)
+template <bool TRANS, int DC>
 __global__ void __launch_bounds__(256)
 k_attn_apply(const float* __restrict__ f, const unsigned short* __restrict__ x, unsigned short* __restrict__ out, float alpha,
-             int n, int H, int To, int Tc, int D) {
+             int n, int H, int To, int Tc, int D, int OB) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
-    long bh = (long)blockIdx.x * 4 + wave;
-    const bool live = bh < (long)n * H;
-    if (!live) bh = (long)n * H - 1;                     // (idle waves redo the last pair, store nothing: tr_frag needs EXEC all ones)
+    long item = (long)blockIdx.x * 4 + wave;
+    const bool live = item < (long)n * H * OB;
+    if (!live) item = (long)n * H * OB - 1;              // (idle waves redo the last item, store nothing: transposed reads need EXEC all ones)
+    const int oblk = (int)(item % OB);
+    const long bh = item / OB;
     const int b = (int)(bh / H), h = (int)(bh - (long)b * H);
     const long pitch = (long)H * D;
+    const int o0 = 64 * oblk;
     unsigned char* tile = smem + wave * (64 * AT_LDS_ROW);
-    // the f32 operand as bf16 B fragments: lane (output row 16 it + c), k-slot (g, j) of step s <-> t = 32 s + 16 (j >> 2) + 4 g + (j & 3)
     const float* fb = f + bh * To * Tc;
-    bf16x8_t ff[4][2];
-#pragma unroll
-    for (int it = 0; it < 4; ++it) {
-        const int i = 16 * it + c;
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            f32x4_t lo, hi;
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int t0 = 32 * s + 4 * g + u, t1 = t0 + 16;
-                const bool ok0 = i < To && t0 < Tc, ok1 = i < To && t1 < Tc;
-                const float v0 = fb[ok0 ? (TRANS ? t0 * To + i : i * Tc + t0) : 0];
-                const float v1 = fb[ok1 ? (TRANS ? t1 * To + i : i * Tc + t1) : 0];
-                lo[u] = ok0 ? v0 : 0.f;
-                hi[u] = ok1 ? v1 : 0.f;
-            }
-            ff[it][s] = pack8(lo, hi);
-        }
-    }
     const unsigned short* xb = x + (long)b * Tc * pitch + h * D;
     unsigned short* ob = out + (long)b * To * pitch + h * D;
-    for (int dc = 0; dc < D / 32; ++dc) {
-        stage_tile<4>(tile, xb + 32 * dc, pitch, Tc, lane);               // rows >= Tc are zero
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        f32x4_t acc[2][4];
+    // the f32 operand as bf16 B fragments, straight from global memory: lane (output row o0 + 16 it + c), k-slot (g, j) of step s <->
+    // token t0 + 32 s + 16 (j >> 2) + 4 g + (j & 3); 64 independent loads per lane (staging the block through LDS for row-contiguous
+    // loads measured slower: 22.9 -> 32 us at 49 x 49 x 128)
+    auto load_ff = [&](int t0, bf16x8_t (&ff)[4][2]) {
 #pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
+        for (int it = 0; it < 4; ++it) {
+            const int i = o0 + 16 * it + c;
 #pragma unroll
-            for (int it = 0; it < 4; ++it) acc[dt][it] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            for (int s = 0; s < 2; ++s) {
+                f32x4_t lo, hi;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int ta = t0 + 32 * s + 4 * g + u, tb = ta + 16;
+                    const bool oka = i < To && ta < Tc, okb = i < To && tb < Tc;
+                    const float va = fb[oka ? (TRANS ? (long)ta * To + i : (long)i * Tc + ta) : 0];
+                    const float vb = fb[okb ? (TRANS ? (long)tb * To + i : (long)i * Tc + tb) : 0];
+                    lo[u] = oka ? va : 0.f;
+                    hi[u] = okb ? vb : 0.f;
+                }
+                ff[it][s] = pack8(lo, hi);
+            }
+        }
+    };
+    auto chunk_mma = [&](int t0, int dc, const bf16x8_t (&ff)[4][2], f32x4_t (&acc)[2][4]) {
+        stage_tile_w(tile, xb + 32 * dc, pitch, t0, Tc, D - 32 * dc, lane);
+        wave_sync_lds();
 #pragma unroll
         for (int s = 0; s < 2; ++s)
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt) {
                 const bf16x8_t xt = tr_frag(tile, dt, s, lane);
 #pragma unroll
-                for (int it = 0; it < 4; ++it) acc[dt][it] = mma32(xt, ff[it][s], acc[dt][it]);      // [d 16 dt + 4 g + r][row 16 it + c]
+                for (int it = 0; it < 4; ++it) acc[dt][it] = mma32(xt, ff[it][s], acc[dt][it]);       // [d 16 dt + 4 g + r][row 16 it + c]
             }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();                                  // every lane's transposed reads are done before the tile is restaged
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (live) {
+        wave_sync_lds();                                                  // every lane's transposed reads are done before the tile is restaged
+    };
+    auto chunk_store = [&](int dc, const f32x4_t (&acc)[2][4]) {
+        if (!live) return;
 #pragma unroll
-            for (int it = 0; it < 4; ++it) {
-                const int row = 16 * it + c;
-                if (row >= To) continue;
+        for (int it = 0; it < 4; ++it) {
+            const int row = o0 + 16 * it + c;
+            if (row >= To) continue;
 #pragma unroll
-                for (int dt = 0; dt < 2; ++dt) {
-                    const f32x4_t o = acc[dt][it];
-                    *reinterpret_cast<uint2*>(ob + row * pitch + 32 * dc + 16 * dt + 4 * g) =
-                        make_uint2(pack_bf2(alpha * o[0], alpha * o[1]), pack_bf2(alpha * o[2], alpha * o[3]));
-                }
+            for (int dt = 0; dt < 2; ++dt) {
+                if (32 * dc + 16 * dt + 4 * g >= D) continue;
+                const f32x4_t o = acc[dt][it];
+                *reinterpret_cast<uint2*>(ob + row * pitch + 32 * dc + 16 * dt + 4 * g) =
+                    make_uint2(pack_bf2(alpha * o[0], alpha * o[1]), pack_bf2(alpha * o[2], alpha * o[3]));
             }
         }
+    };
+    if constexpr (DC == 0) {
+        bf16x8_t ff[4][2];
+        load_ff(0, ff);
+        const int ndc = (D + 31) >> 5;
+#pragma unroll 1
+        for (int dc = 0; dc < ndc; ++dc) {
+            f32x4_t acc[2][4];
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int it = 0; it < 4; ++it) acc[dt][it] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            chunk_mma(0, dc, ff, acc);
+            chunk_store(dc, acc);
+        }
+    } else {
+        f32x4_t acc[DC][2][4];
+#pragma unroll
+        for (int dc = 0; dc < DC; ++dc)
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int it = 0; it < 4; ++it) acc[dc][dt][it] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+        for (int t0 = 0; t0 < Tc; t0 += 64) {
+            bf16x8_t ff[4][2];
+            load_ff(t0, ff);
+#pragma unroll
+            for (int dc = 0; dc < DC; ++dc) chunk_mma(t0, dc, ff, acc[dc]);
+        }
+#pragma unroll
+        for (int dc = 0; dc < DC; ++dc) chunk_store(dc, acc[dc]);
     }
 }
 
-static bool attn2_ok(int n, int H, int Ta, int Tb, int D) { return n >= 1 && H >= 1 && Ta >= 1 && Ta <= 64 && Tb >= 1 && Tb <= 64 && D >= 32 && D <= 128 && D % 32 == 0; }
+static bool attn2_ok(int n, int H, int Ta, int Tb, int D) { return n >= 1 && H >= 1 && Ta >= 1 && Ta <= 256 && Tb >= 1 && Tb <= 256 && D >= 8 && D <= 128 && D % 8 == 0; }
 
 extern "C" int dfd_attn_scores(const void* x, const void* y, float* out, const float* bias, float alpha, int n, int H, int Tx, int Ty,
                                int D, dfd_stream stream) {
     if (!x || !y || !out) return DFD_EINVAL;
     if (!attn2_ok(n, H, Tx, Ty, D)) return DFD_EUNSUPPORTED;
-    const dim3 grid((unsigned)(((long)n * H + 3) / 4));
-    hipStream_t st = (hipStream_t)stream;
-#define SC_GO(KSV) hipLaunchKernelGGL((k_attn_scores<KSV>), grid, dim3(256), 0, st, (const unsigned short*)x, (const unsigned short*)y, out, bias, alpha, n, H, Tx, Ty)
-    switch (D / 32) {
-        case 1: SC_GO(1); break;
-        case 2: SC_GO(2); break;
-        case 3: SC_GO(3); break;
-        default: SC_GO(4); break;
-    }
-#undef SC_GO
+    const int XB = (Tx + 63) / 64, YB = (Ty + 63) / 64;
+    const dim3 grid((unsigned)(((long)n * H * XB * YB + 3) / 4));
+    hipLaunchKernelGGL(k_attn_scores, grid, dim3(256), 0, (hipStream_t)stream, (const unsigned short*)x, (const unsigned short*)y, out, bias,
+                       alpha, n, H, Tx, Ty, D, XB, YB);
     return DFD_CHECK_LAUNCH();
 }
 extern "C" int dfd_attn_apply(const float* f, int f_trans, const void* x, void* out, float alpha, int n, int H, int To, int Tc, int D,
                               dfd_stream stream) {
     if (!f || !x || !out) return DFD_EINVAL;
     if (!attn2_ok(n, H, To, Tc, D)) return DFD_EUNSUPPORTED;
-    const dim3 grid((unsigned)(((long)n * H + 3) / 4));
+    const int OB = (To + 63) / 64;
+    const dim3 grid((unsigned)(((long)n * H * OB + 3) / 4));
     const size_t lds = 4 * 64 * AT_LDS_ROW;
     hipStream_t st = (hipStream_t)stream;
-    if (f_trans) hipLaunchKernelGGL((k_attn_apply<true>), grid, dim3(256), lds, st, f, (const unsigned short*)x, (unsigned short*)out, alpha, n, H, To, Tc, D);
-    else hipLaunchKernelGGL((k_attn_apply<false>), grid, dim3(256), lds, st, f, (const unsigned short*)x, (unsigned short*)out, alpha, n, H, To, Tc, D);
+#define AP_GO(TR, DCV) hipLaunchKernelGGL((k_attn_apply<TR, DCV>), grid, dim3(256), lds, st, f, (const unsigned short*)x, (unsigned short*)out, alpha, n, H, To, Tc, D, OB)
+    const int dc = Tc <= 64 ? 0 : (D + 31) / 32;         // one token block: the chunk-by-chunk form
+    if (f_trans) { if (dc == 0) AP_GO(true, 0); else if (dc == 1) AP_GO(true, 1); else if (dc == 2) AP_GO(true, 2); else if (dc == 3) AP_GO(true, 3); else AP_GO(true, 4); }
+    else { if (dc == 0) AP_GO(false, 0); else if (dc == 1) AP_GO(false, 1); else if (dc == 2) AP_GO(false, 2); else if (dc == 3) AP_GO(false, 3); else AP_GO(false, 4); }
+#undef AP_GO
     return DFD_CHECK_LAUNCH();
 }

@@ -1213,11 +1213,12 @@ def bgemm(A: torch.Tensor, sa: tuple, B: torch.Tensor, sb: tuple, C: torch.Tenso
 
 
 def attn_mfma_supported(dtype: torch.dtype, Nq: int, Nk: int, dk: int, dv: int) -> bool:
-    """The one-wave-per-(image, head) attention products (csrc/dfd_attn.hip, dfd_attn_scores / dfd_attn_apply): bf16 activations,
-    at most 64 tokens on either side, head dimensions that are multiples of 32 up to 128.  DFD_ATTN_MFMA=0 keeps dfd_bgemm (A/B)."""
+    """The one-wave-per-(image, head, 64-token block) attention products (csrc/dfd_attn.hip, dfd_attn_scores / dfd_attn_apply): bf16
+    activations, at most 256 tokens on either side, head dimensions that are multiples of 8 up to 128.  DFD_ATTN_MFMA=0 keeps
+    dfd_bgemm (A/B)."""
     if os.environ.get("DFD_ATTN_MFMA", "1") == "0":
         return False
-    return dtype == torch.bfloat16 and 1 <= Nq <= 64 and 1 <= Nk <= 64 and all(d % 32 == 0 and 32 <= d <= 128 for d in (dk, dv))
+    return dtype == torch.bfloat16 and 1 <= Nq <= 256 and 1 <= Nk <= 256 and all(d % 8 == 0 and 8 <= d <= 128 for d in (dk, dv))
 
 
 def attn_scores(x: torch.Tensor, y: torch.Tensor, H: int, alpha: float = 1.0, bias: torch.Tensor | None = None) -> torch.Tensor:

@@ -611,7 +611,7 @@ int dfd_wattn_bwd(const void* qkv, const void* dout, const float* L, const float
  *   dfd_attn_apply   out[b][i][h*D + d] = alpha * sum_t f[b][h][i][t] * x[b][t][h*D + d]      (f_trans = 0, f [n][H][To][Tc])
  *                                       = alpha * sum_t f[b][h][t][i] * x[b][t][h*D + d]      (f_trans = 1, f [n][H][Tc][To])
  *                    f f32 (rounded to bf16 for the product, f32 accumulation); x [n][Tc][H*D], out [n][To][H*D] bf16  (O, dQ | dV, dK)
- * Token counts <= 64, D % 32 == 0, D <= 128; anything else: DFD_EUNSUPPORTED (callers keep dfd_bgemm).                        */
+ * Token counts <= 256 (walked in blocks of 64), D % 8 == 0, D <= 128; anything else: DFD_EUNSUPPORTED (callers keep dfd_bgemm).     */
 int dfd_attn_scores(const void* x, const void* y, float* out, const float* bias, float alpha, int n, int H, int Tx, int Ty,
                     int D, dfd_stream stream);
 int dfd_attn_apply(const float* f, int f_trans, const void* x, void* out, float alpha, int n, int H, int To, int Tc, int D,

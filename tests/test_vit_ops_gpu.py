@@ -213,7 +213,8 @@ def test_bgemm_reads_heads_in_place_from_nhwc(din, dout):
     close(dV, (P.transpose(-1, -2) @ dOh).permute(0, 2, 1, 3).reshape(B * N, H * dv), 1e-4 if dout == torch.float32 else 1.6e-2, "dV")
 
 
-@pytest.mark.parametrize("shape", [(3, 8, 49, 49, 32, 128), (2, 8, 49, 37, 32, 64), (5, 3, 16, 64, 64, 32), (1, 8, 64, 1, 96, 96)])
+@pytest.mark.parametrize("shape", [(3, 8, 49, 49, 32, 128), (2, 8, 49, 37, 32, 64), (5, 3, 16, 64, 64, 32), (1, 8, 64, 1, 96, 96),
+                                   (3, 8, 49, 196, 16, 64), (2, 5, 130, 65, 8, 24), (1, 2, 256, 256, 48, 120)])
 def test_attention_products_on_the_matrix_cores(shape):
     """dfd_attn_scores / dfd_attn_apply (one wave per (image, head), csrc/dfd_attn.hip) against the f32 products of the same bf16
     inputs — the six GEMMs around the talking-head softmax of timm's Attention2d.  The f32 operand of dfd_attn_apply is rounded to
