@@ -30,7 +30,9 @@
 
 typedef __attribute__((address_space(3))) unsigned char nd_lds_u8;
 
-// one LDS-DMA piece: lane l's 16 bytes at `src` land at lds_addr + 16 l (M0 carries the wave-uniform LDS address)
+// one LDS-DMA piece: lane l's 16 bytes at `src` land at lds_addr + 16 l (M0 carries the wave-uniform LDS address).  M0 is not on the
+// clobber list — hipcc rejects it as a reserved register — and the compiler itself never touches M0 in these kernels (checked in the
+// -S output: every `m0` is one of the s_mov_b32 below); re-check after adding anything that makes it use M0 (LDS-DMA builtins, movrel).
 __device__ __forceinline__ void nd_dma16(const void* src, unsigned lds_addr) {
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(src), "s"(lds_addr) : "memory");
 }
