@@ -1556,7 +1556,7 @@ _profile_sink: list | None = None
 _TIMED = ("bn_act_apply", "bn_bwd_reduce", "act_bn_bwd", "pool_act", "pool_bwd_reduce", "scale_rows", "dwconv_fwd",
           "dwconv_bwd_data", "dwconv_bwd_weight", "dwconv_bwd_fused", "pwconv", "pwconv_wgrad", "pwconv_bwd_fused", "stem_conv_fwd", "stem_conv_wgrad",
           "se_fc_fwd", "se_fc_bwd", "linear_fwd", "linear_bwd", "ce_loss", "adamw_step", "prep_weights", "bn_finalize",
-          "bn_bwd_finalize", "bn_bwd_finalize_ex", "dropout", "bgemm", "attn_softmax_fwd", "attn_softmax_bwd", "im2col", "col2im",
+          "bn_bwd_finalize", "bn_bwd_finalize_ex", "dropout", "bgemm", "attn_scores", "attn_apply", "attn_softmax_fwd", "attn_softmax_bwd", "im2col", "col2im",
           "wattn_fwd", "wattn_bwd", "mx_quant_rows", "mx_gemm",
           "bn_add_act", "bn_add_act_bwd", "affine2_apply", "up2_act_fwd", "up2_act_bwd", "layernorm_fwd", "layernorm_bwd",
           "channel_stats", "subsample_add")
