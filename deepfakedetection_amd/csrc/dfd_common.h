@@ -172,6 +172,14 @@ __device__ __forceinline__ void gelu_parts2(dfd_f2 z, dfd_f2& cdf, dfd_f2& ez) {
 }
 template <int ACT> __device__ __forceinline__ dfd_f2 act_fwd2(dfd_f2 z) {
     if constexpr (ACT == DFD_ACT_GELU) { dfd_f2 cdf, ez; gelu_parts2(z, cdf, ez); return z * cdf; }
+#ifndef DFD_SILU_SCALAR
+    else if constexpr (ACT == DFD_ACT_SILU) {
+        // z * rcp(1 + exp(-z)) with the multiply / add / multiply on pairs (v_pk_*_f32); operation for operation act_fwd<SILU>
+        const dfd_f2 t = z * splat2(-1.44269504088896340736f);               // __expf(-z) = exp2(-z * log2 e)
+        const dfd_f2 d = (dfd_f2){__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)} + splat2(1.0f);
+        return z * (dfd_f2){__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+    }
+#endif
     else return (dfd_f2){act_fwd<ACT>(z.x), act_fwd<ACT>(z.y)};
 }
 template <int ACT> __device__ __forceinline__ dfd_f2 act_grad2(dfd_f2 z) {

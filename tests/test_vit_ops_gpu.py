@@ -690,6 +690,21 @@ def test_packed_pair_gelu_is_the_scalar_gelu_bit_for_bit(rd):
     assert torch.equal(d_packed, d_scalar), float((d_packed.float() - d_scalar.float()).abs().max())
 
 
+@pytest.mark.parametrize("rd", DT)
+def test_packed_pair_silu_is_the_scalar_silu_bit_for_bit(rd):
+    """SiLU on float2 pairs (round 4: act_fwd2<SILU>, every GEMM / row-pass prologue) against the scalar form the bn_add_act row
+    kernel still uses: z * rcp(1 + exp2(-z * log2 e)), same operations in the same order."""
+    K = _k()
+    N, H, W, C = 4, 9, 7, 64
+    y = (gen((N, H, W, C), 81, rd) * 4.0)
+    y.view(-1)[:8] = torch.tensor([0.0, -0.0, 1e-8, -1e-8, 20.0, -20.0, 90.0, -90.0]).to(rd)
+    st = rand_state(C, 83)
+    y, st = y.cuda(), st.cuda()
+    packed = K.bn_act_apply(y, st, R.ACT_SILU)
+    scalar = K.bn_add_act(y, st, None, R.ACT_SILU)
+    assert torch.equal(packed, scalar), float((packed.float() - scalar.float()).abs().max())
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("shape", [(256 * 80 + 17, 192, 520), (256 * 170, 128, 256), (256 * 41 + 255, 1024, 1032)])
 def test_plain_bf16_product_on_256_tiles_with_lds_dma(shape):
