@@ -187,7 +187,17 @@ template <int ACT> __device__ __forceinline__ dfd_f2 act_grad2(dfd_f2 z) {
         dfd_f2 cdf, ez;
         gelu_parts2(z, cdf, ez);
         return __builtin_elementwise_fma(z * splat2(0.39894228040143268f), ez, cdf);
-    } else return (dfd_f2){act_grad<ACT>(z.x), act_grad<ACT>(z.y)};
+    }
+#ifndef DFD_SILU_SCALAR
+    else if constexpr (ACT == DFD_ACT_SILU) {
+        // s * (1 + z * (1 - s)), s = rcp(1 + exp(-z)): act_grad<SILU> operation for operation, on pairs
+        const dfd_f2 t = z * splat2(-1.44269504088896340736f);
+        const dfd_f2 d = (dfd_f2){__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)} + splat2(1.0f);
+        const dfd_f2 sg = (dfd_f2){__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+        return sg * (splat2(1.0f) + z * (splat2(1.0f) - sg));
+    }
+#endif
+    else return (dfd_f2){act_grad<ACT>(z.x), act_grad<ACT>(z.y)};
 }
 // act(scale * v + shift) / act'(..) over an array of N values, in pairs
 template <int ACT, int N>

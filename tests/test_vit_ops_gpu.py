@@ -703,6 +703,10 @@ def test_packed_pair_silu_is_the_scalar_silu_bit_for_bit(rd):
     packed = K.bn_act_apply(y, st, R.ACT_SILU)
     scalar = K.bn_add_act(y, st, None, R.ACT_SILU)
     assert torch.equal(packed, scalar), float((packed.float() - scalar.float()).abs().max())
+    g = gen((N, H, W, C), 82, rd).cuda()
+    d_packed, _, _ = K.act_bn_bwd(g, y, None, None, st, R.ACT_SILU)
+    d_scalar, _, _ = K.bn_add_act_bwd(g, y, st, None, R.ACT_SILU, stats=False)
+    assert torch.equal(d_packed, d_scalar), float((d_packed.float() - d_scalar.float()).abs().max())
 
 
 # ---------------------------------------------------------------------------------------------------------------------
