@@ -45,7 +45,7 @@ FAM = collections.OrderedDict([
     ("pwconv_bwd_fused", ("k_pw_tnw<32, 2, 6, 0, 3, 0, 1>", "k_pw_tnw<32, 2, 6, 0, 3, 0, 2>", "k_pw_tnw<16, 2, 9, 0, 3, 0, 1>", "k_pw_tnw<16, 2, 9, 0, 3, 0, 2>")),
     # the token-mixer families of EfficientFormerV2 / FasterViT (bench.py's names)
     ("layernorm_fwd", ("k_layernorm_fwd",)), ("layernorm_bwd", ("k_layernorm_bwd",)), ("wattn_fwd", ("k_wattn_fwd",)), ("wattn_bwd", ("k_wattn_bwd",)),
-    ("bgemm", ("k_bgemm",)), ("attn_softmax_fwd", ("k_attn_softmax_fwd",)), ("attn_softmax_bwd", ("k_attn_softmax_bwd",)),
+    ("bgemm", ("k_bgemm",)), ("attn_gemm", ("k_attn_scores", "k_attn_apply")), ("attn_softmax_fwd", ("k_attn_softmax_fwd",)), ("attn_softmax_bwd", ("k_attn_softmax_bwd",)),
     ("bn_add_act", ("k_bn_add_act",)), ("conv3", ("k_conv3_",))])
 # (the fused expand backward is an instance of k_pw_tnw: it must be matched before the plain weight-gradient family)
 FAM.move_to_end("pwconv_wgrad")
