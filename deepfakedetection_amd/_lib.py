@@ -65,6 +65,7 @@ SIGNATURES: dict[str, tuple] = {
     "dfd_bias_grad_ws": (c_size_t, [c_int, c_int, c_int]),
     "dfd_bias_grad": (c_int, [c_int, P, P, c_int, c_int, c_int, P, c_int, P, c_size_t, P]),
     "dfd_act_bn_bwd": (c_int, [c_int, P, P, P, P, P, c_int, P, c_int, c_int, c_int, P, c_int, _PI, P]),
+    "dfd_act_bn_bwd_se": (c_int, [c_int, P, P, P, P, P, c_int, P, c_int, c_int, c_int, P, c_int, _PI, P, P, c_int, P, P, P, P, c_int, P]),
     "dfd_prep_weights_multi": (c_int, [P, c_int, P]),
     "dfd_resize_crop_u8": (c_int, [P, P, P, c_int, c_int, c_int, c_int, P]),
     "dfd_augment_u8": (c_int, [P, P, P, c_int, c_int, c_int, P]),

@@ -2,6 +2,7 @@
 // convolution, classifier head, label-smoothed cross entropy, softmax/argmax and the
 // fused multi-tensor AdamW step.  All f32 except the stem's output / gradient tensors.
 #include "dfd_common.h"
+#include "dfd_se.h"
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -110,55 +111,8 @@ __global__ void __launch_bounds__(DFD_THREADS)
 k_se_fc_bwd_w(const float* __restrict__ pooled, const float* __restrict__ ws, int N, int C, int R,
               float* __restrict__ dw1, float* __restrict__ db1, float* __restrict__ dw2, float* __restrict__ db2,
               int accumulate) {
-    __shared__ float red[3][4][64];
-    const float* ws_g = ws;
-    const float* ws_dh = ws + (long)N * C;
-    const float* ws_h = ws_dh + (long)N * R;
-    const int t = threadIdx.x, cl = t & 63, nl = t >> 6;
-    const int c = blockIdx.x * 64 + cl, r = blockIdx.y;
-    float a1 = 0.f, a2 = 0.f, sb2 = 0.f;
-    if (c < C) {
-        int n = nl;
-        for (; n + 12 < N; n += 16) {                           // four images in flight per lane
-            float g[4], pc[4], h[4], dh[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const long m = n + 4 * u;
-                g[u] = ws_g[m * C + c]; pc[u] = pooled[m * C + c]; h[u] = ws_h[m * R + r]; dh[u] = ws_dh[m * R + r];
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) { a2 = fmaf(g[u], h[u], a2); a1 = fmaf(dh[u], pc[u], a1); sb2 += g[u]; }
-        }
-        for (; n < N; n += 4) {
-            const float g = ws_g[(long)n * C + c], pc = pooled[(long)n * C + c];
-            a2 = fmaf(g, ws_h[(long)n * R + r], a2);
-            a1 = fmaf(ws_dh[(long)n * R + r], pc, a1);
-            sb2 += g;
-        }
-    }
-    red[0][nl][cl] = a1; red[1][nl][cl] = a2; red[2][nl][cl] = sb2;
-    __syncthreads();
-    if (nl == 0 && c < C) {
-        a1 = red[0][0][cl] + red[0][1][cl] + red[0][2][cl] + red[0][3][cl];
-        a2 = red[1][0][cl] + red[1][1][cl] + red[1][2][cl] + red[1][3][cl];
-        float* p2 = dw2 + (long)c * R + r;
-        float* p1 = dw1 + (long)r * C + c;
-        *p2 = (accumulate ? *p2 : 0.f) + a2;
-        *p1 = (accumulate ? *p1 : 0.f) + a1;
-        if (r == 0 && db2) {
-            sb2 = red[2][0][cl] + red[2][1][cl] + red[2][2][cl] + red[2][3][cl];
-            db2[c] = (accumulate ? db2[c] : 0.f) + sb2;
-        }
-    }
-    if (blockIdx.x == 0 && db1) {
-        __syncthreads();
-        float s = 0.f;
-        for (int n = t; n < N; n += DFD_THREADS) s += ws_dh[(long)n * R + r];
-        s = wave_sum(s);
-        if ((t & 63) == 0) red[0][t >> 6][0] = s;
-        __syncthreads();
-        if (t == 0) db1[r] = (accumulate ? db1[r] : 0.f) + red[0][0][0] + red[0][1][0] + red[0][2][0] + red[0][3][0];
-    }
+    __shared__ float red[3 * 4 * 64];
+    se_fc_bwd_w_body(pooled, ws, N, C, R, dw1, db1, dw2, db2, accumulate, blockIdx.x, blockIdx.y, red);
 }
 
 // ---- one workgroup per image: the whole squeeze-excite MLP behind the pooling kernel (and the sum of its

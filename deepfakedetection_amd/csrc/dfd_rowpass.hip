@@ -6,6 +6,7 @@
 // strides over rows, accumulate in registers, reduce once through LDS and write ONE
 // partial row per workgroup (fixed summation order => reproducible results).
 #include "dfd_common.h"
+#include "dfd_se.h"
 
 // ------------------------------------------------------------------ bn_act_apply
 template <typename T, int ACT, bool HAS_RES, bool HAS_RS>
@@ -124,13 +125,24 @@ k_bn_bwd_reduce(const T* __restrict__ g, const T* __restrict__ y, const float* _
 
 // ------------------------------------------------------------------ act_bn_bwd
 // MODE 0: da = D ; MODE 1: da = D*gate[n,c] + dpool[n,c]*invHW ; MODE 2: da = dpool[n,c]*invHW
+struct SeWgradJob { const float* pooled; const float* ws; int N, C, R; float* dw1; float* db1; float* dw2; float* db2; int accumulate; };
+
 template <typename T, int ACT, int MODE>
 __global__ void __launch_bounds__(DFD_THREADS)
 k_act_bn_bwd(const T* __restrict__ D, const T* __restrict__ y, const float* __restrict__ gate,
              const float* __restrict__ dpool, const float* __restrict__ bnstate, T* __restrict__ dz,
-             long rows, int HW, int C, float invHW, ChanMap cm, float* __restrict__ partials) {
+             long rows, int HW, int C, float invHW, ChanMap cm, float* __restrict__ partials, int main_x, SeWgradJob job) {
     constexpr int V = Vec<T>::N;
     __shared__ float red[DFD_THREADS * 2 * V];
+    if ((int)blockIdx.x >= main_x) {
+        // passenger workgroups (dfd_act_bn_bwd_se): the squeeze-excite FC weight gradients of this block, which only AdamW reads —
+        // carried here instead of being a ~13 us launch of their own on the dependency chain
+        const int cb = (job.C + 63) / 64;
+        const int id = ((int)blockIdx.x - main_x) * (int)gridDim.y + (int)blockIdx.y;
+        if (id < cb * job.R)
+            se_fc_bwd_w_body(job.pooled, job.ws, job.N, job.C, job.R, job.dw1, job.db1, job.dw2, job.db2, job.accumulate, id % cb, id / cb, red);
+        return;
+    }
     const int t = threadIdx.x, vl = t % cm.cvb, rl = t / cm.cvb;
     const bool active = rl < cm.rpb;
     const int c0 = (blockIdx.y * cm.cvb + vl) * V;
@@ -143,7 +155,7 @@ k_act_bn_bwd(const T* __restrict__ D, const T* __restrict__ y, const float* __re
 #pragma unroll
     for (int j = 0; j < 2 * V; ++j) acc[j] = 0.f;
     if (active) {
-        const long step = (long)gridDim.x * cm.rpb;
+        const long step = (long)main_x * cm.rpb;
         for (long r = (long)blockIdx.x * cm.rpb + rl; r < rows; r += step) {
             float dv[V], yv[V], gt[V], dp[V];
             Vec<T>::load(y + r * C + c0, yv);
@@ -519,12 +531,18 @@ extern "C" int dfd_bias_grad(int dtype, const void* g, const float* row_scale, i
 template <typename T>
 static int act_bn_bwd_t(const void* D, const void* y, const float* gate, const float* dpool, const float* bnstate,
                         int act, void* dz, int N, int HW, int C, float* partials, int pcap, int* nparts,
-                        hipStream_t st) {
+                        hipStream_t st, const SeWgradJob* se = nullptr) {
     const ChanMap cm = make_chanmap(C, Vec<T>::N);
     const long rows = (long)N * HW;
     const int P = pick_parts(rows, cm.rpb, pcap);
     *nparts = P;
-    dim3 grid(P, cm.nvc);
+    SeWgradJob job{nullptr, nullptr, 0, 0, 0, nullptr, nullptr, nullptr, nullptr, 0};
+    int extra = 0;
+    if (se) {                                            // passenger workgroups behind the P x nvc main ones
+        job = *se;
+        extra = (((job.C + 63) / 64) * job.R + cm.nvc - 1) / cm.nvc;
+    }
+    dim3 grid(P + extra, cm.nvc);
     const float invHW = 1.0f / (float)HW;
     int mode;
     if (D && gate && dpool) mode = 1;
@@ -533,7 +551,7 @@ static int act_bn_bwd_t(const void* D, const void* y, const float* gate, const f
     else return DFD_EINVAL;
 #define LAUNCH_ABB(MODE) \
     hipLaunchKernelGGL((k_act_bn_bwd<T, ACT, MODE>), grid, dim3(DFD_THREADS), 0, st, (const T*)D, (const T*)y, gate, dpool, \
-                       bnstate, (T*)dz, rows, HW, C, invHW, cm, partials)
+                       bnstate, (T*)dz, rows, HW, C, invHW, cm, partials, P, job)
     DISPATCH_ACT(act, {
         if (mode == 0) LAUNCH_ABB(0);
         else if (mode == 1) LAUNCH_ABB(1);
@@ -572,6 +590,20 @@ static size_t pool_ws_bytes(int N, int HW, int C, int vec) {
     if (s <= 1) return 0;
     return (size_t)s * N * C * sizeof(float);
 }
+// dfd_act_bn_bwd with the block's squeeze-excite FC weight gradients riding along (include/dfd_hip.h)
+extern "C" int dfd_act_bn_bwd_se(int dtype, const void* D, const void* y, const float* gate, const float* dpool,
+                                 const float* bnstate, int act, void* dz, int N, int HW, int C, float* partials, int pcap,
+                                 int* nparts, const float* se_pooled, const float* se_ws, int R, float* dw1, float* db1, float* dw2,
+                                 float* db2, int accumulate, dfd_stream stream) {
+    if (!shape_ok(dtype, N, HW, C) || !y || !bnstate || !dz || !partials || !nparts || pcap < 1) return DFD_EINVAL;
+    if (!se_pooled || !se_ws || !dw1 || !dw2 || R < 1) return DFD_EINVAL;
+    const SeWgradJob job{se_pooled, se_ws, N, C, R, dw1, db1, dw2, db2, accumulate};
+    hipStream_t st = (hipStream_t)stream;
+    return dtype == DFD_BF16
+               ? act_bn_bwd_t<bf16>(D, y, gate, dpool, bnstate, act, dz, N, HW, C, partials, pcap, nparts, st, &job)
+               : act_bn_bwd_t<float>(D, y, gate, dpool, bnstate, act, dz, N, HW, C, partials, pcap, nparts, st, &job);
+}
+
 extern "C" size_t dfd_pool_ws(int dtype, int N, int HW, int C) {
     if (!shape_ok(dtype, N, HW, C)) return 0;
     return pool_ws_bytes(N, HW, C, dtype == DFD_BF16 ? Vec<bf16>::N : Vec<float>::N);
@@ -705,4 +737,4 @@ extern "C" int dfd_bn_bwd_finalize(const float* partials, int nparts, int C, dou
                                   nullptr, accumulate, coef, stream);
 }
 
-extern "C" int dfd_version(void) { return 133; }   // see include/dfd_hip.h
+extern "C" int dfd_version(void) { return 134; }   // see include/dfd_hip.h

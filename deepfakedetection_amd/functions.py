@@ -83,6 +83,8 @@ def eval_fused_enabled(elems: int, dtype: torch.dtype) -> bool:
 
 
 EVAL_FUSED_MAX_ELEMS = 32 << 20
+# DFD_SE_PASSENGER=0: the squeeze-excite FC weight gradients as a launch of their own (A/B switch)
+SE_WGRAD_PASSENGER = os.environ.get("DFD_SE_PASSENGER", "1") != "0"
 
 
 @contextlib.contextmanager
@@ -291,11 +293,14 @@ class MBConvFunction(torch.autograd.Function):
         # ---- squeeze-excite backward
         want_se = need[7] or need[8] or need[9] or need[10]
         se_outs = (_dest(ctx, 7, (R, Cmid)), _dest(ctx, 8, (R,)), _dest(ctx, 9, (Cmid, R)), _dest(ctx, 10, (Cmid,)))
-        dpooled, dw1, db1, dw2, db2 = K.se_bwd(D, y2, st2, ACT_SILU, gate, hpre, pooled, w1, w2t, ACT_SILU, want_se, se_outs)
+        # the FC weight gradients (read by the optimizer only) ride along with the next launch instead of being one of their own
+        se_res = K.se_bwd(D, y2, st2, ACT_SILU, gate, hpre, pooled, w1, w2t, ACT_SILU, want_se, se_outs, defer_wgrad=SE_WGRAD_PASSENGER)
+        dpooled, dw1, db1, dw2, db2 = se_res[:5]
+        se_job = se_res[5] if SE_WGRAD_PASSENGER else None
+        # ---- SiLU' and depthwise BN backward
+        dz2, parts, n = K.act_bn_bwd(D, y2, gate, dpooled, st2, ACT_SILU, se_job=se_job)
         if dw1 is not None:
             dw1, dw2 = dw1.view(dw1.shape[0], -1, 1, 1), dw2.view(dw2.shape[0], -1, 1, 1)
-        # ---- SiLU' and depthwise BN backward
-        dz2, parts, n = K.act_bn_bwd(D, y2, gate, dpooled, st2, ACT_SILU)
         coef2, dg_dw, db_dw = K.bn_bwd_finalize(parts, n, N * Ho * Wo, g_dw, st2, tr, need[5] or need[6],
                                                 _dest(ctx, 5, (Cmid,)), _dest(ctx, 6, (Cmid,)))
         kk = geom.kernel

@@ -392,12 +392,20 @@ def bias_grad(g: torch.Tensor, row_scale: torch.Tensor | None = None, out: torch
 
 
 def act_bn_bwd(D: torch.Tensor | None, y: torch.Tensor, gate: torch.Tensor | None, dpool: torch.Tensor | None,
-               state: torch.Tensor, act: int):
+               state: torch.Tensor, act: int, se_job: tuple | None = None):
+    """se_job: what se_bwd(defer_wgrad=True) returned — the block's squeeze-excite FC weight gradients then ride along as extra
+    workgroups of this launch (dfd_act_bn_bwd_se) instead of being a launch of their own."""
     _chk_nhwc(y)
     N, H, W, C = y.shape
     dz = torch.empty_like(y)
     parts = partials_buf(y.device, C)
     n = ctypes.c_int(0)
+    if se_job is not None:
+        pooled, ws, R, dw1, db1, dw2, db2 = se_job
+        check(_L().dfd_act_bn_bwd_se(_dt(y), _p(D), _p(y), _p(gate), _p(dpool), _p(state), act, _p(dz), N, H * W, C, _p(parts),
+                                     MAX_PARTIALS, ctypes.byref(n), _p(pooled), _p(ws), R, _p(dw1), _p(db1), _p(dw2), _p(db2), 0,
+                                     _stream()), "dfd_act_bn_bwd_se", str(tuple(y.shape)))
+        return dz, parts, n.value
     check(_L().dfd_act_bn_bwd(_dt(y), _p(D), _p(y), _p(gate), _p(dpool), _p(state), act, _p(dz), N, H * W, C, _p(parts),
                               MAX_PARTIALS, ctypes.byref(n), _stream()), "dfd_act_bn_bwd", str(tuple(y.shape)))
     return dz, parts, n.value
@@ -536,8 +544,11 @@ def se_fwd(y: torch.Tensor, state: torch.Tensor, act_in: int, w1, b1, w2, b2, ac
 
 
 def se_bwd(D, y, state, act_in: int, gate, hpre, pooled, w1, w2t, act: int, want_param_grads: bool = True,
-           outs=(None, None, None, None)):
-    """pool_bwd_reduce + se_fc_bwd in three launches (dfd_se_bwd): returns dpooled, dw1, db1, dw2, db2."""
+           outs=(None, None, None, None), defer_wgrad: bool = False):
+    """pool_bwd_reduce + se_fc_bwd in three launches (dfd_se_bwd): returns dpooled, dw1, db1, dw2, db2.
+    defer_wgrad (with want_param_grads): the third launch — the FC weight gradients, which only the optimizer reads — is left out
+    and a sixth value is returned, the job for act_bn_bwd(se_job=...), whose launch then carries it; dw1 .. db2 are valid after
+    that call.  The caller must make it its NEXT launch (the job points into this call's scratch workspace)."""
     _chk_nhwc(y)
     N, H, W, C = y.shape
     R = w1.shape[0]
@@ -553,9 +564,13 @@ def se_bwd(D, y, state, act_in: int, gate, hpre, pooled, w1, w2t, act: int, want
     else:
         dw1 = db1 = dw2 = db2 = None
     pws = _pool_workspace(y, N, H * W, C)
+    defer = defer_wgrad and want_param_grads
     check(_L().dfd_se_bwd(_dt(y), _p(D), _p(y), _p(state), act_in, N, H * W, C, _p(gate), _p(hpre), _p(pooled), _p(w1), _p(w2t),
-                          R, act, _p(dgate), _p(dpooled), _p(dw1), _p(db1), _p(dw2), _p(db2), 0, _p(pws), _nbytes(pws), _p(ws),
+                          R, act, _p(dgate), _p(dpooled), None if defer else _p(dw1), None if defer else _p(db1),
+                          None if defer else _p(dw2), None if defer else _p(db2), 0, _p(pws), _nbytes(pws), _p(ws),
                           _stream()), "dfd_se_bwd")
+    if defer_wgrad:
+        return dpooled, dw1, db1, dw2, db2, ((pooled, ws, R, dw1, db1, dw2, db2) if defer else None)
     return dpooled, dw1, db1, dw2, db2
 
 

@@ -77,7 +77,7 @@ typedef void* dfd_stream;          /* a hipStream_t */
  * 130 = dfd_tune; the bf16 depthwise entry points run on the matrix cores where the shape allows (same signatures);
  * 131 = dfd_augment_u8, dfd_gemm_plan, dfd_dw_mm_plan, dfd_pwconv_bwd_fused;
  * 132 = dfd_pw_ntd_plan (mid-size 1x1 layers on the LDS-DMA ring kernel; same entry points), tune keys 4-7;
- * 133 = dfd_attn_scores / dfd_attn_apply. */
+ * 133 = dfd_attn_scores / dfd_attn_apply; 134 = dfd_act_bn_bwd_se. */
 int dfd_version(void);
 
 /* Planner knobs (A/B switches and sizes the host-side kernel selection reads).  Process-wide plain ints: set them once at
@@ -188,6 +188,15 @@ int dfd_act_bn_bwd(int dtype, const void* D, const void* y, const float* gate,
                    const float* dpool, const float* bnstate, int act, void* dz,
                    int N, int HW, int C, float* partials, int pcap, int* nparts,
                    dfd_stream stream);
+/* dfd_act_bn_bwd with the squeeze-excite FC weight gradients of the same block riding along as extra workgroups of the launch:
+ * dw1[R][C] = sum_n dh[n][r] pooled[n][c], db1, dw2[C][R] = sum_n g[n][c] h[n][r], db2, from dfd_se_bwd's workspace se_ws
+ * (= [g: N x C | dh: N x R | h: N x R]) — what dfd_se_bwd's third launch computes when it is given dw1 / dw2 (pass NULL there).
+ * Only AdamW reads these gradients, so they need not be a launch of their own on the block's dependency chain; same summation
+ * order, same bits.  The workspace must stay untouched between dfd_se_bwd and this call (both on `stream`).                     */
+int dfd_act_bn_bwd_se(int dtype, const void* D, const void* y, const float* gate, const float* dpool,
+                      const float* bnstate, int act, void* dz, int N, int HW, int C, float* partials, int pcap,
+                      int* nparts, const float* se_pooled, const float* se_ws, int R, float* dw1, float* db1, float* dw2,
+                      float* db2, int accumulate, dfd_stream stream);
 /* pooled[n,c] = mean_hw act(scale*y+shift): SE squeeze and the classifier's
  * global average pool.
  * ws (optional, may be NULL): dfd_pool_ws() bytes of scratch; lets the library split large

@@ -547,6 +547,20 @@ def test_se_branch_in_one_call_each_way(rd, case):
         assert torch.equal(a, b), name
     dp_only = K.se_bwd(D, y, st, R.ACT_SILU, g0, h0, pooled0, w1, w2t, R.ACT_SILU, want_param_grads=False)
     assert torch.equal(dp_only[0], want[0]) and dp_only[1] is None
+    # the FC weight gradients as passenger workgroups of the next launch (dfd_act_bn_bwd_se): same bits as the launch of their own,
+    # and the host launch's own results (dz, statistics) are untouched
+    dz0, parts0, n0 = K.act_bn_bwd(D, y, g0, want[0], st, R.ACT_SILU)
+    parts0 = parts0[: n0 * 2 * C].clone()
+    later = K.se_bwd(D, y, st, R.ACT_SILU, g0, h0, pooled0, w1, w2t, R.ACT_SILU, defer_wgrad=True)
+    assert torch.equal(later[0], want[0]) and later[5] is not None
+    for t in later[1:5]:
+        t.fill_(float("nan"))                   # (nothing has computed them yet)
+    dz1, parts1, n1 = K.act_bn_bwd(D, y, g0, later[0], st, R.ACT_SILU, se_job=later[5])
+    assert n1 == n0 and torch.equal(dz1, dz0) and torch.equal(parts1[: n1 * 2 * C], parts0)
+    for a, b, name in zip(later[1:5], want[1:], ("dw1", "db1", "dw2", "db2")):
+        assert torch.equal(a, b), f"passenger {name}"
+    none_job = K.se_bwd(D, y, st, R.ACT_SILU, g0, h0, pooled0, w1, w2t, R.ACT_SILU, want_param_grads=False, defer_wgrad=True)
+    assert none_job[5] is None and none_job[1] is None
 
 
 @pytest.mark.parametrize("rd", DT)
