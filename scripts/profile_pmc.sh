@@ -19,4 +19,5 @@ run TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum
 run SQ SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY GRBM_GUI_ACTIVE
 python3 -c "import sys; sys.path.insert(0, '$REPO'); from deepfakedetection_amd.build import source_digest; print(source_digest())" > "$OUT/csrc_sha256.txt"
 find "$OUT" -name "*agent_info.csv" -delete
+find "$OUT" -name "*kernel_trace.csv" -delete          # tens of MB per pass; the counter files carry the timestamps
 ls -la "$OUT"
