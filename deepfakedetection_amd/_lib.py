@@ -99,6 +99,8 @@ SIGNATURES: dict[str, tuple] = {
     "dfd_bn_eval_coeffs_multi": (c_int, [P, c_int, P]),
     "dfd_sum_batch_begin": (c_int, []),
     "dfd_sum_batch_end": (c_int, []),
+    "dfd_sum_batch_end_deferred": (c_int, []),
+    "dfd_sum_passengers_flush": (c_int, [P]),
     "dfd_se_fwd": (c_int, [c_int, P, P, c_int, c_int, c_int, c_int, P, P, P, P, c_int, c_int, P, P, P, P, P, c_size_t, P]),
     "dfd_se_bwd": (c_int, [c_int, P, P, P, c_int, c_int, c_int, c_int, P, P, P, P, P, c_int, c_int, P, P, P, P, P, P, c_int,
                            P, c_size_t, P, P]),

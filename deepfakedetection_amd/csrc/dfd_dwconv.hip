@@ -1,11 +1,12 @@
 // dfd_dwconv.hip — fixed-order reduction of per-workgroup partial slabs (used by every
 // weight-gradient kernel).  The depthwise kernels live in dfd_dwfwd.hip / dfd_dwbwd.hip.
 #include "dfd_common.h"
+#include "dfd_sum.h"
+#include <mutex>
 
 // out[i] (+)= sum_p partials[p][i], in a fixed order.  Two stages when there are many
 // partial rows: groups of SUM_GROUP rows are summed by independent workgroups into the
 // rows that FOLLOW the slab in the workspace ([P .. P + ceil(P/SUM_GROUP))), then those.
-#define SUM_GROUP 32
 __global__ void k_sum_partials(const float* __restrict__ partials, int P, long L, float* __restrict__ out,
                                long out_stride, int accumulate) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -29,59 +30,83 @@ __global__ void k_sum_partials(const float* __restrict__ partials, int P, long L
 // every weight-gradient kernel launched from that thread is recorded instead of launched, and the batch is added up by
 // ONE pair of launches (stage 1 over all (job, group) pairs, stage 2 over all jobs) — same grouping, same order, same
 // bits as the unbatched form, 2 launches instead of up to 2 per weight gradient (they are ~5 us each, launch-floor bound).
-#define SUM_MAX_JOBS 8
-struct SumJobs {
-    const float* parts[SUM_MAX_JOBS];
-    float* out[SUM_MAX_JOBS];
-    long L[SUM_MAX_JOBS];
-    int P[SUM_MAX_JOBS], acc[SUM_MAX_JOBS];
-    int gofs[SUM_MAX_JOBS + 1];             // first stage-1 group of each job (jobs with P <= SUM_GROUP have none)
-    int n;
-};
-__device__ __forceinline__ float sum_rows_ordered(const float* __restrict__ base, int p0, int p1, long L, long i) {
-    float s = 0.f;
-    int p = p0;
-    for (; p + 8 <= p1; p += 8) {
-        float u[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) u[k] = base[(long)(p + k) * L + i];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) s += u[k];
-    }
-    for (; p < p1; ++p) s += base[(long)p * L + i];
-    return s;
-}
-__global__ void k_sum_multi(SumJobs J, int stage) {
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (stage == 1) {
-        int j = 0;
-        while (j + 1 < J.n && (int)blockIdx.y >= J.gofs[j + 1]) ++j;
-        if (i >= J.L[j]) return;
-        const int g = blockIdx.y - J.gofs[j], p0 = g * SUM_GROUP;
-        const int p1 = (p0 + SUM_GROUP < J.P[j]) ? p0 + SUM_GROUP : J.P[j];
-        float* mid = const_cast<float*>(J.parts[j]) + (long)J.P[j] * J.L[j];
-        mid[(long)g * J.L[j] + i] = sum_rows_ordered(J.parts[j], p0, p1, J.L[j], i);
-    } else {
-        const int j = blockIdx.y;
-        if (i >= J.L[j]) return;
-        const int P = J.P[j];
-        float s;
-        if (P > SUM_GROUP) s = sum_rows_ordered(J.parts[j] + (long)P * J.L[j], 0, (P + SUM_GROUP - 1) / SUM_GROUP, J.L[j], i);
-        else s = sum_rows_ordered(J.parts[j], 0, P, J.L[j], i);
-        float* o = J.out[j] + i;
-        *o = (J.acc[j] ? *o : 0.f) + s;
-    }
-}
+__global__ void k_sum_multi(SumJobs J, int stage) { sum_multi_body(J, stage, blockIdx.x, blockIdx.y); }
 static thread_local struct { bool on; SumJobs j; hipStream_t st; } tl_batch = {false, {}, nullptr};
 
+static void sum_jobs_finish(SumJobs& J) {
+    long maxL = 0;
+    for (int k = 0; k < J.n; ++k) if (J.L[k] > maxL) maxL = J.L[k];
+    J.gx = (int)((maxL + 255) / 256);
+}
+static void sum_jobs_launch(const SumJobs& J, int stage, hipStream_t st) {
+    if (J.n == 0) return;
+    if (stage == 1) { if (J.gofs[J.n] > 0) hipLaunchKernelGGL(k_sum_multi, dim3(J.gx, J.gofs[J.n]), dim3(256), 0, st, J, 1); }
+    else hipLaunchKernelGGL(k_sum_multi, dim3(J.gx, J.n), dim3(256), 0, st, J, 2);
+}
 static int sum_batch_flush() {
     SumJobs& J = tl_batch.j;
     if (J.n == 0) return DFD_OK;
-    long maxL = 0;
-    for (int k = 0; k < J.n; ++k) if (J.L[k] > maxL) maxL = J.L[k];
-    const unsigned gx = (unsigned)((maxL + 255) / 256);
-    if (J.gofs[J.n] > 0) hipLaunchKernelGGL(k_sum_multi, dim3(gx, J.gofs[J.n]), dim3(256), 0, tl_batch.st, J, 1);
-    hipLaunchKernelGGL(k_sum_multi, dim3(gx, J.n), dim3(256), 0, tl_batch.st, J, 2);
+    sum_jobs_finish(J);
+    sum_jobs_launch(J, 1, tl_batch.st);
+    sum_jobs_launch(J, 2, tl_batch.st);
+    J.n = 0;
+    J.gofs[0] = 0;
+    return DFD_CHECK_LAUNCH();
+}
+
+// ---- passengers.  A batch handed over by dfd_sum_batch_end_deferred() is not launched: its two stages ride along as extra
+// workgroups of the next two launches on its stream that can carry them (dfd_act_bn_bwd: one per network block), and
+// dfd_sum_passengers_flush() launches whatever is still waiting (the end of the backward pass).  The state is process-wide and
+// keyed by the stream (the batch is closed on autograd's thread, the flush comes from the thread that called backward()).
+static std::mutex g_pass_mu;
+static struct { SumJobs j; hipStream_t st; } g_pass[2];          // [0]: stage 1 pending, [1]: stage 2 pending (n = 0: free)
+
+void dfd_sum_passengers_take(hipStream_t st, SumJobs* stage1, SumJobs* stage2) {
+    stage1->n = 0;
+    stage2->n = 0;
+    std::lock_guard<std::mutex> lock(g_pass_mu);
+    if (g_pass[1].j.n > 0 && g_pass[1].st == st) { *stage2 = g_pass[1].j; g_pass[1].j.n = 0; }
+    if (g_pass[0].j.n > 0 && g_pass[0].st == st && g_pass[1].j.n == 0) {
+        *stage1 = g_pass[0].j;
+        g_pass[1] = g_pass[0];
+        g_pass[0].j.n = 0;
+    }
+}
+extern "C" int dfd_sum_passengers_flush(dfd_stream stream) {
+    hipStream_t st = (hipStream_t)stream;
+    std::lock_guard<std::mutex> lock(g_pass_mu);
+    if (g_pass[1].j.n > 0 && g_pass[1].st == st) { sum_jobs_launch(g_pass[1].j, 2, st); g_pass[1].j.n = 0; }
+    if (g_pass[0].j.n > 0 && g_pass[0].st == st) {
+        sum_jobs_launch(g_pass[0].j, 1, st);
+        sum_jobs_launch(g_pass[0].j, 2, st);
+        g_pass[0].j.n = 0;
+    }
+    return DFD_CHECK_LAUNCH();
+}
+extern "C" int dfd_sum_batch_end_deferred(void) {
+    if (!tl_batch.on) return DFD_EINVAL;
+    tl_batch.on = false;
+    SumJobs& J = tl_batch.j;
+    if (J.n == 0) return DFD_OK;
+    sum_jobs_finish(J);
+    hipStream_t st = tl_batch.st;
+    std::lock_guard<std::mutex> lock(g_pass_mu);
+    // the stage-1 slot must be free: a batch nobody carried since the last hand-over is launched now (any order is fine: batches
+    // write disjoint outputs)
+    if (g_pass[0].j.n > 0) {
+        if (g_pass[1].j.n > 0) { sum_jobs_launch(g_pass[1].j, 2, g_pass[1].st); g_pass[1].j.n = 0; }
+        sum_jobs_launch(g_pass[0].j, 1, g_pass[0].st);
+        sum_jobs_launch(g_pass[0].j, 2, g_pass[0].st);
+        g_pass[0].j.n = 0;
+    }
+    if (J.gofs[J.n] == 0) {                              // no job has more than SUM_GROUP rows: stage 2 only
+        if (g_pass[1].j.n > 0) { sum_jobs_launch(g_pass[1].j, 2, g_pass[1].st); g_pass[1].j.n = 0; }
+        g_pass[1].j = J;
+        g_pass[1].st = st;
+    } else {
+        g_pass[0].j = J;
+        g_pass[0].st = st;
+    }
     J.n = 0;
     J.gofs[0] = 0;
     return DFD_CHECK_LAUNCH();

@@ -7,6 +7,7 @@
 // partial row per workgroup (fixed summation order => reproducible results).
 #include "dfd_common.h"
 #include "dfd_se.h"
+#include "dfd_sum.h"
 
 // ------------------------------------------------------------------ bn_act_apply
 template <typename T, int ACT, bool HAS_RES, bool HAS_RS>
@@ -131,16 +132,25 @@ template <typename T, int ACT, int MODE>
 __global__ void __launch_bounds__(DFD_THREADS)
 k_act_bn_bwd(const T* __restrict__ D, const T* __restrict__ y, const float* __restrict__ gate,
              const float* __restrict__ dpool, const float* __restrict__ bnstate, T* __restrict__ dz,
-             long rows, int HW, int C, float invHW, ChanMap cm, float* __restrict__ partials, int main_x, SeWgradJob job) {
+             long rows, int HW, int C, float invHW, ChanMap cm, float* __restrict__ partials, int main_x, SeWgradJob job,
+             SumJobs sum1, SumJobs sum2) {
     constexpr int V = Vec<T>::N;
     __shared__ float red[DFD_THREADS * 2 * V];
     if ((int)blockIdx.x >= main_x) {
-        // passenger workgroups (dfd_act_bn_bwd_se): the squeeze-excite FC weight gradients of this block, which only AdamW reads —
-        // carried here instead of being a ~13 us launch of their own on the dependency chain
-        const int cb = (job.C + 63) / 64;
-        const int id = ((int)blockIdx.x - main_x) * (int)gridDim.y + (int)blockIdx.y;
-        if (id < cb * job.R)
+        // passenger workgroups: work that only the optimizer reads, carried here instead of being ~6-13 us launches of its own on the
+        // dependency chain — the squeeze-excite FC weight gradients of this block (dfd_act_bn_bwd_se), stage 1 / stage 2 of the
+        // batched weight-gradient slab sums handed over by earlier blocks (dfd_sum_batch_end_deferred)
+        int id = ((int)blockIdx.x - main_x) * (int)gridDim.y + (int)blockIdx.y;
+        const int cb = (job.C + 63) / 64, nse = job.dw1 ? cb * job.R : 0;
+        if (id < nse) {
             se_fc_bwd_w_body(job.pooled, job.ws, job.N, job.C, job.R, job.dw1, job.db1, job.dw2, job.db2, job.accumulate, id % cb, id / cb, red);
+            return;
+        }
+        id -= nse;
+        const int n1 = sum1.n > 0 ? sum1.gx * sum1.gofs[sum1.n] : 0;
+        if (id < n1) { sum_multi_body(sum1, 1, id % sum1.gx, id / sum1.gx); return; }
+        id -= n1;
+        if (sum2.n > 0 && id < sum2.gx * sum2.n) sum_multi_body(sum2, 2, id % sum2.gx, id / sum2.gx);
         return;
     }
     const int t = threadIdx.x, vl = t % cm.cvb, rl = t / cm.cvb;
@@ -537,11 +547,14 @@ static int act_bn_bwd_t(const void* D, const void* y, const float* gate, const f
     const int P = pick_parts(rows, cm.rpb, pcap);
     *nparts = P;
     SeWgradJob job{nullptr, nullptr, 0, 0, 0, nullptr, nullptr, nullptr, nullptr, 0};
-    int extra = 0;
+    SumJobs sum1, sum2;
+    dfd_sum_passengers_take(st, &sum1, &sum2);           // slab sums waiting for a launch on this stream (usually none)
+    long passengers = (sum1.n > 0 ? (long)sum1.gx * sum1.gofs[sum1.n] : 0) + (sum2.n > 0 ? (long)sum2.gx * sum2.n : 0);
     if (se) {                                            // passenger workgroups behind the P x nvc main ones
         job = *se;
-        extra = (((job.C + 63) / 64) * job.R + cm.nvc - 1) / cm.nvc;
+        passengers += (long)((job.C + 63) / 64) * job.R;
     }
+    const int extra = (int)((passengers + cm.nvc - 1) / cm.nvc);
     dim3 grid(P + extra, cm.nvc);
     const float invHW = 1.0f / (float)HW;
     int mode;
@@ -551,7 +564,7 @@ static int act_bn_bwd_t(const void* D, const void* y, const float* gate, const f
     else return DFD_EINVAL;
 #define LAUNCH_ABB(MODE) \
     hipLaunchKernelGGL((k_act_bn_bwd<T, ACT, MODE>), grid, dim3(DFD_THREADS), 0, st, (const T*)D, (const T*)y, gate, dpool, \
-                       bnstate, (T*)dz, rows, HW, C, invHW, cm, partials, P, job)
+                       bnstate, (T*)dz, rows, HW, C, invHW, cm, partials, P, job, sum1, sum2)
     DISPATCH_ACT(act, {
         if (mode == 0) LAUNCH_ABB(0);
         else if (mode == 1) LAUNCH_ABB(1);

@@ -129,6 +129,9 @@ class GradAllReducer:
     def __init__(self, params: Iterable[torch.nn.Parameter], bucket_bytes: int = 8 << 20, arena=None) -> None:
         self.params = [p for p in params if p.requires_grad]
         self.world = dist.get_world_size() if dist.is_initialized() else 1
+        # a bucket leaves as soon as its last backward kernel has been launched: weight-gradient sums may not wait for a carrier launch
+        from . import kernels as _K
+        _K.passenger_sums_enabled = False
         self.arena = arena                      # a GradArena (arena.py): flat, copy-free path
         self.bucket_elems = max(1, bucket_bytes // 4)
         # reverse order: the last layers' gradients are ready first in backward

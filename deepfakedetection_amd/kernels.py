@@ -201,8 +201,9 @@ def scratch(device: torch.device, name: str, nbytes: int) -> torch.Tensor:
             _sum_batch.keep.append(buf)                     # the recorded sums read it at sum_batch's exit
         return buf
     if _sum_batch.open:
-        # every weight gradient of an open batch keeps its own workspace until the batch is summed
-        name = f"{name}#{_sum_batch.count}"
+        # every weight gradient of an open batch keeps its own workspace until the batch is summed; with the sums riding along as
+        # passengers of later launches (sum_batch) that is up to two batches later: three generations of names
+        name = f"{name}#{_sum_batch.gen}#{_sum_batch.count}"
         _sum_batch.count += 1
     key = (device.index if device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream, name)
     buf = _scratch.get(key)
@@ -216,7 +217,7 @@ class _SumBatchState(threading.local):
     """Per host thread, like the library's own batch state (dfd_sum_batch_begin is thread-local)."""
 
     def __init__(self) -> None:
-        self.open, self.count, self.keep = False, 0, []
+        self.open, self.count, self.keep, self.gen, self.temp_dest = False, 0, [], 0, False
 
 
 _sum_batch = _SumBatchState()
@@ -233,14 +234,62 @@ def sum_batch():
         yield
         return
     check(_L().dfd_sum_batch_begin(), "dfd_sum_batch_begin")
-    _sum_batch.open, _sum_batch.count = True, 0
+    _sum_batch.open, _sum_batch.count, _sum_batch.temp_dest = True, 0, False
     try:
         yield
     finally:
         _sum_batch.open = False
-        rc = _L().dfd_sum_batch_end()
+        # (only when every gradient of the batch went straight into its arena slot, which autograd adopts as .grad without reading it)
+        if PASSENGER_SUMS and passenger_sums_enabled and not _sum_batch.temp_dest and _register_backward_flush():
+            # the sums are read by the optimizer only: instead of two launches at the end of every block they ride along as extra
+            # workgroups of the next two act_bn_bwd launches (one per block) and whatever is left is launched at the end of the
+            # backward pass (csrc/dfd_dwconv.hip, dfd_sum_batch_end_deferred)
+            rc = _L().dfd_sum_batch_end_deferred()
+            with _passenger_lock:
+                _passenger_keep.extend(_sum_batch.keep)     # (captured runs: the slabs live until the flush)
+            _sum_batch.gen = (_sum_batch.gen + 1) % 3
+        else:
+            rc = _L().dfd_sum_batch_end()
         _sum_batch.keep.clear()
         check(rc, "dfd_sum_batch_end")
+
+
+# ---- sums as passengers (see sum_batch).  DFD_PASSENGER_SUMS=0: two launches at the end of every block (A/B switch);
+# passenger_sums_enabled is cleared by dp.GradAllReducer: a gradient bucket may be handed to RCCL as soon as its last backward kernel
+# has been launched, which a sum still waiting for its carrier would not be part of.
+PASSENGER_SUMS = os.environ.get("DFD_PASSENGER_SUMS", "1") != "0"
+passenger_sums_enabled = True
+_passenger_lock = threading.Lock()
+_passenger_keep: list = []
+_passenger_flush_registered = False
+
+
+def flush_passengers() -> None:
+    """Launch every sum that still waits for a carrier on the current stream (the end of a backward pass; also safe to call at any
+    time on the stream the backward ran on)."""
+    global _passenger_flush_registered
+    with _passenger_lock:
+        _passenger_flush_registered = False
+        keep = list(_passenger_keep)
+        _passenger_keep.clear()
+    check(_L().dfd_sum_passengers_flush(_stream()), "dfd_sum_passengers_flush")
+    del keep
+
+
+def _register_backward_flush() -> bool:
+    """flush_passengers as an end-of-backward callback of the autograd engine, once per backward pass; False outside of one (the caller
+    then sums at once)."""
+    global _passenger_flush_registered
+    with _passenger_lock:
+        if _passenger_flush_registered:
+            return True
+    try:
+        torch.autograd.Variable._execution_engine.queue_callback(flush_passengers)
+    except RuntimeError:
+        return False
+    with _passenger_lock:
+        _passenger_flush_registered = True
+    return True
 
 
 def batched_sums(fn):
@@ -259,6 +308,9 @@ def _nbytes(t: torch.Tensor | None) -> int:
 def _dst(out: torch.Tensor | None, shape, device) -> torch.Tensor:
     """A caller-provided destination (gradient-arena slot) or a fresh f32 tensor."""
     if out is None:
+        # a fresh tensor is handed to autograd, which adds it to (or clones it into) .grad as soon as the Function returns: the open
+        # batch's sums may then not wait for a carrier launch (sum_batch)
+        _sum_batch.temp_dest = True
         return torch.empty(shape, dtype=torch.float32, device=device)
     if tuple(out.shape) != tuple(shape) or out.dtype != torch.float32 or not out.is_contiguous():
         raise ValueError(f"bad gradient destination {tuple(out.shape)} for {tuple(shape)}")

@@ -77,7 +77,7 @@ typedef void* dfd_stream;          /* a hipStream_t */
  * 130 = dfd_tune; the bf16 depthwise entry points run on the matrix cores where the shape allows (same signatures);
  * 131 = dfd_augment_u8, dfd_gemm_plan, dfd_dw_mm_plan, dfd_pwconv_bwd_fused;
  * 132 = dfd_pw_ntd_plan (mid-size 1x1 layers on the LDS-DMA ring kernel; same entry points), tune keys 4-7;
- * 133 = dfd_attn_scores / dfd_attn_apply; 134 = dfd_act_bn_bwd_se. */
+ * 133 = dfd_attn_scores / dfd_attn_apply; 134 = dfd_act_bn_bwd_se, dfd_sum_batch_end_deferred, dfd_sum_passengers_flush. */
 int dfd_version(void);
 
 /* Planner knobs (A/B switches and sizes the host-side kernel selection reads).  Process-wide plain ints: set them once at
@@ -107,6 +107,14 @@ int dfd_tune(int key, int value);
  * unaffected (the ABI stays re-entrant).  begin inside an open batch / end without one: DFD_EINVAL.                   */
 int dfd_sum_batch_begin(void);
 int dfd_sum_batch_end(void);
+/* dfd_sum_batch_end_deferred(): closes the batch like _end() but launches nothing — the two stages of the recorded sums ride along as
+ * extra workgroups of the next two dfd_act_bn_bwd / dfd_act_bn_bwd_se launches on their stream (one per network block; the sums are read by
+ * the optimizer only, so they need not sit on the backward pass's dependency chain), and dfd_sum_passengers_flush(stream) launches whatever
+ * is still waiting.  Contract on top of _end()'s: the workspaces stay untouched, and dw is valid, only after the SECOND carrying launch
+ * or the flush — callers keep three generations of workspaces and flush at the end of the backward pass (kernels.sum_batch).  A batch that
+ * finds the previous one still waiting launches that one at once.  Process-wide state keyed by the stream.                          */
+int dfd_sum_batch_end_deferred(void);
+int dfd_sum_passengers_flush(dfd_stream stream);
 
 /* ---------------------------------------------------------------- BatchNorm ---
  * F.batch_norm inside every conv-bn(-act) triple of the reference's modules

@@ -183,6 +183,35 @@ def test_arena_gradients_are_adopted_in_place():
     assert rel_err(twice, 2 * once) <= 1e-5
 
 
+def test_weight_gradient_sums_as_passengers_give_the_same_bits():
+    """kernels.sum_batch hands a block's weight-gradient slab sums to later launches (passenger workgroups of act_bn_bwd) and flushes
+    the rest at the end of the backward pass: the arena must hold the same bits as with two launches per block, and a second backward
+    that ACCUMULATES (temporary destinations that autograd adds) must not defer."""
+    from deepfakedetection_amd import kernels as K
+    _, HipAdamW, HipCrossEntropyLoss = _hip()
+    _, hip = make_pair("b0", "timm", 2)
+    hip.train()
+    opt = HipAdamW(hip.parameters(), lr=1e-4, weight_decay=5e-2)
+    x = torch.randn(8, 3, 96, 96, generator=torch.Generator().manual_seed(18)).cuda()
+    y = torch.zeros(8, dtype=torch.int64).cuda()
+    was = K.PASSENGER_SUMS, K.passenger_sums_enabled
+    got = []
+    try:
+        for flag in (True, False, True):
+            K.PASSENGER_SUMS, K.passenger_sums_enabled = flag, True
+            hip.eval(); hip.train()
+            opt.zero_grad(set_to_none=True)
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                loss = HipCrossEntropyLoss(0.1)(hip(x, [None] * len(hip.block_list()), None), y)
+            loss.backward()
+            assert opt.arena.holds_all_grads()
+            got.append(opt.arena.flat.clone())
+    finally:
+        K.PASSENGER_SUMS, K.passenger_sums_enabled = was
+    assert torch.isfinite(got[0]).all() and float(got[0].abs().max()) > 0
+    assert torch.equal(got[0], got[1]) and torch.equal(got[0], got[2])
+
+
 def test_bf16_autocast_train_close_to_f32_oracle():
     _, _, HipCrossEntropyLoss = _hip()
     ref, hip = make_pair("b0", "timm", 2)
