@@ -101,6 +101,7 @@ SIGNATURES: dict[str, tuple] = {
     "dfd_sum_batch_end": (c_int, []),
     "dfd_sum_batch_end_deferred": (c_int, []),
     "dfd_sum_passengers_flush": (c_int, [P]),
+    "dfd_sum_passengers_discard": (c_int, []),
     "dfd_se_fwd": (c_int, [c_int, P, P, c_int, c_int, c_int, c_int, P, P, P, P, c_int, c_int, P, P, P, P, P, c_size_t, P]),
     "dfd_se_bwd": (c_int, [c_int, P, P, P, c_int, c_int, c_int, c_int, P, P, P, P, P, c_int, c_int, P, P, P, P, P, P, c_int,
                            P, c_size_t, P, P]),

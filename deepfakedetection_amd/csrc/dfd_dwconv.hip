@@ -83,6 +83,14 @@ extern "C" int dfd_sum_passengers_flush(dfd_stream stream) {
     }
     return DFD_CHECK_LAUNCH();
 }
+// forget whatever still waits (a backward pass that ended in an exception never reached its flush: the jobs point at memory the next
+// pass may no longer own)
+extern "C" int dfd_sum_passengers_discard(void) {
+    std::lock_guard<std::mutex> lock(g_pass_mu);
+    g_pass[0].j.n = 0;
+    g_pass[1].j.n = 0;
+    return DFD_OK;
+}
 extern "C" int dfd_sum_batch_end_deferred(void) {
     if (!tl_batch.on) return DFD_EINVAL;
     tl_batch.on = false;

@@ -287,7 +287,11 @@ def _register_backward_flush() -> bool:
         torch.autograd.Variable._execution_engine.queue_callback(flush_passengers)
     except RuntimeError:
         return False
+    # the first batch of this backward pass: nothing may be waiting (the previous pass flushed); after a pass that died in an exception
+    # something is — drop it, its workspaces may be gone
+    check(_L().dfd_sum_passengers_discard(), "dfd_sum_passengers_discard")
     with _passenger_lock:
+        _passenger_keep.clear()
         _passenger_flush_registered = True
     return True
 

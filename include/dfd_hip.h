@@ -77,7 +77,7 @@ typedef void* dfd_stream;          /* a hipStream_t */
  * 130 = dfd_tune; the bf16 depthwise entry points run on the matrix cores where the shape allows (same signatures);
  * 131 = dfd_augment_u8, dfd_gemm_plan, dfd_dw_mm_plan, dfd_pwconv_bwd_fused;
  * 132 = dfd_pw_ntd_plan (mid-size 1x1 layers on the LDS-DMA ring kernel; same entry points), tune keys 4-7;
- * 133 = dfd_attn_scores / dfd_attn_apply; 134 = dfd_act_bn_bwd_se, dfd_sum_batch_end_deferred, dfd_sum_passengers_flush. */
+ * 133 = dfd_attn_scores / dfd_attn_apply; 134 = dfd_act_bn_bwd_se, dfd_sum_batch_end_deferred, dfd_sum_passengers_flush / _discard. */
 int dfd_version(void);
 
 /* Planner knobs (A/B switches and sizes the host-side kernel selection reads).  Process-wide plain ints: set them once at
@@ -115,6 +115,9 @@ int dfd_sum_batch_end(void);
  * finds the previous one still waiting launches that one at once.  Process-wide state keyed by the stream.                          */
 int dfd_sum_batch_end_deferred(void);
 int dfd_sum_passengers_flush(dfd_stream stream);
+/* drops every waiting batch without launching it (the first batch of a backward pass calls it: after a pass that ended in an exception
+ * the waiting jobs point at memory the next pass may no longer own) */
+int dfd_sum_passengers_discard(void);
 
 /* ---------------------------------------------------------------- BatchNorm ---
  * F.batch_norm inside every conv-bn(-act) triple of the reference's modules
