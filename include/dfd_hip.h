@@ -88,7 +88,9 @@ int dfd_version(void);
  *   1 DFD_TUNE_DW_LDS_KB  LDS budget of one matrix-core depthwise workgroup in KiB                           (default 156)
  *   2 DFD_TUNE_DW_GRID    workgroups a matrix-core depthwise launch aims for                                 (default 256)
  *   3 DFD_TUNE_DEBUG      timing-only ablations of the matrix-core depthwise kernels (results are WRONG when non-zero): bit 0
- *                         no activation arithmetic, 1 no tap loop, 2 no stores, 3 no loads                   (default 0)
+ *                         no activation arithmetic, 1 no tap loop, 2 no stores, 3 no loads; bits 8-12: the same for the LDS-DMA ring
+ *                         kernel of dfd_pwconv_fwd (8 no prologue arithmetic, 9 no MFMAs, 10 no weight DMA, 11 no activation DMA,
+ *                         12 no epilogue; scripts/pw_mid_ablate.py)                                         (default 0)
  *   4 DFD_TUNE_PW_NTD     bit 0: dfd_pwconv_fwd runs bf16 layers of 1 k .. 64 k rows on the LDS-DMA ring kernel (dfd_pw_ntd_plan
  *                         tells which); 0 = the register-staged tile kernel everywhere (A/B runs)             (default 1)
  *   5 DFD_TUNE_NTD_NS     stages of that kernel's LDS ring, 2..4; 0 = chosen from the LDS budget              (default 0)
