@@ -44,6 +44,25 @@ def test_bad_arguments_are_rejected_without_a_gpu(lib):
     assert lib.dfd_pwconv_wgrad_ws(1000, 16, 96) > 0
 
 
+def test_kernel_planners_answer_without_a_gpu(lib):
+    """Host-side kernel selection (no launch): which column-tile width the LDS-DMA ring kernel picks for EfficientNet-B0's mid-size
+    1x1 layers at batch 256, what it leaves to the other kernels, and that the planner knobs switch it."""
+    plan = lib.dfd_pw_ntd_plan
+    assert plan(12544, 1152, 192) == 192 and plan(50176, 480, 80) == 96 and plan(50176, 672, 112) == 128
+    assert plan(12544, 192, 1152) == 192 and plan(12544, 1152, 320) == 192 and plan(6272, 240, 40) == 64
+    assert plan(960, 480, 80) == 0            # fewer than 16 row tiles
+    assert plan(200704, 240, 40) == 0         # more row tiles than partial rows
+    assert plan(50176, 40, 240) == 0          # K below one 64-wide step
+    try:
+        assert lib.dfd_tune(4, 0) == 0 and plan(12544, 1152, 192) == 0
+        assert lib.dfd_tune(4, 1) == 0 and lib.dfd_tune(6, 96) == 0 and plan(12544, 1152, 192) == 96
+    finally:
+        lib.dfd_tune(4, 1)
+        lib.dfd_tune(6, 0)
+    assert lib.dfd_tune(99, 0) != 0
+    assert lib.dfd_sum_passengers_discard() == 0 and lib.dfd_sum_batch_end_deferred() != 0      # no open batch: DFD_EINVAL
+
+
 def test_missing_library_raises_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(_lib, "_lib", None)
     monkeypatch.setattr(_lib, "LIB_PATH", tmp_path / "nope.so")
