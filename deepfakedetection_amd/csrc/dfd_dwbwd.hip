@@ -12,6 +12,7 @@
 // staged-column map is a compile-time table once the parity of pad_left is a template
 // parameter (PLP).
 #include "dfd_dwq.h"
+#include "dfd_dwm.h"
 #ifndef DFD_ABLATE
 #define DFD_ABLATE 0   // timing experiments (scripts/build_variant.sh): 1 = staging only, 2 = taps only
 #endif
@@ -215,8 +216,8 @@ static int dw_bwd_data_q_t(const void* dz, const void* y, const float* coef, con
     if (epi && (!in_bnstate || !partials || !nparts || pcap < 1)) return DFD_EINVAL;
     if (hc && !y) return DFD_EINVAL;
     int cap = epi ? (pcap < DFD_MAX_PARTIALS ? pcap : DFD_MAX_PARTIALS) : DFD_MAX_PARTIALS;
-    int gy = DFD_DW_GRID / nchunks;
-    if (gy < 64) gy = 64;
+    int gy = dfd_tune_get(DFD_TUNE_DWQ_GRID_BWD) / nchunks;
+    if (gy < dfd_tune_get(DFD_TUNE_DWQ_GRID_MIN)) gy = dfd_tune_get(DFD_TUNE_DWQ_GRID_MIN);
     if (gy > cap) gy = cap;
     if (gy > g.nwork) gy = g.nwork;
     if (epi) *nparts = gy;
@@ -381,7 +382,7 @@ static bool dw_wgrad_q_geom(const dfd_dwconv_shape* s, int vec, DwQGeom* g, int*
 }
 
 static int dw_wgrad_q_parts(const DwQGeom& g, int k, int nchunks) {
-    int want = DFD_DW_GRID / (nchunks > 0 ? nchunks : 1);
+    int want = dfd_tune_get(DFD_TUNE_DWQ_GRID_WGRAD) / (nchunks > 0 ? nchunks : 1);
     if (want < 32) want = 32;
     const long per = (long)g.C * k * k * 4;
     long cap = (16l << 20) / per;

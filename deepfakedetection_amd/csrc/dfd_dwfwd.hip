@@ -282,8 +282,8 @@ static int dw_fwd_q_t(const void* x, const float* in_bnstate, int in_act, const 
                ((s->C * (int)sizeof(T)) % 128 != 0 || (cvb * 16) % 128 != 0)) ? 1 : 0;
     const bool stats = partials != nullptr;
     int cap = stats ? (pcap < DFD_MAX_PARTIALS ? pcap : DFD_MAX_PARTIALS) : DFD_MAX_PARTIALS;
-    int gy = DFD_DW_GRID / nchunks;
-    if (gy < 64) gy = 64;
+    int gy = dfd_tune_get(DFD_TUNE_DWQ_GRID_FWD) / nchunks;
+    if (gy < dfd_tune_get(DFD_TUNE_DWQ_GRID_MIN)) gy = dfd_tune_get(DFD_TUNE_DWQ_GRID_MIN);
     if (gy > cap) gy = cap;
     if (gy > g.nwork) gy = g.nwork;
     if (stats) *nparts = gy;

@@ -4,7 +4,9 @@
 
 typedef float f2 __attribute__((ext_vector_type(2)));
 
-// workgroups a depthwise launch aims for (all channel chunks together); 1024 are co-resident at 4 per CU
+// workgroups a depthwise launch aims for (all channel chunks together); 1024 are co-resident at 4 per CU.  The training kernels
+// (forward, data gradient, weight gradient) read theirs from dfd_tune keys 8-10 (default 1024, dfd_dwmm.hip); this constant is what
+// the eval-form forward and the fused backward (off by default) still use.
 #ifndef DFD_DW_GRID
 #define DFD_DW_GRID 2048
 #endif

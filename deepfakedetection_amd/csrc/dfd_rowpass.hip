@@ -750,4 +750,4 @@ extern "C" int dfd_bn_bwd_finalize(const float* partials, int nparts, int C, dou
                                   nullptr, accumulate, coef, stream);
 }
 
-extern "C" int dfd_version(void) { return 134; }   // see include/dfd_hip.h
+extern "C" int dfd_version(void) { return 135; }   // see include/dfd_hip.h

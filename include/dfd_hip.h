@@ -77,7 +77,8 @@ typedef void* dfd_stream;          /* a hipStream_t */
  * 130 = dfd_tune; the bf16 depthwise entry points run on the matrix cores where the shape allows (same signatures);
  * 131 = dfd_augment_u8, dfd_gemm_plan, dfd_dw_mm_plan, dfd_pwconv_bwd_fused;
  * 132 = dfd_pw_ntd_plan (mid-size 1x1 layers on the LDS-DMA ring kernel; same entry points), tune keys 4-7;
- * 133 = dfd_attn_scores / dfd_attn_apply; 134 = dfd_act_bn_bwd_se, dfd_sum_batch_end_deferred, dfd_sum_passengers_flush / _discard. */
+ * 133 = dfd_attn_scores / dfd_attn_apply; 134 = dfd_act_bn_bwd_se, dfd_sum_batch_end_deferred, dfd_sum_passengers_flush / _discard;
+ * 135 = dfd_tune keys 8-11 (grid of the vector-unit depthwise kernels; their default changed, so partial-row counts did). */
 int dfd_version(void);
 
 /* Planner knobs (A/B switches and sizes the host-side kernel selection reads).  Process-wide plain ints: set them once at
@@ -96,7 +97,13 @@ int dfd_version(void);
  *   5 DFD_TUNE_NTD_NS     stages of that kernel's LDS ring, 2..4; 0 = chosen from the LDS budget              (default 0)
  *   6 DFD_TUNE_NTD_MAXN   widest column tile of that kernel (A/B: 96 / 128); 0 = 192                          (default 0)
  *   7 DFD_TUNE_NTD_MINT   fewest 64-row tiles for which it is used: 16 measured best at batch 32 / 64 (4.40 -> 4.25 ms,
- *                         5.74 -> 5.64 ms per EfficientNet-B0 step), neutral at 256                          (default 16) */
+ *                         5.74 -> 5.64 ms per EfficientNet-B0 step), neutral at 256                          (default 16)
+ *   8 / 9 / 10            workgroups a vector-unit depthwise launch aims for (all channel chunks together): forward / data gradient /
+ *                         weight gradient.  1024 = what is co-resident at four per CU: every workgroup starts at once and walks
+ *                         its work items, nobody queues behind a first round (measured against 768 / 1536 / 2048 / 3072 per
+ *                         EfficientNet-B0 layer, scripts/dw_ab.py; 2048 was the value of rounds 2-4: B0 12.94 -> 12.75,
+ *                         EfficientFormerV2-S1 17.00 -> 16.65 ms per step)                                    (default 1024)
+ *   11                    fewest work slots per channel chunk of those launches                             (default 32) */
 int dfd_tune(int key, int value);
 
 /* Batched final summation of weight gradients.  The weight-gradient entry points whose result goes straight to the

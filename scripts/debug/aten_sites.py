@@ -34,7 +34,8 @@ class Sites(TorchDispatchMode):
 
     def __torch_dispatch__(self, func, types, args=(), kwargs=None):
         n = str(func)
-        if any(k in n for k in ("copy_", "_to_copy", "fill_", "zero_", "clone", "contiguous", "aten.add", "aten.mul", "aten.cat", "aten.sum", "aten.div")):
+        if not any(k in n for k in ("aten.empty", "view", "reshape", "as_strided", "detach", "alias", "permute", "transpose", "slice", "select",
+                                    "unsqueeze", "squeeze", "expand", "aten.t.", "unbind", "split", "is_", "_local_scalar", "sym_", "stride", "size")):
             site = "?"
             for fr in reversed(traceback.extract_stack()):
                 if "deepfakedetection_amd" in fr.filename and "aten_sites" not in fr.filename:
@@ -45,6 +46,7 @@ class Sites(TorchDispatchMode):
         return func(*args, **(kwargs or {}))
 
 
+torch.autograd.set_multithreading_enabled(False)      # the dispatch mode is thread-local: keep the backward on this thread
 for _ in range(3):
     step()
 torch.cuda.synchronize()

@@ -1,5 +1,5 @@
 """A/B of the depthwise kernels per EfficientNet-B0 layer: vector-unit kernels (dfd_tune DW_MFMA = 0) against the matrix-core
-form (dfd_dwmm*.hip).   python scripts/dw_ab.py [batch] [lds_kb] [grid]"""
+form (dfd_dwmm*.hip).   python scripts/dw_ab.py [batch] [lds_kb] [grid] [valu_grid] [valu_grid_min]"""
 import sys
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
@@ -12,6 +12,9 @@ N = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 L = load()
 if len(sys.argv) > 2: L.dfd_tune(1, int(sys.argv[2]))
 if len(sys.argv) > 3: L.dfd_tune(2, int(sys.argv[3]))
+if len(sys.argv) > 4:                     # workgroups the vector-unit kernels aim for (forward, data gradient, weight gradient)
+    for key in (8, 9, 10): L.dfd_tune(key, int(sys.argv[4]))
+if len(sys.argv) > 5: L.dfd_tune(11, int(sys.argv[5]))
 DT = torch.bfloat16
 
 def timeit(fn, reps=10):

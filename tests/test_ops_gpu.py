@@ -188,6 +188,50 @@ def test_dwconv_bwd(case, rd):
         assert torch.equal(fz, fz2) and torch.equal(fdw, fdw2), "fused backward is not reproducible"
 
 
+@pytest.mark.parametrize("case", [(5, 28, 28, 240, 5, 1, 2, 2), (6, 30, 30, 144, 3, 1, 1, 1), (12, 33, 35, 96, 3, 2, 1, 1), (7, 14, 14, 672, 5, 1, 2, 2)])
+def test_dwconv_grid_knobs_change_the_partial_rows_not_the_tensors(case):
+    """dfd_tune keys 8-11 size the grids of the vector-unit depthwise kernels.  The small cases above run one work item per workgroup;
+    here the grid is squeezed so that every workgroup walks several items (what a batch-256 launch does): the tensors must not change
+    by a bit, the statistics and the weight gradient (other partial rows, other summation order) within rounding."""
+    from deepfakedetection_amd._lib import load
+
+    K = _k()
+    lib = load()
+    rd = torch.bfloat16
+    N, H, W, C, k, s, pt, pl = case
+    Ho, Wo = -(-H // s), -(-W // s)
+    x, dz, yraw = dev(gen((N, H, W, C), 21, rd)), dev(gen((N, Ho, Wo, C), 22, rd)), dev(gen((N, Ho, Wo, C), 23, rd))
+    w = dev(gen((C, 1, k, k), 24, torch.float32, 0.3))
+    st = dev(rand_state(C, 25))
+    coef = dev(torch.stack([torch.full((C,), 0.8), torch.full((C,), 0.05), torch.full((C,), -0.01)]))
+
+    def run():
+        y, p, n = K.dwconv_fwd(x, st, R.ACT_SILU, w, k, s, pt, pl, Ho, Wo, stats=True)
+        fs = sum_parts(p, n, C)                          # (the partial rows live in a scratch buffer the next call reuses)
+        dx, q, m = K.dwconv_bwd_data(dz, yraw, coef, w, x, st, R.ACT_SILU, (N, H, W, C), k, s, pt, pl)
+        bs = sum_parts(q, m, C)
+        dw = K.dwconv_bwd_weight(dz, yraw, coef, x, st, R.ACT_SILU, k, s, pt, pl)
+        return y, fs, n, dx, bs, m, dw.float().cpu()
+
+    lib.dfd_tune(0, 0)                                   # the vector-unit forward for every shape
+    try:
+        ref = run()
+        for key in (8, 9, 10):
+            assert lib.dfd_tune(key, 16) == 0
+        assert lib.dfd_tune(11, 3) == 0
+        got = run()
+    finally:
+        for key in (8, 9, 10):
+            lib.dfd_tune(key, 1024)
+        lib.dfd_tune(11, 32)
+        lib.dfd_tune(0, 1)
+    assert got[2] < ref[2] and got[5] < ref[5], f"the squeezed grid has as many partial rows as the default one: {got[2]} / {ref[2]}, {got[5]} / {ref[5]}"
+    assert torch.equal(got[0], ref[0]) and torch.equal(got[3], ref[3]), "depthwise results depend on the grid"
+    close(got[1], ref[1], 1e-3, "forward statistics")
+    close(got[4], ref[4], 2e-3, "data-gradient statistics")
+    close(got[6], ref[6], 5e-3, "weight gradient")
+
+
 PW_CASES = [
     # N, HW, K, Nout
     (2, 49, 16, 96),
