@@ -26,6 +26,31 @@ __global__ void k_sum_partials(const float* __restrict__ partials, int P, long L
     float* o = out + (long)blockIdx.y * out_stride + i;
     *o = (accumulate ? *o : 0.f) + s;
 }
+// Both stages in ONE launch for SUM_GROUP < P <= 8 * SUM_GROUP (an immediate sum sits on the dependency chain, and its second stage is a
+// ~5 us launch that adds 2..8 rows): thread (g, i) adds group g's rows of output i exactly as stage 1 does, the groups meet in LDS and the
+// g == 0 threads add them in group order exactly as stage 2 does — same grouping, same order, same bits; the slab is not written.
+// G2 = groups rounded up to a power of two; 256 / G2 outputs per workgroup, consecutive lanes on consecutive outputs.
+__global__ void __launch_bounds__(256) k_sum_partials_1pass(const float* __restrict__ partials, int P, long L, float* __restrict__ out,
+                                                             int accumulate, int g2_log2) {
+    __shared__ float sm[256];
+    const int opb = 256 >> g2_log2;
+    const int g = threadIdx.x >> (8 - g2_log2), ii = threadIdx.x & (opb - 1);
+    const long i = (long)blockIdx.x * opb + ii;
+    const int G = (P + SUM_GROUP - 1) / SUM_GROUP;
+    float s = 0.f;
+    if (i < L && g < G) {
+        const int p0 = g * SUM_GROUP;
+        s = sum_rows_ordered(partials, p0, (p0 + SUM_GROUP < P) ? p0 + SUM_GROUP : P, L, i);
+    }
+    sm[threadIdx.x] = s;
+    __syncthreads();
+    if (g == 0 && i < L) {
+        float t = 0.f;
+        for (int k = 0; k < G; ++k) t += sm[k * opb + ii];
+        float* o = out + i;
+        *o = (accumulate ? *o : 0.f) + t;
+    }
+}
 // ---- batched form: between dfd_sum_batch_begin() and dfd_sum_batch_end() on one host thread, the final summation of
 // every weight-gradient kernel launched from that thread is recorded instead of launched, and the batch is added up by
 // ONE pair of launches (stage 1 over all (job, group) pairs, stage 2 over all jobs) — same grouping, same order, same
@@ -154,7 +179,12 @@ int dfd_launch_sum_partials(float* partials, int P, long L, float* out, int accu
     }
     const int threads = 256;
     const unsigned gx = (unsigned)((L + threads - 1) / threads);
-    if (P > SUM_GROUP) {
+    if (P > SUM_GROUP && P <= 8 * SUM_GROUP) {
+        const int G = (P + SUM_GROUP - 1) / SUM_GROUP;
+        const int g2_log2 = G <= 2 ? 1 : (G <= 4 ? 2 : 3);
+        const long opb = 256 >> g2_log2;
+        hipLaunchKernelGGL(k_sum_partials_1pass, dim3((unsigned)((L + opb - 1) / opb)), dim3(256), 0, st, partials, P, L, out, accumulate, g2_log2);
+    } else if (P > SUM_GROUP) {
         const int G = (P + SUM_GROUP - 1) / SUM_GROUP;          // <= 32 for P <= 1024
         float* mid = partials + (long)P * L;
         hipLaunchKernelGGL(k_sum_partials, dim3(gx, G), dim3(threads), 0, st, partials, P, L, mid, L, 0);

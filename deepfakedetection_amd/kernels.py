@@ -1217,12 +1217,17 @@ def channel_stats(x: torch.Tensor):
     return parts, n.value
 
 
-def sum_rows(partials: torch.Tensor, P: int, L: int, out: torch.Tensor, accumulate: bool = False) -> torch.Tensor:
+def sum_rows(partials: torch.Tensor, P: int, L: int, out: torch.Tensor, accumulate: bool = False, deferred: bool = False) -> torch.Tensor:
     """out[i] = sum_p partials[p][i] in a fixed order; `partials` (flat f32) must hold P + ceil(P/32) rows of L floats
     (the second reduction stage is written behind the slab).  More than 1024 rows are summed in groups of 1024, last
-    group first, so that a group's second stage only overwrites rows that have already been consumed."""
+    group first, so that a group's second stage only overwrites rows that have already been consumed.
+    deferred: `out` is a gradient-arena slot nobody reads before the end of the enclosing block and `partials` comes from
+    scratch(): inside sum_batch() the sum joins the block's batched sums (same order, same bits) instead of two launches here."""
     if partials.numel() < (P + (min(P, 1024) + 31) // 32) * L:
         raise ValueError("sum_rows: partial slab too small for the two-stage reduction")
+    if deferred and P <= 1024 and _sum_batch.open:
+        check(_L().dfd_sum_rows_deferred(_p(partials), P, L, _p(out), int(accumulate), _stream()), "dfd_sum_rows_deferred")
+        return out
     if P <= 1024:
         check(_L().dfd_sum_rows(_p(partials), P, L, _p(out), int(accumulate), _stream()), "dfd_sum_rows")
         return out

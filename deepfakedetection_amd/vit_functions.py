@@ -239,22 +239,33 @@ def attn_core_bwd(gO, q, k, v, S, P, T2, table, idx, th, geo: AttnGeom, need_tab
         pw1, pb1, pw2, pb2 = th_params if th_params is not None else (None, None, None, None)
 
         def dst(param, n):
+            # -> (destination, deferred): a gradient-arena slot is read by nobody before the optimizer, so the final sum of the per-image
+            # rows may join the enclosing block's batched sums (kernels.sum_batch); a fresh tensor is handed to autograd and summed now
             slot = _slot(param, param is not None, tuple(param.shape)) if param is not None else None
-            return slot.view(-1) if slot is not None else torch.empty(n, dtype=torch.float32, device=dev)
+            return (slot.view(-1), True) if slot is not None else (torch.empty(n, dtype=torch.float32, device=dev), False)
 
-        part = torch.empty((_partial_rows(B), H * H), dtype=torch.float32, device=dev)
+        def rows_buf(name, n, deferred):
+            # (a deferred sum's slab must outlive this function: scratch() keeps the slabs of an open batch until they are summed)
+            if deferred:
+                return K.scratch(dev, name, _partial_rows(B) * n * 4)[:_partial_rows(B) * n].view(_partial_rows(B), n)
+            return torch.empty((_partial_rows(B), n), dtype=torch.float32, device=dev)
+
         # dW2[g][h] = sum_{b,l} dT2[b,g,l] * P[b,h,l]   (per-image partials, then a fixed-order row sum)
+        d2, defer2 = dst(pw2, H * H)
+        part = rows_buf("th_dw2", H * H, defer2)
         K.bgemm(dT2, (H * L, 0, L, 1), P, (H * L, 0, 1, L), part, (H * H, 0, H, 1), B, 1, H, H, L)
-        dw2 = K.sum_rows(part.view(-1), B, H * H, dst(pw2, H * H)).view(H, H, 1, 1)
-        part1 = torch.empty((_partial_rows(B), H * H), dtype=torch.float32, device=dev)
+        dw2 = K.sum_rows(part.view(-1), B, H * H, d2, deferred=defer2).view(H, H, 1, 1)
+        d1, defer1 = dst(pw1, H * H)
+        part1 = rows_buf("th_dw1", H * H, defer1)
         K.bgemm(dT1, (H * L, 0, L, 1), S, (H * L, 0, 1, L), part1, (H * H, 0, H, 1), B, 1, H, H, L)
-        dw1 = K.sum_rows(part1.view(-1), B, H * H, dst(pw1, H * H)).view(H, H, 1, 1)
+        dw1 = K.sum_rows(part1.view(-1), B, H * H, d1, deferred=defer1).view(H, H, 1, 1)
         # db2[g] = sum dT2[b,g,:]: the same contraction against a column of ones (all strides 0)
         ones = _ones(dev)
-        partb = torch.empty((_partial_rows(B), H), dtype=torch.float32, device=dev)
+        e2, deferb = dst(pb2, H)
+        partb = rows_buf("th_db2", H, deferb)
         K.bgemm(dT2, (H * L, 0, L, 1), ones, (0, 0, 0, 0), partb, (H, 0, 1, 1), B, 1, H, 1, L)
-        db2 = K.sum_rows(partb.view(-1), B, H, dst(pb2, H))
-        db1 = K.axpby(b1, None, 0.0, 0.0, out=dst(pb1, H))      # softmax is invariant to a per-head shift: exactly zero
+        db2 = K.sum_rows(partb.view(-1), B, H, e2, deferred=deferb)
+        db1 = K.axpby(b1, None, 0.0, 0.0, out=dst(pb1, H)[0])      # softmax is invariant to a per-head shift: exactly zero
         dth = (dw1, db1, dw2, db2)
     dtable = None
     if need_table:

@@ -513,6 +513,44 @@ def test_sum_rows_beyond_1024_partial_rows():
     close(out, parts[:P].double().sum(0).float(), 1e-5, "multi-group row sum")
 
 
+@pytest.mark.parametrize("P", [1, 31, 32, 33, 36, 64, 65, 100, 128, 129, 200, 256, 257, 700])
+def test_sum_rows_has_one_order_whatever_kernel_adds_them(P):
+    """The fixed order of every partial-row sum: rows in groups of 32, each group added in row order from 0.f, then the group sums in group
+    order from 0.f — by one launch (P <= 32), by the one-pass kernel (33..256: both stages in one launch), by the two-launch form (above),
+    and by the batched form inside sum_batch().  All of them must give the bits of that order (restated here in torch f32), and accumulate
+    on top of what the destination holds."""
+    K = _k()
+    L = 1003
+    parts = torch.randn(P + (P + 31) // 32 + 1, L, generator=torch.Generator().manual_seed(P))
+    groups = []
+    for p0 in range(0, P, 32):
+        g = torch.zeros(L)
+        for r in range(p0, min(p0 + 32, P)):
+            g = g + parts[r]
+        groups.append(g)
+    if len(groups) == 1:
+        want = groups[0]
+    else:
+        want = torch.zeros(L)
+        for g in groups:
+            want = want + g
+    out = torch.empty(L, device="cuda")
+    K.sum_rows(parts.cuda().view(-1), P, L, out)
+    assert torch.equal(out.cpu(), want), f"immediate sum of {P} rows differs from the fixed order"
+    base = torch.randn(L, generator=torch.Generator().manual_seed(7))
+    acc = base.cuda()
+    K.sum_rows(parts.cuda().view(-1), P, L, acc, accumulate=True)
+    assert torch.equal(acc.cpu(), base + want), "accumulating sum"
+    slab = K.scratch(torch.device("cuda"), "test_sum_rows", parts.numel() * 4)[:parts.numel()]
+    out2 = torch.empty(L, device="cuda")
+    with K.sum_batch():
+        slab = K.scratch(torch.device("cuda"), "test_sum_rows", parts.numel() * 4)[:parts.numel()]
+        slab.copy_(parts.view(-1))
+        K.sum_rows(slab, P, L, out2, deferred=True)
+        K._sum_batch.temp_dest = True               # out2 is read right after the block: the batch is summed at its end, not as passengers
+    assert torch.equal(out2.cpu(), want), "batched sum"
+
+
 @pytest.mark.parametrize("act", [R.ACT_GELU, R.ACT_SILU])
 def test_wave_autonomous_wgrad_with_bn_act_prologue(act):
     """EfficientFormerV2 ConvMlp fc2 weight gradient at the 56x56 stage: narrow operand through the BN-backward affine
