@@ -12,7 +12,6 @@
 // staged-column map is a compile-time table once the parity of pad_left is a template
 // parameter (PLP).
 #include "dfd_dwq.h"
-#include "dfd_dwm.h"
 #ifndef DFD_ABLATE
 #define DFD_ABLATE 0   // timing experiments (scripts/build_variant.sh): 1 = staging only, 2 = taps only
 #endif

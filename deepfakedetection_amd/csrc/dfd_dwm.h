@@ -40,11 +40,7 @@ struct DwMGeom {
     int in_bytes, out_bytes, opitch; // LDS bytes of one image / one output tile; bytes per pixel of the output tile
 };
 
-// knobs (dfd_tune): A/B switches and sizes read by the host-side planners; set once at start-up, before any launch
-enum { DFD_TUNE_DW_MFMA = 0, DFD_TUNE_DW_LDS_KB = 1, DFD_TUNE_DW_GRID = 2, DFD_TUNE_DEBUG = 3, DFD_TUNE_PW_NTD = 4, DFD_TUNE_NTD_NS = 5, DFD_TUNE_NTD_MAXN = 6, DFD_TUNE_NTD_MINT = 7,
-       DFD_TUNE_DWQ_GRID_FWD = 8, DFD_TUNE_DWQ_GRID_BWD = 9, DFD_TUNE_DWQ_GRID_WGRAD = 10, DFD_TUNE_DWQ_GRID_MIN = 11,
-       DFD_TUNE_COUNT = 16 };
-int dfd_tune_get(int key);
+// (the planner knobs, DFD_TUNE_* / dfd_tune_get, live in dfd_common.h)
 
 // host entry points of the matrix-core kernels; DFD_EUNSUPPORTED: not served (switched off, f32, C % 16, ...) — the caller runs
 // the vector-unit kernel of dfd_dwfwd.hip / dfd_dwbwd.hip

@@ -427,7 +427,7 @@ k_pw_nt(const T* __restrict__ a, ProArgs pa, const T* __restrict__ w, T* __restr
 // ===========================================================================
 #define TN_B 128   // output tile edge (channels of p and of q)
 #ifndef TN_TARGET_WGS
-#define TN_TARGET_WGS 512   // workgroups a weight-gradient launch aims for (tiles x row splits)
+#define TN_TARGET_WGS 512   // workgroups a weight-gradient launch aims for (tiles x row splits): the default of dfd_tune key 12
 #endif
 #ifndef TN_MIN_STEPS
 // reduction steps (of 64 rows) a row split must have at least.  8 starved the small-M layers of workgroups — 1,568 rows (batch 32 at
@@ -935,7 +935,7 @@ static void tn_plan(int dtype, int M, int Ni, int Nj, int* i_tiles, int* j_tiles
     *i_tiles = (Ni + TN_B - 1) / TN_B;
     *j_tiles = (Nj + TN_B - 1) / TN_B;
     const int tiles = *i_tiles * *j_tiles;
-    int s = TN_TARGET_WGS / tiles;
+    int s = dfd_tune_get(DFD_TUNE_TN_WGS) / tiles;
     if (s < 1) s = 1;
     // keep the slab under 64 MiB and give each split at least 8 reduction steps
     const long per = (long)Ni * Nj * 4;
