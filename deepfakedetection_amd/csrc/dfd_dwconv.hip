@@ -26,7 +26,10 @@ __global__ void k_sum_partials(const float* __restrict__ partials, int P, long L
     float* o = out + (long)blockIdx.y * out_stride + i;
     *o = (accumulate ? *o : 0.f) + s;
 }
-// Both stages in ONE launch for SUM_GROUP < P <= 8 * SUM_GROUP (an immediate sum sits on the dependency chain, and its second stage is a
+#ifndef SUM_1PASS_MAX_GROUPS
+#define SUM_1PASS_MAX_GROUPS 8       // (16 = up to 512 rows in 64-byte pieces per group and row: FasterViT-0 19.73 -> 19.82 ms, S1 +-0; same-box A/B)
+#endif
+// Both stages in ONE launch for SUM_GROUP < P <= SUM_1PASS_MAX_GROUPS * SUM_GROUP (an immediate sum sits on the dependency chain, and its second stage is a
 // ~5 us launch that adds 2..8 rows): thread (g, i) adds group g's rows of output i exactly as stage 1 does, the groups meet in LDS and the
 // g == 0 threads add them in group order exactly as stage 2 does — same grouping, same order, same bits; the slab is not written.
 // G2 = groups rounded up to a power of two; 256 / G2 outputs per workgroup, consecutive lanes on consecutive outputs.
@@ -179,9 +182,9 @@ int dfd_launch_sum_partials(float* partials, int P, long L, float* out, int accu
     }
     const int threads = 256;
     const unsigned gx = (unsigned)((L + threads - 1) / threads);
-    if (P > SUM_GROUP && P <= 8 * SUM_GROUP) {
+    if (P > SUM_GROUP && P <= SUM_1PASS_MAX_GROUPS * SUM_GROUP) {
         const int G = (P + SUM_GROUP - 1) / SUM_GROUP;
-        const int g2_log2 = G <= 2 ? 1 : (G <= 4 ? 2 : 3);
+        const int g2_log2 = G <= 2 ? 1 : (G <= 4 ? 2 : (G <= 8 ? 3 : 4));
         const long opb = 256 >> g2_log2;
         hipLaunchKernelGGL(k_sum_partials_1pass, dim3((unsigned)((L + opb - 1) / opb)), dim3(256), 0, st, partials, P, L, out, accumulate, g2_log2);
     } else if (P > SUM_GROUP) {
