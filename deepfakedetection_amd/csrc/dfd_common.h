@@ -286,7 +286,7 @@ int dfd_stem_wgrad_mfma(const float* x, const void* dz, const void* yraw, const 
 
 // knobs (dfd_tune): A/B switches and sizes read by the host-side planners; set once at start-up, before any launch
 enum { DFD_TUNE_DW_MFMA = 0, DFD_TUNE_DW_LDS_KB = 1, DFD_TUNE_DW_GRID = 2, DFD_TUNE_DEBUG = 3, DFD_TUNE_PW_NTD = 4, DFD_TUNE_NTD_NS = 5, DFD_TUNE_NTD_MAXN = 6, DFD_TUNE_NTD_MINT = 7,
-       DFD_TUNE_DWQ_GRID_FWD = 8, DFD_TUNE_DWQ_GRID_BWD = 9, DFD_TUNE_DWQ_GRID_WGRAD = 10, DFD_TUNE_DWQ_GRID_MIN = 11, DFD_TUNE_TN_WGS = 12,
+       DFD_TUNE_DWQ_GRID_FWD = 8, DFD_TUNE_DWQ_GRID_BWD = 9, DFD_TUNE_DWQ_GRID_WGRAD = 10, DFD_TUNE_DWQ_GRID_MIN = 11, DFD_TUNE_TN_WGS = 12, DFD_TUNE_DWQ_WIDE = 13,
        DFD_TUNE_COUNT = 16 };
 int dfd_tune_get(int key);
 

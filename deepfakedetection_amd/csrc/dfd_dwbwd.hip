@@ -207,7 +207,8 @@ static int dw_bwd_data_q_t(const void* dz, const void* y, const float* coef, con
     constexpr int V = Vec<T>::N;
     DwQGeom g; int tile_bytes;
     const int kk = s ? s->k * s->k : 0;
-    if (!dfd_dwq_geom(s, V, 16, true, (size_t)(kk + 5) * 16 * V * 4, 0, 1, &g, &tile_bytes)) return DFD_EINVAL;
+    const DwqOcc occ = dwq_occupancy(1, s);
+    if (!dfd_dwq_geom(s, V, 16, true, (size_t)(kk + 5) * 16 * V * 4, 0, 1, &g, &tile_bytes, 1, occ.lds_budget)) return DFD_EINVAL;
     const int cvb = 1 << g.cvb_log2, nchunks = (g.CV + cvb - 1) / cvb;
     // chunk-workgroups share cache lines unless both the pixel stride and the chunk width are whole lines
     g.remap = (s->stride == 1 && nchunks > 1 && ((s->C * (int)sizeof(T)) % 128 != 0 || (cvb * 16) % 128 != 0)) ? 1 : 0;
@@ -215,7 +216,7 @@ static int dw_bwd_data_q_t(const void* dz, const void* y, const float* coef, con
     if (epi && (!in_bnstate || !partials || !nparts || pcap < 1)) return DFD_EINVAL;
     if (hc && !y) return DFD_EINVAL;
     int cap = epi ? (pcap < DFD_MAX_PARTIALS ? pcap : DFD_MAX_PARTIALS) : DFD_MAX_PARTIALS;
-    int gy = dfd_tune_get(DFD_TUNE_DWQ_GRID_BWD) / nchunks;
+    int gy = occ.grid / nchunks;
     if (gy < dfd_tune_get(DFD_TUNE_DWQ_GRID_MIN)) gy = dfd_tune_get(DFD_TUNE_DWQ_GRID_MIN);
     if (gy > cap) gy = cap;
     if (gy > g.nwork) gy = g.nwork;
@@ -374,14 +375,14 @@ k_dw_bwd_weight_q(const T* __restrict__ dz, const T* __restrict__ yraw, const fl
 
 static bool dw_wgrad_q_geom(const dfd_dwconv_shape* s, int vec, DwQGeom* g, int* tile_bytes) {
     const int max_cvb = (s && s->k == 5) ? 8 : 16;          // needs 256/cvb >= K lanes per run
-    if (!dfd_dwq_geom(s, vec, max_cvb, false, (size_t)5 * 16 * vec * 4, 16, s ? s->k : 1, g, tile_bytes)) return false;
+    if (!dfd_dwq_geom(s, vec, max_cvb, false, (size_t)5 * 16 * vec * 4, 16, s ? s->k : 1, g, tile_bytes, 1, dwq_occupancy(2, s).lds_budget)) return false;
     const int cvb = 1 << g->cvb_log2, nchunks = (g->CV + cvb - 1) / cvb, esz = vec == 8 ? 2 : 4;
     g->remap = (nchunks > 1 && ((s->C * esz) % 128 != 0 || (cvb * 16) % 128 != 0)) ? 1 : 0;
     return true;
 }
 
-static int dw_wgrad_q_parts(const DwQGeom& g, int k, int nchunks) {
-    int want = dfd_tune_get(DFD_TUNE_DWQ_GRID_WGRAD) / (nchunks > 0 ? nchunks : 1);
+static int dw_wgrad_q_parts(const DwQGeom& g, int k, int nchunks, int grid) {
+    int want = grid / (nchunks > 0 ? nchunks : 1);
     if (want < 32) want = 32;
     const long per = (long)g.C * k * k * 4;
     long cap = (16l << 20) / per;
@@ -407,7 +408,7 @@ static int dw_bwd_weight_q_t(const void* dz, const void* y, const float* coef, c
     DwQGeom g; int tile_bytes;
     if (!dw_wgrad_q_geom(s, V, &g, &tile_bytes)) return DFD_EINVAL;
     const int cvb = 1 << g.cvb_log2, nchunks = (g.CV + cvb - 1) / cvb, KK = s->k * s->k;
-    const int P = dw_wgrad_q_parts(g, s->k, nchunks);
+    const int P = dw_wgrad_q_parts(g, s->k, nchunks, dwq_occupancy(2, s).grid);
     if ((size_t)(P + P / 32 + 2) * g.C * KK * 4 > ws_bytes) return DFD_EWORKSPACE;
     size_t lds = (size_t)tile_bytes + (size_t)g.TH * 4 * g.QW * cvb * 16 + (size_t)5 * cvb * V * 4;
     const size_t red = (size_t)((DFD_THREADS / cvb) / s->k) * KK * cvb * V * 4;

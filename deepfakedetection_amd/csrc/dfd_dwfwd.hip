@@ -265,6 +265,23 @@ bool dfd_dwq_geom(const dfd_dwconv_shape* s, int vec, int max_cvb, bool centre_i
     return true;
 }
 
+DwqOcc dwq_occupancy(int op, const dfd_dwconv_shape* s) {
+    const int mode = dfd_tune_get(DFD_TUNE_DWQ_WIDE);
+    bool wide = false;
+    if (mode > 0) wide = true;
+    else if (mode < 0 && s) {
+        const bool k5s1 = s->k == 5 && s->stride == 1;
+        if (op == 0) wide = k5s1;
+        else if (op == 1) wide = k5s1 || (s->k == 3 && s->stride == 2);
+        else wide = k5s1 && s->H * s->W > 64;          // (7x7: the weight gradient's own staging measured 52 -> 55 us wide)
+    }
+    const int target = dfd_tune_get(op == 0 ? DFD_TUNE_DWQ_GRID_FWD : (op == 1 ? DFD_TUNE_DWQ_GRID_BWD : DFD_TUNE_DWQ_GRID_WGRAD));
+    DwqOcc o;
+    o.lds_budget = wide ? 48 * 1024 : 36 * 1024;
+    o.grid = wide ? target * 3 / 4 : target;
+    return o;
+}
+
 template <typename T>
 static int dw_fwd_q_t(const void* x, const float* in_bnstate, int in_act, const float* w, void* y,
                       const dfd_dwconv_shape* s, float* partials, int pcap, int* nparts, hipStream_t st) {
@@ -273,7 +290,8 @@ static int dw_fwd_q_t(const void* x, const float* in_bnstate, int in_act, const 
     // two outputs per lane (five workgroups per CU: tile + tables within 31 KB): bf16 3x3 stride-1 layers (DW_FWD_PAIRS)
     const bool pairs = DW_FWD_PAIRS && sizeof(T) == 2 && s && s->k == 3 && s->stride == 1;
     const size_t tables = (size_t)(s ? s->k * s->k + 2 : 0) * 16 * V * 4;
-    if (!dfd_dwq_geom(s, V, 16, false, tables, 0, 1, &g, &tile_bytes, 1, pairs ? 31 * 1024 : 36 * 1024)) return DFD_EINVAL;
+    const DwqOcc occ = dwq_occupancy(0, s);
+    if (!dfd_dwq_geom(s, V, 16, false, tables, 0, 1, &g, &tile_bytes, 1, pairs ? 31 * 1024 : occ.lds_budget)) return DFD_EINVAL;
     const int cvb = 1 << g.cvb_log2, nchunks = (g.CV + cvb - 1) / cvb;
     // XCD-aware order (dwq_block): measured per layer — helps the forward kernel when an image spans
     // several tiles and the channel chunks share cache lines (block 2: 219 -> 201 us), hurts when one
@@ -282,7 +300,7 @@ static int dw_fwd_q_t(const void* x, const float* in_bnstate, int in_act, const 
                ((s->C * (int)sizeof(T)) % 128 != 0 || (cvb * 16) % 128 != 0)) ? 1 : 0;
     const bool stats = partials != nullptr;
     int cap = stats ? (pcap < DFD_MAX_PARTIALS ? pcap : DFD_MAX_PARTIALS) : DFD_MAX_PARTIALS;
-    int gy = dfd_tune_get(DFD_TUNE_DWQ_GRID_FWD) / nchunks;
+    int gy = occ.grid / nchunks;
     if (gy < dfd_tune_get(DFD_TUNE_DWQ_GRID_MIN)) gy = dfd_tune_get(DFD_TUNE_DWQ_GRID_MIN);
     if (gy > cap) gy = cap;
     if (gy > g.nwork) gy = g.nwork;

@@ -27,7 +27,7 @@ typedef float dwm_f4 __attribute__((ext_vector_type(4)));
 typedef __bf16 dwm_bf8 __attribute__((ext_vector_type(8)));
 
 static int g_tune[DFD_TUNE_COUNT] = {/*DW_MFMA*/ 1, /*DW_LDS_KB*/ 156, /*DW_GRID*/ 256, /*DEBUG*/ 0, /*PW_NTD*/ 1, /*NTD_NS*/ 0, /*NTD_MAXN*/ 0, /*NTD_MINT*/ 16,
-                                      /*DWQ_GRID_FWD*/ 1024, /*DWQ_GRID_BWD*/ 1024, /*DWQ_GRID_WGRAD*/ 1024, /*DWQ_GRID_MIN*/ 32, /*TN_WGS*/ 512};
+                                      /*DWQ_GRID_FWD*/ 1024, /*DWQ_GRID_BWD*/ 1024, /*DWQ_GRID_WGRAD*/ 1024, /*DWQ_GRID_MIN*/ 32, /*TN_WGS*/ 512, /*DWQ_WIDE*/ -1};
 int dfd_tune_get(int key) { return (key >= 0 && key < DFD_TUNE_COUNT) ? g_tune[key] : 0; }
 extern "C" int dfd_tune(int key, int value) {
     if (key < 0 || key >= DFD_TUNE_COUNT) return DFD_EINVAL;

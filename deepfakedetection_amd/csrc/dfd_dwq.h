@@ -97,6 +97,17 @@ template <typename T> __device__ __forceinline__ f2 round2(f2 v) {
 bool dfd_dwq_geom(const dfd_dwconv_shape* s, int vec, int max_cvb, bool centre_is_input, size_t extra_lds,
                   int extra_centre, int lane_div, DwQGeom* g, int* tile_bytes, int halo_tiles = 1, long lds_budget = 36 * 1024);
 
+// Occupancy class of a vector-unit depthwise launch (op: 0 forward, 1 data gradient, 2 weight gradient): FOUR workgroups per CU with
+// tile + tables within 36 KB and a grid of the launch's dfd_tune target (1024), or THREE per CU within 48 KB and 3/4 of the target (768).
+// The wide class buys larger tiles (less halo; for 5x5 layers with 16-vector chunks it is what lets a whole 7x7 picture + its 15 KB tap
+// table be ONE tile) for a quarter of the resident waves.  Measured per EfficientNet-B0 layer at batch 256 (scripts/dw_ab.py):
+// it wins on the 5x5 stride-1 layers (data gradient 7x7 C1152 82 -> 49 us, 28x28 C240 212 -> 174, 14x14 C480 / C672 86 -> 72 / 122 -> 111;
+// forward 28x28 153 -> 140, 7x7 51 -> 43; weight gradient 14x14 80 -> 71 / 104 -> 101) and on the 3x3 stride-2 data gradient (389 -> 379,
+// 63 -> 55), and loses on the other 3x3 and stride-2 launches (56x56 C144 forward 174 -> 189, weight gradient 232 -> 250; 14 -> 7 5x5
+// forward 52 -> 63), so the rule below names those classes.  dfd_tune key 13: -1 this rule, 0 never wide, 1 always wide (A/B runs).
+struct DwqOcc { long lds_budget; int grid; };
+DwqOcc dwq_occupancy(int op, const dfd_dwconv_shape* s);
+
 // stage the input tile: tile[pix][vl] = rnd(act(scale*x+shift)) or x, zero outside the image
 template <typename T, int ACT, bool PRO, int U = 4>
 __device__ __forceinline__ void stage_q(uint4* __restrict__ tile, const T* __restrict__ src, const f2 (&sc)[V2<T>::N],

@@ -78,7 +78,7 @@ typedef void* dfd_stream;          /* a hipStream_t */
  * 131 = dfd_augment_u8, dfd_gemm_plan, dfd_dw_mm_plan, dfd_pwconv_bwd_fused;
  * 132 = dfd_pw_ntd_plan (mid-size 1x1 layers on the LDS-DMA ring kernel; same entry points), tune keys 4-7;
  * 133 = dfd_attn_scores / dfd_attn_apply; 134 = dfd_act_bn_bwd_se, dfd_sum_batch_end_deferred, dfd_sum_passengers_flush / _discard;
- * 135 = dfd_tune keys 8-12 (grids of the vector-unit depthwise kernels — their default changed, so partial-row counts did — and of the
+ * 135 = dfd_tune keys 8-13 (grids of the vector-unit depthwise kernels — their default changed, so partial-row counts did — and of the
  * tiled weight gradient); immediate partial-row sums of 33..256 rows in one launch (same order, same bits). */
 int dfd_version(void);
 
@@ -108,7 +108,10 @@ int dfd_version(void);
  *   12 DFD_TUNE_TN_WGS    workgroups a tiled weight-gradient launch (k_pw_tn: output tiles x row splits) aims for.  512 = what is
  *                         co-resident at two per CU; measured 256 / 384 / 512 / 768 / 1024 on one box: EfficientNet-B0 12.88 / 12.80 /
  *                         12.62 / 13.03 / 12.96 ms, EfficientFormerV2-S1 16.71 / 16.57 / 16.44 / 16.94 / 17.11, FasterViT-0 22.04 /
- *                         21.46 / 19.59 / 20.27 / 20.20                                                       (default 512) */
+ *                         21.46 / 19.59 / 20.27 / 20.20                                                       (default 512)
+ *   13 DFD_TUNE_DWQ_WIDE  occupancy class of the vector-unit depthwise launches: -1 = by shape (5x5 stride-1 layers and the 3x3
+ *                         stride-2 data gradient run THREE workgroups per CU with 48 KB of tile + tables and 3/4 of the grid
+ *                         target, everything else four per CU with 36 KB), 0 = never wide, 1 = always wide (A/B)   (default -1) */
 int dfd_tune(int key, int value);
 
 /* Batched final summation of weight gradients.  The weight-gradient entry points whose result goes straight to the
