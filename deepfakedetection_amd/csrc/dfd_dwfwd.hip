@@ -277,7 +277,9 @@ DwqOcc dwq_occupancy(int op, const dfd_dwconv_shape* s) {
     }
     const int target = dfd_tune_get(op == 0 ? DFD_TUNE_DWQ_GRID_FWD : (op == 1 ? DFD_TUNE_DWQ_GRID_BWD : DFD_TUNE_DWQ_GRID_WGRAD));
     DwqOcc o;
-    o.lds_budget = wide ? 48 * 1024 : 36 * 1024;
+    // narrow: 39 KB x 4 leaves 4 KB of the CU's 160 (36 KB until round 4: EfficientFormerV2-S1 16.39 -> 16.26 ms at 39 / 40 KB, B0 -0.03 ms);
+    // wide: 44 / 48 / 50 / 52 KB measured within 0.04 ms of each other on B0
+    o.lds_budget = wide ? 48 * 1024 : 39 * 1024;
     o.grid = wide ? target * 3 / 4 : target;
     return o;
 }

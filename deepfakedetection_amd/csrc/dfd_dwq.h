@@ -98,7 +98,7 @@ bool dfd_dwq_geom(const dfd_dwconv_shape* s, int vec, int max_cvb, bool centre_i
                   int extra_centre, int lane_div, DwQGeom* g, int* tile_bytes, int halo_tiles = 1, long lds_budget = 36 * 1024);
 
 // Occupancy class of a vector-unit depthwise launch (op: 0 forward, 1 data gradient, 2 weight gradient): FOUR workgroups per CU with
-// tile + tables within 36 KB and a grid of the launch's dfd_tune target (1024), or THREE per CU within 48 KB and 3/4 of the target (768).
+// tile + tables within 39 KB and a grid of the launch's dfd_tune target (1024), or THREE per CU within 48 KB and 3/4 of the target (768).
 // The wide class buys larger tiles (less halo; for 5x5 layers with 16-vector chunks it is what lets a whole 7x7 picture + its 15 KB tap
 // table be ONE tile) for a quarter of the resident waves.  Measured per EfficientNet-B0 layer at batch 256 (scripts/dw_ab.py):
 // it wins on the 5x5 stride-1 layers (data gradient 7x7 C1152 82 -> 49 us, 28x28 C240 212 -> 174, 14x14 C480 / C672 86 -> 72 / 122 -> 111;

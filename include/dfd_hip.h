@@ -111,7 +111,7 @@ int dfd_version(void);
  *                         21.46 / 19.59 / 20.27 / 20.20                                                       (default 512)
  *   13 DFD_TUNE_DWQ_WIDE  occupancy class of the vector-unit depthwise launches: -1 = by shape (5x5 stride-1 layers and the 3x3
  *                         stride-2 data gradient run THREE workgroups per CU with 48 KB of tile + tables and 3/4 of the grid
- *                         target, everything else four per CU with 36 KB), 0 = never wide, 1 = always wide (A/B)   (default -1) */
+ *                         target, everything else four per CU with 39 KB), 0 = never wide, 1 = always wide (A/B)   (default -1) */
 int dfd_tune(int key, int value);
 
 /* Batched final summation of weight gradients.  The weight-gradient entry points whose result goes straight to the
