@@ -170,7 +170,9 @@ int dfd_conv3_direct(const void* x, const dfd_dwconv_shape* s, const float* in_b
     const int tiles_y = (s->H + th - 1) / th, tiles_x = (s->W + C3_TW - 1) / C3_TW;
     const long nwork = (long)s->N * tiles_y * tiles_x;
     const bool stats = partials != nullptr;
-    long gx = 512;                                       // two workgroups per CU, persistent
+    // two workgroups per CU, persistent: 512 over ALL 64-channel column blocks.  (Until round 4 it was 512 PER block: with Cout = 128 half of
+    // the workgroups queued behind the other half and every one loaded its 147 KB of weights for half the work; FasterViT-0 19.74 -> 19.53 ms.)
+    long gx = 512 / (Cout / 64);
     if (stats) { const long cap = pcap < DFD_MAX_PARTIALS ? pcap : DFD_MAX_PARTIALS; if (gx > cap) gx = cap; }
     if (gx > nwork) gx = nwork;
     if (stats) *nparts = (int)gx;
