@@ -16,8 +16,12 @@
 #define DFD_ABLATE 0   // timing experiments (scripts/build_variant.sh): 1 = staging only, 2 = taps only
 #endif
 
-template <typename T, int K, int S, int PLP, int ACT, bool COEF, bool EPI>
-__global__ void __launch_bounds__(DFD_THREADS, 4)
+// WPC = workgroups per CU the instance is compiled for: 4, or 3 for the wide occupancy class of the 5x5 stride-1 layers (dwq_occupancy), where only
+// three are resident anyway: 168 instead of 128 registers per lane.  The 4-per-CU 5x5 instances with the epilogue spill 20-48 bytes per lane; the
+// 3-per-CU ones take 139-159 registers, no scratch, and twice the staging depth: data gradient 28x28 C240 174 -> 160 us, 14x14 C480 / C672 72 -> 67 /
+// 111 -> 98, 7x7 49 -> 48; weight gradient 14x14 71 -> 68 / 101 -> 99 (B0 step -0.05 ms).  The forward has no spills at 4 per CU and gained nothing.
+template <typename T, int K, int S, int PLP, int ACT, bool COEF, bool EPI, int WPC = 4>
+__global__ void __launch_bounds__(DFD_THREADS, WPC)
 k_dw_bwd_data_q(const T* __restrict__ dz, const T* __restrict__ yraw, const float* __restrict__ coef,
                 const float* __restrict__ w, const T* __restrict__ xin, const float* __restrict__ in_bnstate,
                 T* __restrict__ dzin, DwQGeom g, float* __restrict__ partials, int tile_bytes) {
@@ -81,7 +85,7 @@ k_dw_bwd_data_q(const T* __restrict__ dz, const T* __restrict__ yraw, const floa
         const int sx0 = (S == 1) ? nx : (nx >= 0 ? nx / 2 : -((-nx + 1) / 2));
         __syncthreads();
 #if DFD_ABLATE != 2
-        stage_dy<T, COEF, StageDepth<K, S>::DY>(tile, dz, yraw, cf, cvbV, vl, (long)n * g.Ho * g.Wo * g.C, g.Ho, g.Wo, g.C, c0, cvalid, sy0, sx0,
+        stage_dy<T, COEF, (WPC == 3 ? 2 : 1) * StageDepth<K, S>::DY>(tile, dz, yraw, cf, cvbV, vl, (long)n * g.Ho * g.Wo * g.C, g.Ho, g.Wo, g.C, c0, cvalid, sy0, sx0,
                           g.IH, g.IW, g.iw_magic, g.cvb_log2);
 #endif
         __syncthreads();
@@ -227,9 +231,19 @@ static int dw_bwd_data_q_t(const void* dz, const void* y, const float* coef, con
     dim3 grid(nchunks, gy);
     const int plp = s->pad_left & 1;
     if (!epi) in_act = DFD_ACT_NONE;
+    const bool wide3 = occ.lds_budget > 40 * 1024;
 #define LAUNCH_BD(PLP, COEF, EPI) \
-    hipLaunchKernelGGL((k_dw_bwd_data_q<T, K, S, PLP, ACT, COEF, EPI>), grid, dim3(DFD_THREADS), lds, st, (const T*)dz, \
-                       (const T*)y, coef, w, (const T*)xin, in_bnstate, (T*)dzin, g, partials, tile_bytes)
+    do { \
+        if constexpr (sizeof(T) == 2 && K == 5 && S == 1) { \
+            if (wide3) { \
+                hipLaunchKernelGGL((k_dw_bwd_data_q<T, K, S, PLP, ACT, COEF, EPI, 3>), grid, dim3(DFD_THREADS), lds, st, (const T*)dz, \
+                                   (const T*)y, coef, w, (const T*)xin, in_bnstate, (T*)dzin, g, partials, tile_bytes); \
+                break; \
+            } \
+        } \
+        hipLaunchKernelGGL((k_dw_bwd_data_q<T, K, S, PLP, ACT, COEF, EPI>), grid, dim3(DFD_THREADS), lds, st, (const T*)dz, \
+                           (const T*)y, coef, w, (const T*)xin, in_bnstate, (T*)dzin, g, partials, tile_bytes); \
+    } while (0)
 #define LAUNCH_BD_P(COEF, EPI) \
     if (S == 2 && plp) LAUNCH_BD(1, COEF, EPI); else LAUNCH_BD(0, COEF, EPI)
     DISPATCH_KS(s->k, s->stride, {
@@ -266,8 +280,8 @@ extern "C" int dfd_dwconv_bwd_data(int dtype, const void* dz, const void* y, con
 // vectors of its kernel row once each, and accumulates its K taps in registers over the
 // whole persistent loop.  partial layout: [workgroup][C][K*K].
 // ===========================================================================
-template <typename T, int K, int S, int ACT, bool PRO, bool COEF>
-__global__ void __launch_bounds__(DFD_THREADS, 4)
+template <typename T, int K, int S, int ACT, bool PRO, bool COEF, int WPC = 4>      // WPC: see k_dw_bwd_data_q (here it only lifts the register cap: the 4-per-CU 5x5 instances spill 32-40 bytes)
+__global__ void __launch_bounds__(DFD_THREADS, WPC)
 k_dw_bwd_weight_q(const T* __restrict__ dz, const T* __restrict__ yraw, const float* __restrict__ coef,
                   const T* __restrict__ xin, const float* __restrict__ in_bnstate, DwQGeom g,
                   float* __restrict__ partials, int tile_bytes) {
@@ -417,9 +431,19 @@ static int dw_bwd_weight_q_t(const void* dz, const void* y, const float* coef, c
     const bool pro = in_bnstate != nullptr, hc = coef != nullptr;
     if (hc && !y) return DFD_EINVAL;
     if (!pro) in_act = DFD_ACT_NONE;
+    const bool wide3 = dwq_occupancy(2, s).lds_budget > 40 * 1024;
 #define LAUNCH_BW(PRO, COEF) \
-    hipLaunchKernelGGL((k_dw_bwd_weight_q<T, K, S, ACT, PRO, COEF>), grid, dim3(DFD_THREADS), lds, st, (const T*)dz, \
-                       (const T*)y, coef, (const T*)xin, in_bnstate, g, ws, tile_bytes)
+    do { \
+        if constexpr (sizeof(T) == 2 && K == 5 && S == 1) { \
+            if (wide3) { \
+                hipLaunchKernelGGL((k_dw_bwd_weight_q<T, K, S, ACT, PRO, COEF, 3>), grid, dim3(DFD_THREADS), lds, st, (const T*)dz, \
+                                   (const T*)y, coef, (const T*)xin, in_bnstate, g, ws, tile_bytes); \
+                break; \
+            } \
+        } \
+        hipLaunchKernelGGL((k_dw_bwd_weight_q<T, K, S, ACT, PRO, COEF>), grid, dim3(DFD_THREADS), lds, st, (const T*)dz, \
+                           (const T*)y, coef, (const T*)xin, in_bnstate, g, ws, tile_bytes); \
+    } while (0)
     DISPATCH_KS(s->k, s->stride, {
         if (pro) {
             DISPATCH_ACT_DW(in_act, { if (hc) LAUNCH_BW(true, true); else LAUNCH_BW(true, false); });
